@@ -1,0 +1,134 @@
+"""Pin the oracle (oracle/*.py) against fixtures produced by running the reference (tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import bigvgan_ref, gpt_ref, sampling_ref
+
+torch.set_grad_enabled(False)
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def gpt_shapes(layers):
+    D = 1280
+    s = {"text_embedding.weight": (12001, D), "mel_embedding.weight": (8194, D),
+         "mel_pos_embedding.emb.weight": (803, D), "text_pos_embedding.emb.weight": (602, D),
+         "gpt.ln_f.weight": (D,), "gpt.ln_f.bias": (D,), "final_norm.weight": (D,), "final_norm.bias": (D,),
+         "mel_head.weight": (8194, D), "mel_head.bias": (8194,)}
+    for i in range(layers):
+        p = f"gpt.h.{i}."
+        s.update({p + "ln_1.weight": (D,), p + "ln_1.bias": (D,), p + "attn.c_attn.weight": (D, 3 * D),
+                  p + "attn.c_attn.bias": (3 * D,), p + "attn.c_proj.weight": (D, D), p + "attn.c_proj.bias": (D,),
+                  p + "ln_2.weight": (D,), p + "ln_2.bias": (D,), p + "mlp.c_fc.weight": (D, 4 * D),
+                  p + "mlp.c_fc.bias": (4 * D,), p + "mlp.c_proj.weight": (4 * D, D), p + "mlp.c_proj.bias": (D,)})
+    return s
+
+
+def gpt_weights(layers):
+    return {k: torch.from_numpy(v) for k, v in synth.fill_state_dict(gpt_shapes(layers), synth.gpt_param).items()}
+
+
+@pytest.mark.parametrize("tag,layers", [("gpt_small", 2), ("gpt_full", 24)])
+def test_gpt_decode_and_latent(tag, layers):
+    g = np.load(os.path.join(G, tag + ".npz"))
+    W = gpt_weights(layers)
+    conds = torch.from_numpy(g["conds"])
+    text = torch.from_numpy(g["text"])
+    emb, mask, pads = gpt_ref.prepare_gpt_inputs(conds, text, W)
+    assert np.array_equal(mask.numpy().astype(np.int64), g["attention_mask"])
+    np.testing.assert_allclose(emb.numpy(), g["prefix_emb"], atol=1e-6)
+    steps = g["logits"].shape[0]
+    logits, past = gpt_ref.decode_prefill(emb, mask, W)
+    errs = [np.abs(logits.numpy() - g["logits"][0]).max()]
+    codes = torch.from_numpy(g["codes"])
+    for s in range(1, steps):
+        mask = torch.cat([mask, torch.ones(mask.shape[0], 1, dtype=torch.bool)], dim=1)
+        logits, past = gpt_ref.decode_step(codes[:, s - 1], s, mask, past, W)
+        errs.append(np.abs(logits.numpy() - g["logits"][s]).max())
+    assert max(errs) < 2e-4, errs
+    # greedy codes with repetition penalty 10 over the fake prefix + generated history
+    hist = g["fake_inputs"]
+    for s in range(steps):
+        sc = sampling_ref.repetition_penalty(g["logits"][s], hist, 10.0)
+        assert np.array_equal(sampling_ref.greedy(sc), g["codes"][:, s])
+        hist = np.concatenate([hist, g["codes"][:, s:s + 1]], axis=1)
+    # latent pass
+    n = int(g["text_lens"][0])
+    lat = gpt_ref.latent_pass(conds, text[0, :n], codes[0], W)
+    np.testing.assert_allclose(lat.numpy(), g["latent_row0"], atol=2e-4)
+
+
+def test_left_pad_invariance_small():
+    """tests/padding_test.py:69-97: a row decoded alone equals the same row inside a left-padded batch."""
+    g = np.load(os.path.join(G, "gpt_small.npz"))
+    W = gpt_weights(2)
+    conds = torch.from_numpy(g["conds"])
+    n = int(g["text_lens"][2])
+    emb, mask, _ = gpt_ref.prepare_gpt_inputs(conds, torch.from_numpy(g["text"][2:3, :n]), W)
+    logits, _ = gpt_ref.decode_prefill(emb, mask, W)
+    np.testing.assert_allclose(logits.numpy(), g["logits_row2_alone_step0"], atol=2e-4)
+    np.testing.assert_allclose(logits.numpy()[0], g["logits"][0][2], atol=2e-4)
+
+
+def test_sampling_processors():
+    g = np.load(os.path.join(G, "sampling.npz"))
+    s = sampling_ref.repetition_penalty(g["logits"], g["history"], 10.0)
+    np.testing.assert_array_equal(s, g["after_penalty"])
+    s = sampling_ref.temperature(s, 0.8)
+    np.testing.assert_allclose(s, g["after_temperature"], rtol=1e-6)
+    s = sampling_ref.top_k(g["after_temperature"], 30)
+    np.testing.assert_array_equal(s, g["after_topk"])
+    s = sampling_ref.top_p(g["after_topk"], 0.8)
+    np.testing.assert_array_equal(np.isfinite(s), np.isfinite(g["after_topp"]))
+    np.testing.assert_array_equal(s[np.isfinite(s)], g["after_topp"][np.isfinite(g["after_topp"])])
+
+
+def test_philox_known_answer():
+    # Random123 known-answer vectors for philox4x32-10
+    assert [int(x) for x in sampling_ref.philox4x32((0, 0, 0, 0), (0, 0))] == \
+        [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert [int(x) for x in sampling_ref.philox4x32((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2)] == \
+        [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert [int(x) for x in sampling_ref.philox4x32((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344),
+                                                    (0xA4093822, 0x299F31D0))] == \
+        [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_activation1d():
+    g = np.load(os.path.join(G, "act1d.npz"))
+    np.testing.assert_allclose(bigvgan_ref.kaiser_sinc_filter(), g["up_filter"], atol=2e-8)
+    np.testing.assert_allclose(bigvgan_ref.kaiser_sinc_filter(), g["down_filter"], atol=2e-8)
+    i = 0
+    while f"x{i}" in g:
+        y = bigvgan_ref.activation1d(torch.from_numpy(g[f"x{i}"]), torch.from_numpy(g[f"alpha{i}"]),
+                                     torch.from_numpy(g[f"beta{i}"]), g["up_filter"], g["down_filter"])
+        np.testing.assert_allclose(y.numpy(), g[f"y{i}"], atol=2e-6)
+        i += 1
+    assert i == 6
+
+
+def bigvgan_sd():
+    import json
+    shapes = json.load(open(os.path.join(G, "bigvgan_shapes.json")))
+    return synth.fill_state_dict({k: tuple(v) for k, v in shapes.items()}, synth.bigvgan_param)
+
+
+def test_bigvgan_forward():
+    g = np.load(os.path.join(G, "bigvgan.npz"))
+    W = bigvgan_ref.Weights(bigvgan_sd())
+    taps = {}
+    spk = torch.from_numpy(g["spk4"]).transpose(1, 2)
+    wav = bigvgan_ref.forward(torch.from_numpy(g["latent4"]), spk, W, taps)
+    np.testing.assert_allclose(taps["conv_pre"].numpy(), g["conv_pre4"], atol=1e-5)
+    for i in range(6):
+        np.testing.assert_allclose(taps[f"up{i}"].numpy(), g[f"up{i}_4"], atol=5e-5)
+        np.testing.assert_allclose(taps[f"stage{i}"].numpy(), g[f"stage{i}_4"], atol=5e-5)
+    np.testing.assert_allclose(wav.numpy(), g["wav4"], atol=2e-5)
+    wav8 = bigvgan_ref.forward(torch.from_numpy(g["latent8"]), spk, W)
+    assert np.sqrt(np.mean((wav8.numpy() - g["wav8"]) ** 2)) < 1e-5
+    spk2 = torch.from_numpy(g["spk_b2"]).transpose(1, 2)
+    wav2 = bigvgan_ref.forward(torch.from_numpy(g["latent_b2"]), spk2, W)
+    assert np.sqrt(np.mean((wav2.numpy() - g["wav_b2"]) ** 2)) < 1e-5
