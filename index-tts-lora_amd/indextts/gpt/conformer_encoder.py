@@ -1,0 +1,79 @@
+"""Conformer conditioning encoder (host-side PyTorch-ROCm; runs once per prompt).
+
+Functional restatement over a flat weight dict that uses the reference's checkpoint key names
+(`conditioning_encoder.*`).  Follows indextts/gpt/conformer_encoder.py:167-290,360-386 (layer order,
+pre-norm, no macaron FFN, final per-layer LayerNorm), conformer/subsampling.py:111-143 (Conv2dSubsampling2),
+conformer/embedding.py (sinusoidal table, x*sqrt(d), pos_emb = table[:T]) and conformer/attention.py
+(rel-pos attention WITHOUT rel_shift: scores = ((q+u)k^T + (q+v)p^T)/sqrt(dk)).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def sinusoid_table(n: int, d: int, device, dtype=torch.float32):
+    pos = torch.arange(n, device=device, dtype=torch.float32)[:, None]
+    div = torch.exp(torch.arange(0, d, 2, device=device, dtype=torch.float32) * (-math.log(10000.0) / d))
+    pe = torch.zeros(n, d, device=device, dtype=torch.float32)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe.to(dtype)
+
+
+def _ln(x, W, p):
+    return F.layer_norm(x, (x.shape[-1],), W[p + ".weight"], W[p + ".bias"], 1e-5)
+
+
+def _lin(x, W, p):
+    return F.linear(x, W[p + ".weight"], W.get(p + ".bias"))
+
+
+def conformer_encode(W: dict, mel_btf: torch.Tensor, lengths: torch.Tensor, heads: int = 8, prefix="conditioning_encoder."):
+    """mel_btf [B,T,100], lengths [B] -> (x [B,T',512], mask [B,1,T'] bool)."""
+    B, T, _ = mel_btf.shape
+    dev = mel_btf.device
+    mask = (torch.arange(T, device=dev)[None, :] < lengths.to(dev)[:, None])[:, None, :]
+    # Conv2dSubsampling2
+    x = F.relu(F.conv2d(mel_btf[:, None], W[prefix + "embed.conv.0.weight"], W[prefix + "embed.conv.0.bias"], stride=2))
+    b, c, t, f = x.shape
+    x = _lin(x.transpose(1, 2).reshape(b, t, c * f), W, prefix + "embed.out.0")
+    mask = mask[:, :, 2::2]
+    d = x.shape[-1]
+    x = x * math.sqrt(d)
+    pos = sinusoid_table(t, d, dev, x.dtype)[None]
+    dk = d // heads
+    n = 0
+    while f"{prefix}encoders.{n}.norm_mha.weight" in W:
+        n += 1
+    for i in range(n):
+        p = f"{prefix}encoders.{i}."
+        # --- rel-pos self attention
+        y = _ln(x, W, p + "norm_mha")
+        q = _lin(y, W, p + "self_attn.linear_q").view(B, t, heads, dk)
+        k = _lin(y, W, p + "self_attn.linear_k").view(B, t, heads, dk).transpose(1, 2)
+        v = _lin(y, W, p + "self_attn.linear_v").view(B, t, heads, dk).transpose(1, 2)
+        pp = F.linear(pos, W[p + "self_attn.linear_pos.weight"]).view(1, t, heads, dk).transpose(1, 2)
+        qu = (q + W[p + "self_attn.pos_bias_u"]).transpose(1, 2)
+        qv = (q + W[p + "self_attn.pos_bias_v"]).transpose(1, 2)
+        sc = (qu @ k.transpose(-1, -2) + qv @ pp.transpose(-1, -2)) / math.sqrt(dk)
+        km = ~mask[:, None]  # [B,1,1,T'] True = padded
+        sc = sc.masked_fill(km, float("-inf"))
+        att = torch.softmax(sc, dim=-1).masked_fill(km, 0.0)
+        y = (att @ v).transpose(1, 2).reshape(B, t, d)
+        x = x + _lin(y, W, p + "self_attn.linear_out")
+        # --- convolution module
+        y = _ln(x, W, p + "norm_conv").transpose(1, 2)
+        y = y.masked_fill(~mask, 0.0)
+        y = F.glu(F.conv1d(y, W[p + "conv_module.pointwise_conv1.weight"], W[p + "conv_module.pointwise_conv1.bias"]), dim=1)
+        wd = W[p + "conv_module.depthwise_conv.weight"]
+        y = F.conv1d(y, wd, W[p + "conv_module.depthwise_conv.bias"], padding=(wd.shape[-1] - 1) // 2, groups=wd.shape[0])
+        y = F.silu(_ln(y.transpose(1, 2), W, p + "conv_module.norm")).transpose(1, 2)
+        y = F.conv1d(y, W[p + "conv_module.pointwise_conv2.weight"], W[p + "conv_module.pointwise_conv2.bias"])
+        y = y.masked_fill(~mask, 0.0)
+        x = x + y.transpose(1, 2)
+        # --- feed forward
+        y = _ln(x, W, p + "norm_ff")
+        y = _lin(F.silu(_lin(y, W, p + "feed_forward.w_1")), W, p + "feed_forward.w_2")
+        x = _ln(x + y, W, p + "norm_final")
+    return _ln(x, W, prefix + "after_norm"), mask
