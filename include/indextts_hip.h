@@ -1,0 +1,194 @@
+/*
+ * indextts_hip.h -- C ABI of libindextts_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the IndexTTS
+ * inference hot path (GPT-2 acoustic-token decoder with KV cache + conditioned BigVGAN vocoder).
+ *
+ * Conventions
+ *   - every entry point returns ITTS_OK (0) or an ITTS_ERR_* code; the message is available from
+ *     itts_last_error() (thread-local).  No exceptions cross the ABI, no hidden device allocations: all
+ *     buffers (outputs, workspaces) are passed in by the caller.  Launches are asynchronous on `stream`
+ *     (a hipStream_t passed as void*; NULL = default stream) and are hipGraph-capturable.
+ *   - `dtype` selects the storage type T of weights / T-typed activations: ITTS_F32, ITTS_BF16, ITTS_F16.
+ *     All accumulation is fp32.  The GPT residual stream, logits and LayerNorm statistics are always fp32.
+ *   - activations of the vocoder are channels-last: [B][T][C] (time-major rows, channels contiguous).
+ *
+ * Reference interfaces replaced (paths relative to the reference repo, CreateIntelligens/index-tts-lora):
+ *   itts_aa_snake_fwd      <- the reference's only native op: anti_alias_activation_cuda.forward(input, up_filter,
+ *                             down_filter, alpha, beta), indextts/BigVGAN/alias_free_activation/cuda/
+ *                             anti_alias_activation.cpp:19-22 / anti_alias_activation_cuda.cu:44-181,214-256, and its
+ *                             torch twin alias_free_torch/act.py:10-28 (the numerical oracle).
+ *   itts_gemm_skinny,
+ *   itts_attn_decode,
+ *   itts_embed_step,
+ *   itts_sample            <- one cached decode step of GPT2InferenceModel.forward (indextts/gpt/model.py:163-193)
+ *                             + the HF generate() logits processors / token selection reached from model.py:710-715.
+ *   itts_gemm_conv,
+ *   itts_attn_prefill,
+ *   itts_layernorm         <- prefill branch (model.py:151-162) and the teacher-forced latent pass
+ *                             UnifiedVoice.forward(return_latent=True) (model.py:548-597, 459-474).
+ *   itts_gemm_conv,
+ *   itts_aa_snake_fwd,
+ *   itts_tanh_pcm          <- BigVGAN.forward / AMPBlock1.forward (indextts/BigVGAN/models.py:203-252, 65-74) and the
+ *                             output stage of IndexTTS.infer (indextts/infer.py:892-893).
+ */
+#ifndef INDEXTTS_HIP_H
+#define INDEXTTS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ITTS_OK 0
+#define ITTS_ERR_INVALID 1 /* bad argument / unsupported shape (nothing was launched) */
+#define ITTS_ERR_LAUNCH 2  /* HIP reported an error at launch */
+
+#define ITTS_F32 0
+#define ITTS_BF16 1
+#define ITTS_F16 2
+
+#define ITTS_ABI_VERSION 1
+
+int itts_abi_version(void);
+const char* itts_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Packed weight layout (shared by itts_gemm_skinny and itts_gemm_conv).  A logical matrix W[K][N] (K = reduction
+ * dim, N = output columns) is stored as 1-KiB blocks in MFMA B-fragment order:
+ *     block(nt, ks) , nt = n/16 in [0, ceil(N/16)), ks = k/KS in [0, ceil(K/KS)),  KS = 32 (bf16/f16) or 16 (f32)
+ *     inside a block: lane l = (g<<4)|c (g = 0..3, c = 0..15) owns 16 contiguous bytes = E elements
+ *                     W[ks*KS + g*E + e][nt*16 + c],  e = 0..E-1,  E = 8 (bf16/f16) or 4 (f32)
+ *     block order: ((tap * NT + nt) * KT + ks), zero-padded in K and N.
+ * itts_pack_weight performs this packing on the device.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int itts_pack_weight(const void* w /* [taps][K][N] T, row-major */, void* packed, int taps, int K, int N, int dtype,
+                     void* stream);
+/* bytes needed for `packed` */
+int64_t itts_packed_bytes(int taps, int K, int N, int dtype);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Anti-aliased periodic activation (Activation1d(SnakeBeta)):
+ *   replicate-pad 5 | x2 zero-stuffed 12-tap FIR (gain 2) | x + sin^2(x e^alpha)/(e^beta + 1e-9) | replicate-pad 5/6
+ *   | 12-tap stride-2 FIR.   alpha/beta are the log-scale per-channel parameters; fp32 accumulation.
+ * layout 0: x,y are [B][T][C] (channels-last, product path);  layout 1: [B][C][T] (the reference op's layout).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int itts_aa_snake_fwd(const void* x, void* y, const float* alpha_log, const float* beta_log, const float* up_filter12,
+                      const float* down_filter12, int B, int T, int C, int dtype, int layout, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Skinny GEMM for the decode step: Y[M][N] = epi( pro(X)[M][K] @ W[K][N] + bias ), M <= 32 (bf16/f16) or <= 16 (f32)
+ * rows per launch (larger M is processed in row chunks by the entry point).  One 16-column tile per workgroup,
+ * the K range split over the workgroup's waves and reduced deterministically through LDS.
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define ITTS_PRO_NONE 0 /* A = x (T [M][K]) */
+#define ITTS_PRO_LN 1   /* A = LayerNorm(h; ln_w, ln_b), h fp32 [M][K], eps 1e-5 */
+#define ITTS_PRO_LN2 2  /* A = LayerNorm(LayerNorm(h; ln_w, ln_b); ln2_w, ln2_b)  (ln_f then final_norm) */
+
+#define ITTS_EPI_STORE 0      /* y (T [M][N]) = v */
+#define ITTS_EPI_GELU_STORE 1 /* y (T [M][N]) = gelu_new(v) */
+#define ITTS_EPI_RESID_F32 2  /* yf (fp32 [M][N]) += v              (residual stream update) */
+#define ITTS_EPI_QKV_CACHE 3  /* cols [0,D): y (T [M][D]) = v ; [D,2D): K cache ; [2D,3D): V cache, at position *pos */
+#define ITTS_EPI_STORE_F32 4  /* yf (fp32 [M][N]) = v               (logits) */
+
+typedef struct itts_skinny_args {
+  int dtype;
+  int M, N, K;
+  const void* wp;    /* packed W */
+  const float* bias; /* [N] or NULL */
+  int pro;
+  const void* x;  /* PRO_NONE */
+  const float* h; /* PRO_LN / PRO_LN2 */
+  const float *ln_w, *ln_b, *ln2_w, *ln2_b;
+  int epi;
+  void* y;
+  float* yf;
+  void* kcache; /* T [M][heads][smax][64] for this layer */
+  void* vcache;
+  const int32_t* pos; /* device scalar: cache row to write */
+  int heads, smax;
+} itts_skinny_args;
+int itts_gemm_skinny(const itts_skinny_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Tiled MFMA GEMM / 1-D convolution, channels-last.
+ *   acc(b,t,n) = sum_{j<taps} sum_{c<Cin} X[b][t + off0 + j*dil][c] * W[j][c][n]      (rows outside [0,Tin) are zero)
+ *   v = scale * (act(acc + bias[n] + bias2[b][n]) + resid(b,t,n))
+ *   y(b,t,n) = (accumulate ? y(b,t,n) : 0) + v
+ * element (b,t,n) of y / resid lives at base + b*y_bstride + (t*N + n + y_shift), and is touched only when
+ * 0 <= t*N + n + y_shift < y_limit.  A plain GEMM is taps=1, off0=0, B=1, Tin=Tout=M.  A transposed convolution with
+ * stride u, kernel 2u (or u) is a 2-tap (1-tap) convolution with N = u*Cout and y_shift = -pad*Cout.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct itts_conv_args {
+  int dtype;
+  int B, Tin, Tout, Cin, N;
+  int taps, off0, dil;
+  const void* x;
+  int64_t x_bstride; /* elements between batches of x */
+  const void* wp;    /* packed [taps][ceil(N/16)][ceil(Cin/KS)] blocks */
+  const float* bias; /* [N] or NULL */
+  const float* bias2; /* [B][N] or NULL */
+  int act;            /* 0 none, 1 gelu_new */
+  void* y;
+  int y_f32; /* y and resid are fp32 instead of T */
+  int64_t y_bstride, y_shift, y_limit;
+  const void* resid; /* same mapping as y, or NULL */
+  int accumulate;
+  float scale;
+} itts_conv_args;
+int itts_gemm_conv(const itts_conv_args* a, void* stream);
+
+/* LayerNorm over the last dim of fp32 rows; y is T (y_f32 = 0) or fp32 (y_f32 = 1).  If w2 != NULL a second LayerNorm
+ * (w2,b2) is applied to the result of the first (ln_f followed by final_norm). */
+int itts_layernorm(const float* h, const float* w, const float* b, const float* w2, const float* b2, void* y, int y_f32,
+                   int M, int D, int dtype, void* stream);
+
+/* h[b][:] = table[tokens[b]][:] + pos_table[*step + pos_add][:]   (fp32 tables, fp32 h) */
+int itts_embed_step(const int32_t* tokens, const float* table, const float* pos_table, const int32_t* step, int pos_add,
+                    float* h, int B, int D, void* stream);
+
+/* Single-query attention over the KV cache (decode).  q,out: T [B][H*64]; caches T [B][H][smax][64];
+ * keys j in [pad[b], *pos] are visible (the key at *pos was just appended).  scale 1/8. */
+int itts_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, const int32_t* pad,
+                     const int32_t* pos, int B, int H, int smax, int dtype, void* stream);
+
+/* Causal self-attention over a whole (left-padded) sequence.  qkv: T [B][S][3*H*64] (q|k|v); out: T [B][S][H*64];
+ * query i sees key j iff pad[b] <= j <= i; rows with no visible key produce zeros.  If kcache/vcache are non-NULL the
+ * k/v rows are also written to the caches (T [B][H][smax][64]) at rows [0,S). */
+int itts_attn_prefill(const void* qkv, void* out, void* kcache, void* vcache, const int32_t* pad, int B, int S, int H,
+                      int smax, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Token selection for one decode step, on device (no host sync in the loop).
+ * state (int32[8], device): [0] = step k (number of tokens already generated), [1] = cache position of the NEXT token
+ * to be fed, [2] = number of finished rows.  The kernel reads logits (fp32 [B][V]), applies repetition penalty over
+ * {extra_ids} U history[b][0..k), temperature, top-k, top-p, draws (Philox4x32-10 keyed by seed, counter (row,k,0,0))
+ * or takes the argmax, then appends to history, updates tokens/finished, and increments state[0], state[1].
+ * Rows already finished, or with force_stop[b] == k, emit stop_token.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct itts_sample_args {
+  const float* logits;
+  int B, V, ldl; /* ldl = row stride of logits */
+  int32_t* tokens;   /* [B] out: token selected this step */
+  int32_t* history;  /* [B][hist_cap] generated tokens */
+  int hist_cap;
+  int32_t* finished; /* [B] */
+  int32_t* state;    /* [8] */
+  const int32_t* extra_ids; /* ids always penalised (the fake prefix: 1 and 8192) */
+  int n_extra;
+  const int32_t* force_stop; /* [B] or NULL */
+  float rep_penalty, temperature, top_p;
+  int top_k, do_sample;
+  uint64_t seed;
+  int stop_token;
+  float* dbg_scores; /* optional [B][V] processed scores (-inf = removed), for parity tests; NULL in production */
+} itts_sample_args;
+int itts_sample(const itts_sample_args* a, void* stream);
+
+/* pcm[b][i] = trunc( clamp(32767 * tanh(x[b][i]), -32767, 32767) ) as int16; also writes fp32 wav if wav != NULL.
+ * apply_tanh = 0 skips the tanh (input already in (-1,1)). */
+int itts_tanh_pcm(const void* x, float* wav, int16_t* pcm, int64_t n, int dtype, int apply_tanh, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INDEXTTS_HIP_H */

@@ -1,0 +1,117 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of the IndexTTS hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/indextts_hip.h"
+
+namespace itts {
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WAVE = 64;
+
+// ---------------------------------------------------------------------------------------------------------------
+// Element traits.  E = elements per 16-byte fragment chunk; KS = 4*E = K extent of one "k-step":
+// one v_mfma_f32_16x16x32 (16-bit types) or four v_mfma_f32_16x16x4_f32 (fp32, exact fmaf-chain numerics).
+// Fragment convention (both operands): lane l = (g<<4)|r holds 16 bytes = elements k0 + g*E + [0,E) of A row r
+// (resp. B column r).  For fp32 the four elements feed four MFMAs, i.e. MFMA i consumes k = k0 + 4g + i; A and B use
+// the same assignment so the product is the plain dot product over the 16 k of the step.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+  static constexpr int E = 4, KS = 16, DT = ITTS_F32;
+  typedef f32x4 frag;
+  static __device__ __forceinline__ float to_f(float v) { return v; }
+  static __device__ __forceinline__ float from_f(float v) { return v; }
+  static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+    return c;
+  }
+};
+template <>
+struct Elem<bf16_t> {
+  static constexpr int E = 8, KS = 32, DT = ITTS_BF16;
+  typedef bf16x8 frag;
+  static __device__ __forceinline__ float to_f(bf16_t v) { return (float)v; }
+  static __device__ __forceinline__ bf16_t from_f(float v) { return (bf16_t)v; }
+  static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct Elem<f16_t> {
+  static constexpr int E = 8, KS = 32, DT = ITTS_F16;
+  typedef f16x8 frag;
+  static __device__ __forceinline__ float to_f(f16_t v) { return (float)v; }
+  static __device__ __forceinline__ f16_t from_f(float v) { return (f16_t)v; }
+  static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename F>
+__device__ __forceinline__ F zero_frag() {
+  F z;
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(F) / sizeof(z[0])); ++i) z[i] = 0;
+  return z;
+}
+
+// 16-byte global / LDS accesses through a POD carrier
+struct __attribute__((aligned(16))) B16 {
+  uint32_t w[4];
+};
+template <typename F>
+__device__ __forceinline__ F ld16(const void* p) {
+  B16 v = *reinterpret_cast<const B16*>(p);
+  return __builtin_bit_cast(F, v);
+}
+template <typename F>
+__device__ __forceinline__ void st16(void* p, F f) {
+  *reinterpret_cast<B16*>(p) = __builtin_bit_cast(B16, f);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// transformers NewGELUActivation (gelu_new): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+__device__ __forceinline__ float gelu_new(float x) {
+  const float k = 0.7978845608028654f;
+  float u = k * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(u));
+}
+
+}  // namespace itts
+
+// host-side helpers -------------------------------------------------------------------------------------------------
+namespace itts {
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+}  // namespace itts
+
+#define ITTS_REQUIRE(cond, ...)        \
+  do {                                 \
+    if (!(cond)) {                     \
+      itts::set_error(__VA_ARGS__);    \
+      return ITTS_ERR_INVALID;         \
+    }                                  \
+  } while (0)

@@ -1,0 +1,263 @@
+// On-device token selection for the decode loop (no host synchronisation per step).
+// Restates the transformers 4.44.2 processors reached from indextts/gpt/model.py:710-715 in their call order:
+// repetition penalty -> temperature -> top-k -> top-p -> softmax -> draw | argmax, plus the EOS/pad bookkeeping of
+// GenerationMixin (finished rows keep emitting pad = stop token).  One workgroup per batch row.
+#include "common.h"
+
+namespace itts {
+
+constexpr int SM_MAXV = 8448;   // logits staged in LDS (33 x 256)
+constexpr int SM_MAXC = 1024;   // candidate cap after top-k
+
+struct SampleParams {
+  const float* logits;
+  int B, V, ldl;
+  int32_t* tokens;
+  int32_t* history;
+  int hist_cap;
+  int32_t* finished;
+  int32_t* state;
+  const int32_t* extra_ids;
+  int n_extra;
+  const int32_t* force_stop;
+  float rep_penalty, temperature, top_p;
+  int top_k, do_sample;
+  uint32_t seed_lo, seed_hi;
+  int stop_token;
+  float* dbg_scores;
+};
+
+__device__ __forceinline__ uint32_t fkey(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// Philox4x32-10 (Salmon et al. 2011); returns the first output word.
+__device__ __forceinline__ uint32_t philox_first(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c0;
+}
+
+__global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
+  __shared__ float sv[SM_MAXV];
+  __shared__ uint32_t flag[SM_MAXV / 32];
+  __shared__ int hist[256];
+  __shared__ float cs[SM_MAXC];
+  __shared__ int ci[SM_MAXC];
+  __shared__ float ss[SM_MAXC];
+  __shared__ int si[SM_MAXC];
+  __shared__ float rv[4];
+  __shared__ int ri[4];
+  __shared__ int sh_n, sh_sel, sh_rem, sh_tok, sh_keep;
+  __shared__ uint32_t sh_prefix;
+
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = p.state[0];
+  const int V = p.V;
+  const float* lg = p.logits + (int64_t)b * p.ldl;
+  const bool forced = p.finished[b] != 0 || (p.force_stop != nullptr && p.force_stop[b] >= 0 && p.force_stop[b] <= k);
+
+  // ---- repetition-penalty membership bitmap
+  for (int i = tid; i < SM_MAXV / 32; i += 256) flag[i] = 0u;
+  if (tid == 0) { sh_n = 0; sh_tok = p.stop_token; sh_keep = 0; }
+  __syncthreads();
+  if (p.rep_penalty != 1.0f) {
+    for (int i = tid; i < p.n_extra; i += 256) {
+      int id = p.extra_ids[i];
+      if (id >= 0 && id < V) atomicOr(&flag[id >> 5], 1u << (id & 31));
+    }
+    int nh = min(k, p.hist_cap);
+    for (int i = tid; i < nh; i += 256) {
+      int id = p.history[(int64_t)b * p.hist_cap + i];
+      if (id >= 0 && id < V) atomicOr(&flag[id >> 5], 1u << (id & 31));
+    }
+  }
+  __syncthreads();
+  const float inv_t = (p.do_sample && p.temperature != 1.0f) ? 1.0f / p.temperature : 1.0f;
+  for (int i = tid; i < V; i += 256) {
+    float v = lg[i];
+    if ((flag[i >> 5] >> (i & 31)) & 1u) v = v < 0.f ? v * p.rep_penalty : v / p.rep_penalty;
+    if (inv_t != 1.0f) v = v / p.temperature;
+    sv[i] = v;
+  }
+  __syncthreads();
+
+  if (!p.do_sample) {
+    // ---- greedy: argmax, lowest id on ties
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += 256) {
+      float v = sv[i];
+      if (v > bv) { bv = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float ov = __shfl_xor(bv, o, 64);
+      int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { rv[wave] = bv; ri[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      float fv = rv[0];
+      int fi = ri[0];
+      for (int w = 1; w < 4; ++w)
+        if (rv[w] > fv || (rv[w] == fv && ri[w] < fi)) { fv = rv[w]; fi = ri[w]; }
+      sh_tok = fi;
+    }
+    if (p.dbg_scores)
+      for (int i = tid; i < V; i += 256) p.dbg_scores[(int64_t)b * V + i] = sv[i];
+    __syncthreads();
+  } else {
+    // ---- top-k threshold by 4-pass radix select on order-preserving keys
+    int kk = p.top_k > 0 ? min(p.top_k, V) : min(V, SM_MAXC);
+    if (kk > SM_MAXC) kk = SM_MAXC;
+    if (tid == 0) { sh_prefix = 0u; sh_rem = kk; }
+    __syncthreads();
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      hist[tid] = 0;
+      __syncthreads();
+      const uint32_t prefix = sh_prefix;
+      const uint32_t himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+      for (int i = tid; i < V; i += 256) {
+        uint32_t key = fkey(sv[i]);
+        if ((key & himask) == (prefix & himask)) atomicAdd(&hist[(key >> shift) & 255], 1);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int rem = sh_rem, cum = 0, bin = 255;
+        for (; bin > 0; --bin) {
+          if (cum + hist[bin] >= rem) break;
+          cum += hist[bin];
+        }
+        sh_rem = rem - cum;
+        sh_prefix = prefix | ((uint32_t)bin << shift);
+      }
+      __syncthreads();
+    }
+    const uint32_t kth = sh_prefix;  // key of the k-th largest score; ties with it are kept (HF: scores < kth removed)
+    for (int i = tid; i < V; i += 256) {
+      if (fkey(sv[i]) >= kth) {
+        int slot = atomicAdd(&sh_n, 1);
+        if (slot < SM_MAXC) { cs[slot] = sv[i]; ci[slot] = i; }
+      }
+    }
+    __syncthreads();
+    const int n = min(sh_n, SM_MAXC);
+    // ---- rank sort: descending score, ascending id
+    for (int i = tid; i < n; i += 256) {
+      float v = cs[i];
+      int id = ci[i];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) {
+        float w = cs[j];
+        rank += (w > v || (w == v && ci[j] < id)) ? 1 : 0;
+      }
+      ss[rank] = v;
+      si[rank] = id;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      // softmax numerators relative to the maximum; cs is reused for them
+      float total = 0.f;
+      for (int i = n - 1; i >= 0; --i) {
+        float e = expf(ss[i] - ss[0]);
+        cs[i] = e;
+        total += e;
+      }
+      int keep = n;
+      if (p.top_p < 1.0f) {
+        // HF TopPLogitsWarper: ascending cumulative probability <= 1 - top_p is removed, at least one token kept
+        float cum = 0.f;
+        const float lim = 1.0f - p.top_p;
+        for (int i = n - 1; i >= 1; --i) {
+          cum += cs[i] / total;
+          if (cum <= lim) keep = i; else break;
+        }
+      }
+      sh_keep = keep;
+      uint32_t x = philox_first((uint32_t)b, (uint32_t)k, 0u, 0u, p.seed_lo, p.seed_hi);
+      float u = (float)(x >> 8) * (1.0f / 16777216.0f);
+      float tot2 = 0.f;
+      for (int i = 0; i < keep; ++i) tot2 += cs[i];
+      float thr = u * tot2, run = 0.f;
+      int pick = si[keep - 1];
+      for (int i = 0; i < keep; ++i) {
+        run += cs[i];
+        if (run > thr) { pick = si[i]; break; }
+      }
+      sh_tok = pick;
+    }
+    __syncthreads();
+    if (p.dbg_scores) {
+      for (int i = tid; i < V; i += 256) p.dbg_scores[(int64_t)b * V + i] = -INFINITY;
+      __syncthreads();
+      for (int i = tid; i < sh_keep; i += 256) p.dbg_scores[(int64_t)b * V + si[i]] = ss[i];
+    }
+  }
+
+  // ---- bookkeeping
+  if (tid == 0) {
+    int tok = forced ? p.stop_token : sh_tok;
+    p.tokens[b] = tok;
+    if (k < p.hist_cap) p.history[(int64_t)b * p.hist_cap + k] = tok;
+    if (tok == p.stop_token && p.finished[b] == 0) {
+      p.finished[b] = 1;
+      atomicAdd(&p.state[2], 1);
+    }
+    __threadfence();
+    int done = atomicAdd(&p.state[3], 1);
+    if (done == p.B - 1) {  // last row of this launch: every workgroup has already read state[0]
+      p.state[3] = 0;
+      p.state[0] = k + 1;
+      p.state[1] = p.state[1] + 1;
+    }
+  }
+}
+
+}  // namespace itts
+
+using namespace itts;
+
+extern "C" int itts_sample(const itts_sample_args* a, void* stream) {
+  ITTS_REQUIRE(a && a->logits && a->tokens && a->history && a->finished && a->state, "itts_sample: null pointer");
+  ITTS_REQUIRE(a->B > 0 && a->V > 0 && a->V <= SM_MAXV && a->ldl >= a->V, "itts_sample: bad shape B=%d V=%d (max %d)", a->B, a->V, SM_MAXV);
+  ITTS_REQUIRE(a->rep_penalty > 0.f && a->temperature > 0.f, "itts_sample: rep_penalty/temperature must be positive");
+  ITTS_REQUIRE(a->top_k <= SM_MAXC, "itts_sample: top_k=%d exceeds %d", a->top_k, SM_MAXC);
+  SampleParams p;
+  p.logits = a->logits;
+  p.B = a->B;
+  p.V = a->V;
+  p.ldl = a->ldl;
+  p.tokens = a->tokens;
+  p.history = a->history;
+  p.hist_cap = a->hist_cap;
+  p.finished = a->finished;
+  p.state = a->state;
+  p.extra_ids = a->extra_ids;
+  p.n_extra = a->extra_ids ? a->n_extra : 0;
+  p.force_stop = a->force_stop;
+  p.rep_penalty = a->rep_penalty;
+  p.temperature = a->temperature;
+  p.top_p = a->top_p;
+  p.top_k = a->top_k;
+  p.do_sample = a->do_sample;
+  p.seed_lo = (uint32_t)(a->seed & 0xFFFFFFFFull);
+  p.seed_hi = (uint32_t)(a->seed >> 32);
+  p.stop_token = a->stop_token;
+  p.dbg_scores = a->dbg_scores;
+  hipLaunchKernelGGL(sample_kernel, dim3(a->B), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("itts_sample");
+}

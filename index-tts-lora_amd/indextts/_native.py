@@ -1,0 +1,222 @@
+"""ctypes binding of libindextts_hip.so (the C ABI declared in include/indextts_hip.h).
+
+The product path has NO CPU/PyTorch fallback for the hot ops: if the shared library is missing or a call fails, an
+exception is raised.  torch is used here only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+F32, BF16, F16 = 0, 1, 2
+PRO_NONE, PRO_LN, PRO_LN2 = 0, 1, 2
+EPI_STORE, EPI_GELU_STORE, EPI_RESID_F32, EPI_QKV_CACHE, EPI_STORE_F32 = 0, 1, 2, 3, 4
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libindextts_hip.so")
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class SkinnyArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("wp", C.c_void_p),
+                ("bias", C.c_void_p), ("pro", C.c_int), ("x", C.c_void_p), ("h", C.c_void_p), ("ln_w", C.c_void_p),
+                ("ln_b", C.c_void_p), ("ln2_w", C.c_void_p), ("ln2_b", C.c_void_p), ("epi", C.c_int),
+                ("y", C.c_void_p), ("yf", C.c_void_p), ("kcache", C.c_void_p), ("vcache", C.c_void_p),
+                ("pos", C.c_void_p), ("heads", C.c_int), ("smax", C.c_int)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("Tin", C.c_int), ("Tout", C.c_int), ("Cin", C.c_int),
+                ("N", C.c_int), ("taps", C.c_int), ("off0", C.c_int), ("dil", C.c_int), ("x", C.c_void_p),
+                ("x_bstride", C.c_int64), ("wp", C.c_void_p), ("bias", C.c_void_p), ("bias2", C.c_void_p),
+                ("act", C.c_int), ("y", C.c_void_p), ("y_f32", C.c_int), ("y_bstride", C.c_int64),
+                ("y_shift", C.c_int64), ("y_limit", C.c_int64), ("resid", C.c_void_p), ("accumulate", C.c_int),
+                ("scale", C.c_float)]
+
+
+class SampleArgs(C.Structure):
+    _fields_ = [("logits", C.c_void_p), ("B", C.c_int), ("V", C.c_int), ("ldl", C.c_int), ("tokens", C.c_void_p),
+                ("history", C.c_void_p), ("hist_cap", C.c_int), ("finished", C.c_void_p), ("state", C.c_void_p),
+                ("extra_ids", C.c_void_p), ("n_extra", C.c_int), ("force_stop", C.c_void_p),
+                ("rep_penalty", C.c_float), ("temperature", C.c_float), ("top_p", C.c_float), ("top_k", C.c_int),
+                ("do_sample", C.c_int), ("seed", C.c_uint64), ("stop_token", C.c_int), ("dbg_scores", C.c_void_p)]
+
+
+_SIGNATURES = {
+    "itts_abi_version": (C.c_int, []),
+    "itts_last_error": (C.c_char_p, []),
+    "itts_packed_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "itts_pack_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "itts_aa_snake_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "itts_gemm_skinny": (C.c_int, [C.POINTER(SkinnyArgs), C.c_void_p]),
+    "itts_gemm_conv": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "itts_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "itts_embed_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                  C.c_int, C.c_void_p]),
+    "itts_attn_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "itts_attn_prefill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "itts_sample": (C.c_int, [C.POINTER(SampleArgs), C.c_void_p]),
+    "itts_tanh_pcm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raise NativeError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(f"{LIB_PATH} not found: build it with `make -C index-tts-lora_amd/csrc` "
+                              f"(or python -c 'import __graft_entry__ as g; g.build()'). There is no fallback path.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.itts_abi_version() != 1:
+            raise NativeError("libindextts_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise NativeError(f"{what} failed (code {rc}): {lib().itts_last_error().decode()}")
+
+
+def dt(t: torch.dtype) -> int:
+    return _DT[t]
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None:
+            if not t.is_cuda:
+                raise NativeError("HIP kernels need device tensors (no CPU fallback)")
+            if not t.is_contiguous():
+                raise NativeError("HIP kernels need contiguous tensors")
+
+
+# ------------------------------------------------------------------------------------------------------ wrappers
+def pack_weight(w: torch.Tensor) -> torch.Tensor:
+    """w [K,N] or [taps,K,N] (device, T) -> packed uint8 buffer in MFMA B-fragment order."""
+    if w.dim() == 2:
+        w = w[None]
+    w = w.contiguous()
+    _dev(w)
+    taps, K, N = w.shape
+    nbytes = lib().itts_packed_bytes(taps, K, N, dt(w.dtype))
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    _check(lib().itts_pack_weight(_p(w), _p(out), taps, K, N, dt(w.dtype), _stream()), "itts_pack_weight")
+    return out
+
+
+def aa_snake(x, alpha_log, beta_log, up_f, down_f, layout=0, out=None):
+    """x [B,T,C] (layout 0) or [B,C,T] (layout 1); filters are HOST float32 tensors/arrays of 12 taps."""
+    _dev(x, alpha_log, beta_log)
+    if layout == 0:
+        B, T, Cn = x.shape
+    else:
+        B, Cn, T = x.shape
+    y = torch.empty_like(x) if out is None else out
+    uf = (C.c_float * 12)(*[float(v) for v in up_f])
+    df = (C.c_float * 12)(*[float(v) for v in down_f])
+    _check(lib().itts_aa_snake_fwd(_p(x), _p(y), _p(alpha_log), _p(beta_log), C.cast(uf, C.c_void_p),
+                                   C.cast(df, C.c_void_p), B, T, Cn, dt(x.dtype), layout, _stream()),
+           "itts_aa_snake_fwd")
+    return y
+
+
+def gemm_skinny(dtype, M, N, K, wp, bias=None, pro=PRO_NONE, x=None, h=None, ln=None, ln2=None, epi=EPI_STORE, y=None,
+                yf=None, kcache=None, vcache=None, pos=None, heads=0, smax=0):
+    a = SkinnyArgs()
+    a.dtype, a.M, a.N, a.K = dt(dtype), M, N, K
+    a.wp, a.bias, a.pro = _p(wp), _p(bias), pro
+    a.x, a.h = _p(x), _p(h)
+    a.ln_w, a.ln_b = (_p(ln[0]), _p(ln[1])) if ln else (None, None)
+    a.ln2_w, a.ln2_b = (_p(ln2[0]), _p(ln2[1])) if ln2 else (None, None)
+    a.epi, a.y, a.yf = epi, _p(y), _p(yf)
+    a.kcache, a.vcache, a.pos, a.heads, a.smax = _p(kcache), _p(vcache), _p(pos), heads, smax
+    _check(lib().itts_gemm_skinny(C.byref(a), _stream()), "itts_gemm_skinny")
+
+
+def gemm_conv(dtype, B, Tin, Tout, Cin, N, wp, x, y, taps=1, off0=0, dil=1, x_bstride=None, bias=None, bias2=None,
+              act=0, y_f32=False, y_bstride=None, y_shift=0, y_limit=None, resid=None, accumulate=False, scale=1.0):
+    a = ConvArgs()
+    a.dtype, a.B, a.Tin, a.Tout, a.Cin, a.N = dt(dtype), B, Tin, Tout, Cin, N
+    a.taps, a.off0, a.dil = taps, off0, dil
+    a.x, a.x_bstride = _p(x), Tin * Cin if x_bstride is None else x_bstride
+    a.wp, a.bias, a.bias2, a.act = _p(wp), _p(bias), _p(bias2), act
+    a.y, a.y_f32 = _p(y), int(y_f32)
+    a.y_bstride = Tout * N if y_bstride is None else y_bstride
+    a.y_shift = y_shift
+    a.y_limit = Tout * N if y_limit is None else y_limit
+    a.resid, a.accumulate, a.scale = _p(resid), int(accumulate), float(scale)
+    _check(lib().itts_gemm_conv(C.byref(a), _stream()), "itts_gemm_conv")
+
+
+def layernorm(h, w, b, out, w2=None, b2=None):
+    """h fp32 [M,D] -> out (T or fp32) [M,D]."""
+    _dev(h, w, b, out)
+    M, D = h.shape
+    y_f32 = out.dtype == torch.float32
+    d = F32 if y_f32 else dt(out.dtype)
+    _check(lib().itts_layernorm(_p(h), _p(w), _p(b), _p(w2), _p(b2), _p(out), int(y_f32), M, D, d, _stream()),
+           "itts_layernorm")
+    return out
+
+
+def embed_step(tokens, table, pos_table, step, pos_add, h):
+    B, D = h.shape
+    _check(lib().itts_embed_step(_p(tokens), _p(table), _p(pos_table), _p(step), pos_add, _p(h), B, D, _stream()),
+           "itts_embed_step")
+
+
+def attn_decode(q, kcache, vcache, out, pad, pos, B, H, smax):
+    _check(lib().itts_attn_decode(_p(q), _p(kcache), _p(vcache), _p(out), _p(pad), _p(pos), B, H, smax, dt(q.dtype),
+                                  _stream()), "itts_attn_decode")
+
+
+def attn_prefill(qkv, out, kcache, vcache, pad, B, S, H, smax):
+    _check(lib().itts_attn_prefill(_p(qkv), _p(out), _p(kcache), _p(vcache), _p(pad), B, S, H, smax, dt(qkv.dtype),
+                                   _stream()), "itts_attn_prefill")
+
+
+def sample(logits, tokens, history, finished, state, extra_ids, force_stop, rep_penalty, temperature, top_k, top_p,
+           do_sample, seed, stop_token, dbg_scores=None):
+    a = SampleArgs()
+    B, V = logits.shape
+    a.logits, a.B, a.V, a.ldl = _p(logits), B, V, logits.stride(0)
+    a.tokens, a.history, a.hist_cap = _p(tokens), _p(history), history.shape[1]
+    a.finished, a.state = _p(finished), _p(state)
+    a.extra_ids, a.n_extra = _p(extra_ids), 0 if extra_ids is None else extra_ids.numel()
+    a.force_stop = _p(force_stop)
+    a.rep_penalty, a.temperature, a.top_p = float(rep_penalty), float(temperature), float(top_p)
+    a.top_k, a.do_sample, a.seed, a.stop_token = int(top_k), int(bool(do_sample)), int(seed), int(stop_token)
+    a.dbg_scores = _p(dbg_scores)
+    _check(lib().itts_sample(C.byref(a), _stream()), "itts_sample")
+
+
+def tanh_pcm(x, wav=None, pcm=None, apply_tanh=True):
+    _dev(x)
+    _check(lib().itts_tanh_pcm(_p(x), _p(wav), _p(pcm), x.numel(), dt(x.dtype), int(apply_tanh), _stream()),
+           "itts_tanh_pcm")

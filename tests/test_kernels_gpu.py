@@ -1,0 +1,366 @@
+"""Op-level parity of every HIP kernel (through the C ABI / ctypes) against plain PyTorch fp32 references and the
+reference-run fixtures.  Tolerances: fp32 kernels use exact-fp32 MFMA (fmaf-chain numerics) -> 1e-4 abs on O(1) data;
+16-bit storage types are compared against the same fp32 reference evaluated on inputs ROUNDED to that type."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def nat():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from indextts import _native
+    _native.lib()
+    return _native
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def ref_pack(w, dtype):
+    """torch restatement of the packed layout documented in include/indextts_hip.h."""
+    taps, K, N = w.shape
+    E = 4 if dtype == torch.float32 else 8
+    KS = 4 * E
+    KT, NT = (K + KS - 1) // KS, (N + 15) // 16
+    wpad = torch.zeros(taps, KT * KS, NT * 16, dtype=w.dtype, device=w.device)
+    wpad[:, :K, :N] = w
+    v = wpad.view(taps, KT, 4, E, NT, 16).permute(0, 4, 1, 2, 5, 3).contiguous()  # [tap][nt][ks][g][c][e]
+    return v.view(-1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_pack_weight(nat, dtype):
+    w = rnd(3, 40, 50, seed=1).to(dtype)
+    got = nat.pack_weight(w).view(dtype)
+    exp = ref_pack(w, dtype)
+    assert torch.equal(got, exp)
+
+
+def test_aa_snake_golden(nat):
+    g = np.load(os.path.join(G, "act1d.npz"))
+    i = 0
+    while f"x{i}" in g:
+        x = torch.from_numpy(g[f"x{i}"]).to(DEV)
+        a = torch.from_numpy(g[f"alpha{i}"]).to(DEV)
+        b = torch.from_numpy(g[f"beta{i}"]).to(DEV)
+        y_ref = torch.from_numpy(g[f"y{i}"]).to(DEV)
+        y1 = nat.aa_snake(x.contiguous(), a, b, g["up_filter"], g["down_filter"], layout=1)
+        assert (y1 - y_ref).abs().max().item() < 2e-5, f"layout1 case {i}"
+        y0 = nat.aa_snake(x.transpose(1, 2).contiguous(), a, b, g["up_filter"], g["down_filter"], layout=0)
+        assert (y0.transpose(1, 2) - y_ref).abs().max().item() < 2e-5, f"layout0 case {i}"
+        for dt_, tol in ((torch.bfloat16, 6e-2), (torch.float16, 8e-3)):
+            xh = x.to(dt_)
+            yh = nat.aa_snake(xh.transpose(1, 2).contiguous(), a, b, g["up_filter"], g["down_filter"], layout=0)
+            yr = nat.aa_snake(xh.float().transpose(1, 2).contiguous(), a, b, g["up_filter"], g["down_filter"], layout=0)
+            assert (yh.float() - yr).abs().max().item() < tol
+        i += 1
+    assert i == 6
+
+
+def test_layernorm(nat):
+    h = rnd(37, 1280, seed=2, scale=3.0) + 0.5
+    w, b = rnd(1280, seed=3), rnd(1280, seed=4)
+    w2, b2 = rnd(1280, seed=5), rnd(1280, seed=6)
+    ref = F.layer_norm(h, (1280,), w, b, 1e-5)
+    out = torch.empty_like(h)
+    nat.layernorm(h, w, b, out)
+    assert (out - ref).abs().max().item() < 2e-5
+    ref2 = F.layer_norm(ref, (1280,), w2, b2, 1e-5)
+    nat.layernorm(h, w, b, out, w2, b2)
+    assert (out - ref2).abs().max().item() < 5e-5
+    outh = torch.empty(37, 1280, dtype=torch.bfloat16, device=DEV)
+    nat.layernorm(h, w, b, outh)
+    assert (outh.float() - ref).abs().max().item() < 0.05
+
+
+def gelu_new(x):
+    return 0.5 * x * (1.0 + torch.tanh(0.7978845608028654 * (x + 0.044715 * x ** 3)))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(1, 1280, 1280), (7, 3840, 1280), (16, 1280, 5120), (32, 5120, 1280), (19, 8194, 1280),
+                                   (32, 1280, 5120), (45, 64, 96)])
+def test_gemm_skinny_plain(nat, dtype, M, N, K):
+    x = rnd(M, K, seed=10).to(dtype)
+    w = (rnd(K, N, seed=11) * 0.05).to(dtype)
+    bias = rnd(N, seed=12)
+    wp = nat.pack_weight(w)
+    ref = x.float() @ w.float() + bias
+    tol = 2e-4 if dtype == torch.float32 else 2e-2
+    y = torch.empty(M, N, dtype=dtype, device=DEV)
+    nat.gemm_skinny(dtype, M, N, K, wp, bias, x=x, epi=nat.EPI_STORE, y=y)
+    assert (y.float() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+    nat.gemm_skinny(dtype, M, N, K, wp, bias, x=x, epi=nat.EPI_GELU_STORE, y=y)
+    assert (y.float() - gelu_new(ref)).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+    yf = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    nat.gemm_skinny(dtype, M, N, K, wp, bias, x=x, epi=nat.EPI_STORE_F32, yf=yf)
+    assert (yf - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+    h0 = rnd(M, N, seed=13)
+    hres = h0.clone()
+    nat.gemm_skinny(dtype, M, N, K, wp, None, x=x, epi=nat.EPI_RESID_F32, yf=hres)
+    assert (hres - (h0 + x.float() @ w.float())).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M", [1, 13, 32])
+def test_gemm_skinny_layernorm(nat, dtype, M):
+    K, N = 1280, 3840
+    h = rnd(M, K, seed=20, scale=2.0) + 0.3
+    lw, lb = 1 + 0.1 * rnd(K, seed=21), 0.1 * rnd(K, seed=22)
+    lw2, lb2 = 1 + 0.1 * rnd(K, seed=23), 0.1 * rnd(K, seed=24)
+    w = (rnd(K, N, seed=25) * 0.03).to(dtype)
+    bias = rnd(N, seed=26)
+    wp = nat.pack_weight(w)
+    xn = F.layer_norm(h, (K,), lw, lb, 1e-5)
+    xn_r = xn.to(dtype).float()  # the kernel rounds the normalised activations to T before the MFMA
+    ref = xn_r @ w.float() + bias
+    y = torch.empty(M, N, dtype=dtype, device=DEV)
+    nat.gemm_skinny(dtype, M, N, K, wp, bias, pro=nat.PRO_LN, h=h, ln=(lw, lb), epi=nat.EPI_STORE, y=y)
+    tol = 3e-4 if dtype == torch.float32 else 3e-2
+    assert (y.float() - ref).abs().max().item() < tol
+    xn2 = F.layer_norm(xn, (K,), lw2, lb2, 1e-5)
+    ref2 = xn2.to(dtype).float() @ w.float() + bias
+    yf = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    nat.gemm_skinny(dtype, M, N, K, wp, bias, pro=nat.PRO_LN2, h=h, ln=(lw, lb), ln2=(lw2, lb2), epi=nat.EPI_STORE_F32,
+                    yf=yf)
+    assert (yf - ref2).abs().max().item() < (5e-4 if dtype == torch.float32 else 4e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_skinny_qkv_cache(nat, dtype):
+    M, D, H, smax = 5, 1280, 20, 40
+    h = rnd(M, D, seed=30)
+    lw, lb = 1 + 0.1 * rnd(D, seed=31), 0.1 * rnd(D, seed=32)
+    w = (rnd(D, 3 * D, seed=33) * 0.03).to(dtype)
+    bias = rnd(3 * D, seed=34)
+    wp = nat.pack_weight(w)
+    ref = F.layer_norm(h, (D,), lw, lb, 1e-5).to(dtype).float() @ w.float() + bias
+    q = torch.zeros(M, D, dtype=dtype, device=DEV)
+    kc = torch.zeros(M, H, smax, 64, dtype=dtype, device=DEV)
+    vc = torch.zeros(M, H, smax, 64, dtype=dtype, device=DEV)
+    pos = torch.tensor([17], dtype=torch.int32, device=DEV)
+    nat.gemm_skinny(dtype, M, 3 * D, D, wp, bias, pro=nat.PRO_LN, h=h, ln=(lw, lb), epi=nat.EPI_QKV_CACHE, y=q,
+                    kcache=kc, vcache=vc, pos=pos, heads=H, smax=smax)
+    tol = 3e-4 if dtype == torch.float32 else 3e-2
+    assert (q.float() - ref[:, :D]).abs().max().item() < tol
+    assert (kc[:, :, 17, :].reshape(M, D).float() - ref[:, D:2 * D]).abs().max().item() < tol
+    assert (vc[:, :, 17, :].reshape(M, D).float() - ref[:, 2 * D:]).abs().max().item() < tol
+    kc[:, :, 17, :] = 0
+    assert kc.abs().max().item() == 0  # nothing else was touched
+
+
+CONV_CASES = [
+    # (B, T, Cin, Cout, k, dil)
+    (1, 37, 1280, 1536, 7, 1), (2, 50, 768, 768, 3, 5), (1, 70, 384, 384, 11, 3), (2, 300, 192, 192, 7, 5),
+    (1, 700, 96, 96, 11, 5), (2, 1000, 48, 48, 3, 1), (1, 1500, 24, 24, 11, 5), (2, 900, 24, 1, 7, 1),
+    (1, 5, 96, 96, 3, 3),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_gemm_conv_conv1d(nat, dtype, case):
+    B, T, Cin, Cout, k, dil = case
+    x = rnd(B, T, Cin, seed=40).to(dtype)  # channels-last
+    w = (rnd(Cout, Cin, k, seed=41) * (1.0 / (Cin * k) ** 0.5)).to(dtype)
+    bias = rnd(Cout, seed=42)
+    pad = (k * dil - dil) // 2
+    ref = F.conv1d(x.float().transpose(1, 2), w.float(), bias, dilation=dil, padding=pad).transpose(1, 2)
+    wp = nat.pack_weight(w.permute(2, 1, 0).contiguous())  # [taps][Cin][Cout]
+    y = torch.empty(B, T, Cout, dtype=dtype, device=DEV)
+    nat.gemm_conv(dtype, B, T, T, Cin, Cout, wp, x, y, taps=k, off0=-pad, dil=dil, bias=bias)
+    tol = {torch.float32: 2e-4, torch.float16: 6e-3, torch.bfloat16: 4e-2}[dtype]
+    assert (y.float() - ref).abs().max().item() < tol
+    # fused epilogue: y = y_prev + scale * (conv + bias + bias2[b] + resid)
+    bias2 = rnd(B, Cout, seed=43)
+    resid = rnd(B, T, Cout, seed=44).to(dtype)
+    yprev = rnd(B, T, Cout, seed=45).to(dtype)
+    y2 = yprev.clone()
+    nat.gemm_conv(dtype, B, T, T, Cin, Cout, wp, x, y2, taps=k, off0=-pad, dil=dil, bias=bias, bias2=bias2, resid=resid,
+                  accumulate=True, scale=1.0 / 3.0)
+    ref2 = yprev.float() + (ref + bias2[:, None, :] + resid.float()) / 3.0
+    assert (y2.float() - ref2).abs().max().item() < 2 * tol
+
+
+UPS = [(1, 9, 1536, 768, 8, 4), (2, 33, 768, 384, 8, 4), (1, 100, 384, 192, 4, 4), (2, 130, 192, 96, 4, 4),
+       (1, 500, 96, 48, 4, 2), (2, 700, 48, 24, 4, 2)]
+
+
+def convtr_as_conv(w, u):
+    """ConvTranspose1d weight [Cin,Cout,k] (stride u, padding (k-u)//2) -> ([taps][Cin][u*Cout], off0, y_shift).
+
+    t' + pad = q*u + s:  y[t'] = x[q] W[:,:,s] + x[q-1] W[:,:,s+u]   (second term only when k = 2u)."""
+    Cin, Cout, k = w.shape
+    pad = (k - u) // 2
+    if k == u:
+        taps = w.permute(2, 0, 1).reshape(1, u, Cin, Cout).permute(0, 2, 1, 3).reshape(1, Cin, u * Cout)
+        return taps.contiguous(), 0, -pad * Cout
+    assert k == 2 * u
+    lo = w[:, :, :u].permute(0, 2, 1).reshape(Cin, u * Cout)   # pairs with x[q]
+    hi = w[:, :, u:].permute(0, 2, 1).reshape(Cin, u * Cout)   # pairs with x[q-1]
+    return torch.stack([hi, lo], 0).contiguous(), -1, -pad * Cout
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("case", UPS)
+def test_gemm_conv_transposed(nat, dtype, case):
+    B, T, Cin, Cout, k, u = case
+    x = rnd(B, T, Cin, seed=50).to(dtype)
+    w = (rnd(Cin, Cout, k, seed=51) * (1.0 / (Cin * k / u) ** 0.5)).to(dtype)
+    bias = rnd(Cout, seed=52)
+    ref = F.conv_transpose1d(x.float().transpose(1, 2), w.float(), bias, stride=u, padding=(k - u) // 2).transpose(1, 2)
+    Tout = T * u
+    assert ref.shape[1] == Tout
+    wt, off0, y_shift = convtr_as_conv(w, u)
+    wp = nat.pack_weight(wt)
+    y = torch.full((B, Tout, Cout), 7.0, dtype=dtype, device=DEV)
+    rows = T + 1 if wt.shape[0] == 2 else T
+    nat.gemm_conv(dtype, B, T, rows, Cin, u * Cout, wp, x, y, taps=wt.shape[0], off0=off0, dil=1,
+                  bias=bias.repeat(u), y_bstride=Tout * Cout, y_shift=y_shift, y_limit=Tout * Cout)
+    tol = 2e-4 if dtype == torch.float32 else 6e-3
+    assert (y.float() - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_conv_plain_gemm_residual(nat, dtype):
+    M, K, N = 300, 1280, 3840
+    x = rnd(M, K, seed=60).to(dtype)
+    w = (rnd(K, N, seed=61) * 0.03).to(dtype)
+    bias = rnd(N, seed=62)
+    wp = nat.pack_weight(w)
+    ref = x.float() @ w.float() + bias
+    y = torch.empty(M, N, dtype=dtype, device=DEV)
+    nat.gemm_conv(dtype, 1, M, M, K, N, wp, x, y, bias=bias, act=1)
+    tol = 3e-4 if dtype == torch.float32 else 3e-2
+    assert (y.float() - gelu_new(ref)).abs().max().item() < tol
+    w2 = (rnd(K, K, seed=63) * 0.03).to(dtype)
+    wp2 = nat.pack_weight(w2)
+    h0 = rnd(M, K, seed=64)
+    h = h0.clone()
+    nat.gemm_conv(dtype, 1, M, M, K, K, wp2, x, h, bias=bias[:K].contiguous(), y_f32=True, resid=h)
+    assert (h - (h0 + x.float() @ w2.float() + bias[:K])).abs().max().item() < 3e-4 * (1 if dtype == torch.float32 else 50)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attn_decode(nat, dtype):
+    B, H, smax = 5, 20, 200
+    pos = 150
+    q = rnd(B, H * 64, seed=70).to(dtype)
+    kc = rnd(B, H, smax, 64, seed=71).to(dtype)
+    vc = rnd(B, H, smax, 64, seed=72).to(dtype)
+    pad = torch.tensor([0, 3, 17, 149, 150], dtype=torch.int32, device=DEV)
+    out = torch.empty(B, H * 64, dtype=dtype, device=DEV)
+    nat.attn_decode(q, kc, vc, out, pad, torch.tensor([pos], dtype=torch.int32, device=DEV), B, H, smax)
+    qf = q.float().view(B, H, 1, 64)
+    sc = (qf @ kc.float().transpose(-1, -2)) / 8.0
+    j = torch.arange(smax, device=DEV)[None, None, None, :]
+    vis = (j <= pos) & (j >= pad[:, None, None, None])
+    sc = sc.masked_fill(~vis, float("-inf"))
+    ref = (torch.softmax(sc, -1) @ vc.float()).view(B, H * 64)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert (out.float() - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("S", [47, 130])
+def test_attn_prefill(nat, dtype, S):
+    B, H, smax = 3, 20, 160
+    D = H * 64
+    qkv = rnd(B, S, 3 * D, seed=80).to(dtype)
+    pad = torch.tensor([0, 5, 40], dtype=torch.int32, device=DEV)
+    out = torch.empty(B, S, D, dtype=dtype, device=DEV)
+    kc = torch.zeros(B, H, smax, 64, dtype=dtype, device=DEV)
+    vc = torch.zeros(B, H, smax, 64, dtype=dtype, device=DEV)
+    nat.attn_prefill(qkv, out, kc, vc, pad, B, S, H, smax)
+    q, k, v = (t.float().view(B, S, H, 64).transpose(1, 2) for t in qkv.split(D, dim=-1))
+    sc = (q @ k.transpose(-1, -2)) / 8.0
+    i = torch.arange(S, device=DEV)
+    vis = (i[None, :] <= i[:, None])[None, None] & (i[None, None, None, :] >= pad[:, None, None, None])
+    sc = sc.masked_fill(~vis, float("-inf"))
+    anyv = vis.any(-1, keepdim=True)
+    pr = torch.where(anyv, torch.softmax(sc.masked_fill(~anyv, 0.0), -1), torch.zeros_like(sc))
+    ref = (pr @ v).transpose(1, 2).reshape(B, S, D)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert (out.float() - ref).abs().max().item() < tol
+    assert torch.equal(kc[:, :, :S].float(), k)
+    assert torch.equal(vc[:, :, :S].float(), v)
+    out2 = torch.empty_like(out)
+    nat.attn_prefill(qkv, out2, None, None, pad, B, S, H, smax)
+    assert torch.equal(out, out2)
+
+
+def test_sample_matches_hf_fixture(nat):
+    from oracle import sampling_ref
+    g = np.load(os.path.join(G, "sampling.npz"))
+    logits = torch.from_numpy(g["logits"]).to(DEV)
+    B, V = logits.shape
+    gen = g["history"][:, 31:]  # generated part; the fake prefix contributes ids {1, 8192}
+    cap = 64
+    history = torch.zeros(B, cap, dtype=torch.int32, device=DEV)
+    history[:, :gen.shape[1]] = torch.from_numpy(gen).to(torch.int32).to(DEV)
+    extra = torch.tensor([1, 8192], dtype=torch.int32, device=DEV)
+    for do_sample in (True, False):
+        tokens = torch.zeros(B, dtype=torch.int32, device=DEV)
+        finished = torch.zeros(B, dtype=torch.int32, device=DEV)
+        state = torch.zeros(8, dtype=torch.int32, device=DEV)
+        state[0] = gen.shape[1]
+        state[1] = 100
+        dbg = torch.empty(B, V, dtype=torch.float32, device=DEV)
+        nat.sample(logits, tokens, history.clone(), finished, state, extra, None, 10.0, 0.8, 30, 0.8, do_sample, 1234,
+                   8193, dbg)
+        torch.cuda.synchronize()
+        st = state.cpu().numpy()
+        assert st[0] == gen.shape[1] + 1 and st[1] == 101 and st[3] == 0
+        d = dbg.cpu().numpy()
+        if do_sample:
+            exp = g["after_topp"]
+            assert np.array_equal(np.isfinite(d), np.isfinite(exp))
+            np.testing.assert_allclose(d[np.isfinite(d)], exp[np.isfinite(exp)], rtol=1e-6)
+            for b in range(B):
+                u = sampling_ref.uniform01(1234, b, gen.shape[1])
+                assert int(tokens[b]) == sampling_ref.pick(exp[b], u)
+        else:
+            np.testing.assert_allclose(d, g["after_penalty"], rtol=1e-6)
+            assert np.array_equal(tokens.cpu().numpy(), np.argmax(g["after_penalty"], -1))
+
+
+def test_sample_finish_and_force(nat):
+    B, V = 3, 8194
+    logits = torch.zeros(B, V, device=DEV)
+    logits[0, 8193] = 50.0  # row 0 emits the stop token
+    logits[1, 77] = 50.0
+    logits[2, 99] = 50.0
+    tokens = torch.zeros(B, dtype=torch.int32, device=DEV)
+    history = torch.zeros(B, 16, dtype=torch.int32, device=DEV)
+    finished = torch.zeros(B, dtype=torch.int32, device=DEV)
+    state = torch.zeros(8, dtype=torch.int32, device=DEV)
+    force = torch.tensor([-1, -1, 1], dtype=torch.int32, device=DEV)
+    for step in range(3):
+        nat.sample(logits, tokens, history, finished, state, None, force, 1.0, 1.0, 30, 0.8, False, 0, 8193)
+    torch.cuda.synchronize()
+    assert history[:, :3].cpu().tolist() == [[8193, 8193, 8193], [77, 77, 77], [99, 8193, 8193]]
+    assert finished.cpu().tolist() == [1, 0, 1]
+    assert state.cpu().tolist()[:4] == [3, 3, 2, 0]
+
+
+def test_tanh_pcm(nat):
+    x = rnd(3, 1000, seed=90, scale=2.0)
+    wav = torch.empty_like(x)
+    pcm = torch.empty(3, 1000, dtype=torch.int16, device=DEV)
+    nat.tanh_pcm(x, wav, pcm)
+    ref = torch.tanh(x)
+    assert (wav - ref).abs().max().item() < 2e-6
+    exp = torch.clamp(32767 * wav, -32767.0, 32767.0).cpu().numpy().astype(np.int16)
+    assert np.array_equal(pcm.cpu().numpy(), exp)
