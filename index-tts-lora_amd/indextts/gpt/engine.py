@@ -1,0 +1,210 @@
+"""GPT-2 acoustic-token decoder engine on the HIP kernels (prefill, cached decode loop, teacher-forced latent pass).
+
+Replaces, for the inference path, HF `GPT2Model` + `GenerationMixin.generate` as wired by the reference in
+indextts/gpt/model.py:125-205 (GPT2InferenceModel.forward), :263-286 (build_hf_gpt_transformer) and :459-474
+(get_logits).  Host code only does tensor plumbing (torch device memory, streams, CUDA-graph capture/replay); every
+FLOP of the transformer runs in libindextts_hip.so.
+
+Data layout in HBM
+  * weights: packed MFMA B-fragment blocks (include/indextts_hip.h), dtype T (fp32 parity mode / bf16 speed mode);
+    LayerNorm parameters, biases and embedding tables stay fp32.
+  * residual stream h: fp32 [rows][D].  T-typed scratch: xn, qkv, attn, ffn.
+  * KV cache: T [L][Bmax][H][Smax][64], K and V separate; all rows of a (left-padded) batch share one write position.
+  * decode-loop state (int32[8], device): step k, cache position, finished count, arrival counter.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _native as nat
+
+
+class GPTEngine:
+    def __init__(self, W: dict, layers: int, model_dim: int, heads: int, dtype=torch.bfloat16, device="cuda",
+                 start_mel_token=8192, stop_mel_token=8193):
+        assert model_dim == heads * 64, "kernels are specialised for head_dim 64"
+        self.L, self.D, self.H = layers, model_dim, heads
+        self.dtype, self.device = dtype, torch.device(device)
+        self.start_mel, self.stop_mel = start_mel_token, stop_mel_token
+        dev = self.device
+
+        def f32(k):
+            return W[k].detach().to(dev, torch.float32).contiguous()
+
+        def packed(w_kn):
+            return nat.pack_weight(w_kn.detach().to(dev, dtype).contiguous())
+
+        self.layers = []
+        for i in range(layers):
+            p = f"gpt.h.{i}."
+            self.layers.append(dict(
+                ln1=(f32(p + "ln_1.weight"), f32(p + "ln_1.bias")),
+                ln2=(f32(p + "ln_2.weight"), f32(p + "ln_2.bias")),
+                w_qkv=packed(W[p + "attn.c_attn.weight"]), b_qkv=f32(p + "attn.c_attn.bias"),
+                w_o=packed(W[p + "attn.c_proj.weight"]), b_o=f32(p + "attn.c_proj.bias"),
+                w_fc=packed(W[p + "mlp.c_fc.weight"]), b_fc=f32(p + "mlp.c_fc.bias"),
+                w_pr=packed(W[p + "mlp.c_proj.weight"]), b_pr=f32(p + "mlp.c_proj.bias"),
+            ))
+        self.ln_f = (f32("gpt.ln_f.weight"), f32("gpt.ln_f.bias"))
+        self.final_norm = (f32("final_norm.weight"), f32("final_norm.bias"))
+        self.V = W["mel_head.weight"].shape[0]
+        self.w_head = packed(W["mel_head.weight"].t())
+        self.b_head = f32("mel_head.bias")
+        self.mel_emb = f32("mel_embedding.weight")
+        self.mel_pos = f32("mel_pos_embedding.emb.weight")
+        self.text_emb = f32("text_embedding.weight")
+        self.text_pos = f32("text_pos_embedding.emb.weight")
+        self.extra_ids = torch.tensor([1, start_mel_token], dtype=torch.int32, device=dev)  # fake prefix ids (model.py:658-667)
+        self._cap_b = self._cap_s = 0
+        self._graphs = {}
+        self.weight_bytes = sum(t.numel() * t.element_size() for l in self.layers for t in
+                                (l["w_qkv"], l["w_o"], l["w_fc"], l["w_pr"])) + self.w_head.numel()
+
+    # ------------------------------------------------------------------------------------------------ buffers
+    def _ensure(self, B: int, smax: int):
+        if B <= self._cap_b and smax <= self._cap_s:
+            return
+        B = max(B, self._cap_b)
+        smax = max(smax, self._cap_s)
+        smax = (smax + 63) // 64 * 64
+        if smax > 2048:
+            raise ValueError(f"context {smax} exceeds the decode-attention limit of 2048")
+        dev, T = self.device, self.dtype
+        self.kc = torch.zeros(self.L, B, self.H, smax, 64, dtype=T, device=dev)
+        self.vc = torch.zeros(self.L, B, self.H, smax, 64, dtype=T, device=dev)
+        self.h = torch.zeros(B, self.D, dtype=torch.float32, device=dev)
+        self.q = torch.zeros(B, self.D, dtype=T, device=dev)
+        self.a = torch.zeros(B, self.D, dtype=T, device=dev)
+        self.f = torch.zeros(B, 4 * self.D, dtype=T, device=dev)
+        self.logits = torch.zeros(B, self.V, dtype=torch.float32, device=dev)
+        self.tokens = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.finished = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.pad = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.force_stop = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        self.state = torch.zeros(8, dtype=torch.int32, device=dev)
+        self.history = torch.zeros(B, 2048, dtype=torch.int32, device=dev)
+        self._cap_b, self._cap_s = B, smax
+        self._graphs.clear()
+
+    # ------------------------------------------------------------------------------------------------ big-M passes
+    def _blocks_full(self, h, B, S, pad, use_cache):
+        """All transformer blocks over h fp32 [B*S, D] (in place).  pad: int32 [B] device or None."""
+        T, D, H = self.dtype, self.D, self.H
+        M = B * S
+        dev = self.device
+        xn = torch.empty(M, D, dtype=T, device=dev)
+        qkv = torch.empty(M, 3 * D, dtype=T, device=dev)
+        att = torch.empty(M, D, dtype=T, device=dev)
+        ff = torch.empty(M, 4 * D, dtype=T, device=dev)
+        for i, l in enumerate(self.layers):
+            nat.layernorm(h, l["ln1"][0], l["ln1"][1], xn)
+            nat.gemm_conv(T, 1, M, M, D, 3 * D, l["w_qkv"], xn, qkv, bias=l["b_qkv"])
+            nat.attn_prefill(qkv, att, self.kc[i] if use_cache else None, self.vc[i] if use_cache else None, pad, B, S, H,
+                             self._cap_s)
+            nat.gemm_conv(T, 1, M, M, D, D, l["w_o"], att, h, bias=l["b_o"], y_f32=True, resid=h)
+            nat.layernorm(h, l["ln2"][0], l["ln2"][1], xn)
+            nat.gemm_conv(T, 1, M, M, D, 4 * D, l["w_fc"], xn, ff, bias=l["b_fc"], act=1)
+            nat.gemm_conv(T, 1, M, M, 4 * D, D, l["w_pr"], ff, h, bias=l["b_pr"], y_f32=True, resid=h)
+        return h
+
+    def _head(self, h_rows, B):
+        nat.gemm_skinny(self.dtype, B, self.V, self.D, self.w_head, self.b_head, pro=nat.PRO_LN2, h=h_rows, ln=self.ln_f,
+                        ln2=self.final_norm, epi=nat.EPI_STORE_F32, yf=self.logits)
+
+    def prefill(self, prefix_emb: torch.Tensor, pad: torch.Tensor, max_new: int):
+        """prefix_emb fp32 [B,P,D] (left-padded with zeros), pad int [B].  Runs prefix + start token (mel position 0,
+        model.py:152-162), fills the KV cache rows [0,P], leaves logits of the last position in self.logits."""
+        B, P, D = prefix_emb.shape
+        S = P + 1
+        self._ensure(B, S + max_new + 1)
+        start = self.mel_emb[self.start_mel] + self.mel_pos[0]
+        emb = torch.cat([prefix_emb.to(self.device, torch.float32), start.expand(B, 1, D)], dim=1).contiguous()
+        self.pad[:B] = pad.to(self.device, torch.int32)
+        h = self._blocks_full(emb.view(B * S, D), B, S, self.pad, True)
+        last = h.view(B, S, D)[:, -1, :].contiguous()
+        self._head(last, B)
+        self.state.zero_()
+        self.state[1] = S - 1
+        self.finished[:B] = 0
+        self.history[:B].zero_()
+        self._B, self._S = B, S
+        return self.logits[:B]
+
+    def latent(self, emb: torch.Tensor) -> torch.Tensor:
+        """Teacher-forced pass (model.py:459-474): emb fp32 [B,S,D] (right-padded rows allowed) ->
+        final_norm(ln_f(blocks(emb))) fp32 [B,S,D]."""
+        B, S, D = emb.shape
+        self._ensure(1, 64)
+        h = emb.to(self.device, torch.float32).contiguous().view(B * S, D).clone()
+        self._blocks_full(h, B, S, None, False)
+        out = torch.empty_like(h)
+        nat.layernorm(h, self.ln_f[0], self.ln_f[1], out, self.final_norm[0], self.final_norm[1])
+        return out.view(B, S, D)
+
+    # ------------------------------------------------------------------------------------------------ decode loop
+    def _sample(self, B, sp, dbg=None):
+        nat.sample(self.logits[:B], self.tokens, self.history, self.finished, self.state, self.extra_ids, self.force_stop,
+                   sp["repetition_penalty"], sp["temperature"], sp["top_k"], sp["top_p"], sp["do_sample"], sp["seed"],
+                   self.stop_mel, dbg)
+
+    def _step_kernels(self, B, sp):
+        """One cached decode step (model.py:163-193): embed token k at mel position k+1, 24 blocks, head, sample."""
+        T, D, H = self.dtype, self.D, self.H
+        step, pos = self.state[0:1], self.state[1:2]
+        nat.embed_step(self.tokens, self.mel_emb, self.mel_pos, step, 1, self.h[:B])
+        for i, l in enumerate(self.layers):
+            nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv"], l["b_qkv"], pro=nat.PRO_LN, h=self.h, ln=l["ln1"],
+                            epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i], vcache=self.vc[i], pos=pos, heads=H,
+                            smax=self._cap_s)
+            nat.attn_decode(self.q, self.kc[i], self.vc[i], self.a, self.pad, pos, B, H, self._cap_s)
+            nat.gemm_skinny(T, B, D, D, l["w_o"], l["b_o"], x=self.a, epi=nat.EPI_RESID_F32, yf=self.h)
+            nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], pro=nat.PRO_LN, h=self.h, ln=l["ln2"],
+                            epi=nat.EPI_GELU_STORE, y=self.f)
+            nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], l["b_pr"], x=self.f, epi=nat.EPI_RESID_F32, yf=self.h)
+        self._head(self.h, B)
+        self._sample(B, sp)
+
+    def decode(self, max_new: int, sp: dict, force_stop=None, use_graph=True, check_every=16, return_logits=False):
+        """Run the sampling loop after prefill().  Returns codes int64 [B, n] padded with the stop token
+        (HF generate semantics: rows that emitted EOS keep emitting pad = EOS)."""
+        B = self._B
+        if self._S + max_new + 1 > self._cap_s:
+            raise ValueError("decode(): max_new exceeds the capacity reserved by prefill()")
+        if force_stop is None:
+            self.force_stop[:B] = -1
+        else:
+            self.force_stop[:B] = torch.as_tensor(force_stop, dtype=torch.int32).to(self.device)
+        logits_trace = [self.logits[:B].clone()] if return_logits else None
+        self._sample(B, sp)  # token 1 from the prefill logits
+        n = 1
+        graph = None
+        while n < max_new:
+            if use_graph and graph is None and n >= 2:
+                graph = self._get_graph(B, sp)
+            if graph is not None:
+                graph.replay()
+            else:
+                self._step_kernels(B, sp)
+            n += 1
+            if return_logits:
+                logits_trace.append(self.logits[:B].clone())
+            if n % check_every == 0 and int(self.state[2].item()) >= B:
+                break
+        codes = self.history[:B, :n].to(torch.int64)
+        return (codes, torch.stack(logits_trace, 0)) if return_logits else codes
+
+    def _get_graph(self, B, sp):
+        key = (B, tuple(sorted(sp.items())))
+        g = self._graphs.get(key)
+        if g is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step_kernels(B, sp)
+            self._graphs[key] = g
+        return g
+
+    def step_bytes(self, B: int, ctx: int) -> int:
+        """Algorithmic HBM bytes of one decode step: weights once + KV read + KV append."""
+        es = 4 if self.dtype == torch.float32 else 2
+        kv = self.L * 2 * self.D * es
+        return self.weight_bytes + B * ctx * kv + B * kv
