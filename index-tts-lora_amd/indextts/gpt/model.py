@@ -1,0 +1,217 @@
+"""UnifiedVoice: the IndexTTS GPT wrapper (drop-in surface of indextts/gpt/model.py:312-720, inference only).
+
+Kept from the reference: constructor keywords (`UnifiedVoice(**cfg.gpt)`), `load_state_dict/state_dict` with the
+reference key names, `.eval()/.half()/.bfloat16()/.to()`, `post_init_gpt2_config(use_deepspeed, kv_cache, half)`,
+`get_conditioning`, `prepare_gpt_inputs`, `inference_speech(...)` (HF-generate keyword arguments) and
+`forward(..., return_latent=True)`.  The transformer itself runs in GPTEngine (HIP kernels); the Conformer+Perceiver
+conditioner is host-side PyTorch-ROCm.  Training paths (losses, LoRA) are out of scope.
+"""
+from __future__ import annotations
+
+import warnings
+
+import torch
+import torch.nn.functional as F
+
+from .conformer_encoder import conformer_encode
+from .engine import GPTEngine
+from .perceiver import perceiver_resample
+
+
+class UnifiedVoice:
+    def __init__(self, layers=8, model_dim=512, heads=8, max_text_tokens=120, max_mel_tokens=250,
+                 max_conditioning_inputs=1, mel_length_compression=1024, number_text_tokens=256, start_text_token=0,
+                 stop_text_token=1, number_mel_codes=8194, start_mel_token=8192, stop_mel_token=8193,
+                 train_solo_embeddings=False, use_mel_codes_as_input=True, checkpointing=True, types=1,
+                 activation_function=None, condition_num_latent=32, condition_type="perceiver", condition_module=None):
+        if condition_type != "conformer_perceiver":
+            raise NotImplementedError("only condition_type='conformer_perceiver' is on the IndexTTS inference path")
+        if activation_function not in (None, "gelu_new"):
+            raise NotImplementedError("only gelu_new is supported")
+        self.layers, self.model_dim, self.heads = layers, model_dim, heads
+        self.max_text_tokens, self.max_mel_tokens = max_text_tokens, max_mel_tokens
+        self.max_conditioning_inputs = max_conditioning_inputs
+        self.mel_length_compression = mel_length_compression
+        self.number_text_tokens, self.number_mel_codes = number_text_tokens, number_mel_codes
+        self.start_text_token, self.stop_text_token = start_text_token, stop_text_token
+        self.start_mel_token, self.stop_mel_token = start_mel_token, stop_mel_token
+        self.condition_type, self.cond_num = condition_type, condition_num_latent
+        self.condition_module = dict(condition_module or {})
+        self.mean_condition = None
+        self.device = torch.device("cpu")
+        self.dtype = torch.float32
+        self._sd = {}
+        self._cond_w = None
+        self.engine: GPTEngine | None = None
+        self.inference_model = None
+
+    # ---- nn.Module-like surface -------------------------------------------------------------------------------
+    def load_state_dict(self, sd, strict=False):
+        self._sd = {k: v.detach() for k, v in sd.items() if not k.startswith("inference_model.")}
+        self._cond_w, self.engine = None, None
+        return self
+
+    def state_dict(self):
+        return dict(self._sd)
+
+    def parameters(self):
+        return iter(self._sd.values())
+
+    def to(self, *args, **kw):
+        for a in list(args) + list(kw.values()):
+            if isinstance(a, torch.dtype):
+                self.dtype = a
+            elif isinstance(a, (str, torch.device)):
+                self.device = torch.device(a)
+        self._cond_w, self.engine = None, None
+        return self
+
+    def half(self):
+        # the HIP GPT kernels implement fp32 and bf16; a request for fp16 is served in bf16 (same storage width,
+        # fp32 accumulation) -- the reference makes the same substitution when bf16 is available (infer.py:287-293)
+        return self.to(torch.bfloat16)
+
+    def bfloat16(self):
+        return self.to(torch.bfloat16)
+
+    def float(self):
+        return self.to(torch.float32)
+
+    def eval(self):
+        return self
+
+    def post_init_gpt2_config(self, use_deepspeed=False, kv_cache=False, half=False):
+        """Reference: builds GPT2InferenceModel (model.py:395-432).  Here: packs the weights into the HIP engine."""
+        if self.device.type != "cuda":
+            raise RuntimeError("UnifiedVoice runs on the HIP kernels only: move it to a cuda device (no CPU fallback)")
+        need = ["gpt.ln_f.weight", "mel_head.weight", "mel_embedding.weight", "text_embedding.weight"]
+        missing = [k for k in need if k not in self._sd]
+        if missing:
+            raise RuntimeError(f"checkpoint is missing {missing}")
+        self.engine = GPTEngine(self._sd, self.layers, self.model_dim, self.heads, dtype=self.dtype, device=self.device,
+                                start_mel_token=self.start_mel_token, stop_mel_token=self.stop_mel_token)
+        self.inference_model = self.engine
+        return self
+
+    def _cond_weights(self):
+        if self._cond_w is None:
+            self._cond_w = {k: v.to(self.device, torch.float32) for k, v in self._sd.items()
+                            if k.startswith(("conditioning_encoder.", "perceiver_encoder.")) and not k.endswith("pos_enc.pe")}
+        return self._cond_w
+
+    # ---- conditioning / prefix --------------------------------------------------------------------------------
+    def get_conditioning(self, speech_conditioning_input, cond_mel_lengths=None, speaker_ids=None):
+        """model.py:487-546 (conformer_perceiver branch, plus the stored mean_condition_{id} shortcut)."""
+        if speaker_ids is not None and speech_conditioning_input is None:
+            out = []
+            for sid in speaker_ids:
+                c = getattr(self, f"mean_condition_{sid}", None)
+                if c is None:
+                    raise ValueError(f"no stored condition for speaker {sid}")
+                c = c.to(self.device, torch.float32)
+                out.append(c[None] if c.ndim == 2 else (c[0] if c.ndim == 4 else c))
+            return torch.cat(out, dim=0)
+        if self.mean_condition is not None and speech_conditioning_input is None:
+            return self.mean_condition.to(self.device).expand(1, -1, -1)
+        mel = speech_conditioning_input.to(self.device, torch.float32)
+        if mel.ndim == 2:
+            mel = mel[None]
+        if cond_mel_lengths is None:
+            cond_mel_lengths = torch.full((mel.shape[0],), mel.shape[-1], device=self.device)
+        W = self._cond_weights()
+        x, mask = conformer_encode(W, mel.transpose(1, 2), cond_mel_lengths.to(self.device),
+                                   heads=int(self.condition_module.get("attention_heads", 8)))
+        cmask = F.pad(mask.squeeze(1), (self.cond_num, 0), value=True)
+        return perceiver_resample(W, x, cmask, heads=int(self.condition_module.get("attention_heads", 8)))
+
+    def prepare_gpt_inputs(self, conditional_latents, text_inputs):
+        """model.py:606-667 -> (fake_inputs [B,P+1], prefix_emb [B,P,D] fp32, attention_mask [B,P+1])."""
+        eng = self.engine
+        dev = self.device
+        text_inputs = text_inputs.to(dev).long()
+        B, L = text_inputs.shape
+        D = conditional_latents.shape[-1]
+        P = conditional_latents.shape[1] + L + 2
+        emb = torch.zeros(B, P, D, dtype=torch.float32, device=dev)
+        mask = torch.ones(B, P + 1, dtype=torch.long, device=dev)
+        single = conditional_latents.shape[0] == 1
+        for b in range(B):
+            t = text_inputs[b]
+            t = t[(t != self.stop_text_token) & (t != self.start_text_token)]
+            t = F.pad(F.pad(t, (1, 0), value=self.start_text_token), (0, 1), value=self.stop_text_token)
+            te = eng.text_emb[t] + eng.text_pos[: t.numel()]
+            row = torch.cat([conditional_latents[0 if single else b].to(dev, torch.float32), te], dim=0)
+            pad = P - row.shape[0]
+            emb[b, pad:] = row
+            mask[b, :pad] = 0
+        fake = torch.ones(B, P + 1, dtype=torch.long, device=dev)
+        fake[:, -1] = self.start_mel_token
+        return fake, emb, mask
+
+    # ---- generation -------------------------------------------------------------------------------------------
+    def inference_speech(self, speech_conditioning_mel, text_inputs, cond_mel_lengths=None, input_tokens=None,
+                         num_return_sequences=1, max_generate_length=None, typical_sampling=False, typical_mass=.9,
+                         speaker_ids=None, force_stop=None, seed=None, return_logits=False, **hf):
+        """model.py:669-720.  Accepted generate() keywords: do_sample, top_p, top_k, temperature, repetition_penalty,
+        num_beams, length_penalty.  Returns codes [B, n] (stop-token padded), like `output[:, trunc_index:]`."""
+        if self.engine is None:
+            raise RuntimeError("call post_init_gpt2_config() first")
+        if input_tokens is not None or typical_sampling or num_return_sequences != 1:
+            raise NotImplementedError("input_tokens / typical_sampling / num_return_sequences>1 are off the infer.py path")
+        num_beams = int(hf.pop("num_beams", 1))
+        hf.pop("length_penalty", None)
+        if num_beams != 1:
+            warnings.warn("beam-sample (num_beams>1) is not implemented on device yet; decoding with num_beams=1",
+                          RuntimeWarning)
+        sp = dict(do_sample=bool(hf.pop("do_sample", False)), top_p=float(hf.pop("top_p", 1.0)),
+                  top_k=int(hf.pop("top_k", 50)), temperature=float(hf.pop("temperature", 1.0)),
+                  repetition_penalty=float(hf.pop("repetition_penalty", 1.0)),
+                  seed=int(torch.initial_seed() & 0x7FFFFFFFFFFFFFFF) if seed is None else int(seed))
+        if not sp["do_sample"]:
+            sp["top_p"], sp["top_k"], sp["temperature"] = 1.0, 0, 1.0
+        if hf:
+            raise TypeError(f"unsupported generate() arguments: {sorted(hf)}")
+        conds = self.get_conditioning(speech_conditioning_mel, cond_mel_lengths, speaker_ids=speaker_ids)
+        _, emb, mask = self.prepare_gpt_inputs(conds, text_inputs)
+        pad = (mask == 0).sum(dim=1).to(torch.int32)
+        max_new = (self.max_mel_tokens - 1) if max_generate_length is None else int(max_generate_length)
+        self.engine.prefill(emb, pad, max_new)
+        out = self.engine.decode(max_new, sp, force_stop=force_stop, return_logits=return_logits)
+        return out
+
+    # ---- teacher-forced latent pass -----------------------------------------------------------------------------
+    def forward(self, speech_conditioning_latent, text_inputs, text_lengths, mel_codes, wav_lengths,
+                cond_mel_lengths=None, types=None, text_first=True, raw_mels=None, return_attentions=False,
+                return_latent=False, clip_inputs=False, speaker_ids=None, conds=None):
+        """model.py:548-597 with return_latent=True (the only mode infer.py uses): -> latent [B, T, D] fp32."""
+        if not return_latent:
+            raise NotImplementedError("training losses are out of scope; call with return_latent=True")
+        eng = self.engine
+        dev = self.device
+        if conds is None:
+            conds = self.get_conditioning(speech_conditioning_latent, cond_mel_lengths, speaker_ids)
+        text_inputs = text_inputs.to(dev).long()
+        mel_codes = mel_codes.to(dev).long()
+        B = text_inputs.shape[0]
+        text_lengths = torch.as_tensor(text_lengths).to(dev).long().reshape(-1)
+        wav_lengths = torch.as_tensor(wav_lengths).to(dev).reshape(-1)
+        mel_len = torch.ceil(wav_lengths.float() / self.mel_length_compression).long() + 1
+        T = mel_codes.shape[1]
+        # set_mel_padding / set_text_padding (:439-457), stop pads (:576-577), aligned inputs (:580-588)
+        ar_t = torch.arange(text_inputs.shape[1], device=dev)[None]
+        text_inputs = torch.where(ar_t < text_lengths[:, None], text_inputs, torch.full_like(text_inputs, self.stop_text_token))
+        ar_m = torch.arange(T, device=dev)[None]
+        mel_codes = torch.where(ar_m < mel_len[:, None], mel_codes, torch.full_like(mel_codes, self.stop_mel_token))
+        ti = F.pad(F.pad(text_inputs, (0, 1), value=self.stop_text_token), (1, 0), value=self.start_text_token)
+        mi = F.pad(F.pad(mel_codes, (0, 1), value=self.stop_mel_token), (1, 0), value=self.start_mel_token)
+        te = eng.text_emb[ti] + eng.text_pos[: ti.shape[1]]
+        me = eng.mel_emb[mi] + eng.mel_pos[: mi.shape[1]]
+        c = conds.to(dev, torch.float32)
+        if c.shape[0] == 1 and B > 1:
+            c = c.expand(B, -1, -1)
+        emb = torch.cat([c, te, me], dim=1)
+        enc = eng.latent(emb)[:, c.shape[1]:]
+        mel_part = enc[:, -mi.shape[1]:]
+        return mel_part[:, :-2]
+
+    __call__ = forward

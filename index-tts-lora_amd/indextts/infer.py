@@ -1,0 +1,463 @@
+"""IndexTTS inference orchestrator -- same Python surface as the reference's indextts/infer.py (class IndexTTS,
+`infer`, `infer_fast`, `set_seed`), running the GPT decoder and the BigVGAN vocoder on hand-written gfx950 kernels.
+
+Control flow follows the reference (infer.py:185-439 __init__, :446-497 remove_long_silence, :499-580 bucketing and
+padding, :595-777 infer_fast, :779-917 infer); the arithmetic is in indextts.gpt.engine / indextts.BigVGAN.models.
+Differences that are deliberate and visible: no CPU/MPS execution path (the HIP library is mandatory), bitsandbytes
+quantisation and DeepSpeed are accepted in the config but not used, and the conditioning latents / speaker embedding of
+a prompt are computed once per call instead of once per sentence (same values).
+"""
+from __future__ import annotations
+
+import json
+import os
+import random
+import time
+import warnings
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from indextts.BigVGAN.models import BigVGAN as Generator
+from indextts.gpt.model import UnifiedVoice
+from indextts.utils.audio import read_audio, write_pcm16
+from indextts.utils.checkpoint import load_checkpoint
+from indextts.utils.config import Config, load_config
+from indextts.utils.feature_extractors import MelSpectrogramFeatures, resample
+from indextts.utils.front import TextNormalizer, TextTokenizer
+
+
+def set_seed(seed):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def _resolve_dtype(name):
+    if name in ("bf16", "bfloat16"):
+        return torch.bfloat16
+    if name in ("fp16", "float16"):
+        return torch.float16
+    if name == "fp8":
+        return torch.bfloat16  # no fp8 weights path; served in bf16
+    return torch.float32
+
+
+class IndexTTS:
+    def __init__(self, cfg_path="checkpoints/config.yaml", model_dir="checkpoints", is_fp16=True, device=None,
+                 use_cuda_kernel=None, speaker_info_path=None, precision_config=None, gpt_path=None,
+                 _weights=None, _cfg=None):
+        if device is None:
+            device = "cuda:0" if torch.cuda.is_available() else "cpu"
+        if not str(device).startswith("cuda") or not torch.cuda.is_available():
+            raise RuntimeError("this build of IndexTTS runs on an AMD GPU through libindextts_hip.so; "
+                               f"device={device!r} is not supported (there is no CPU fallback)")
+        self.device = device
+        self.is_fp16 = is_fp16
+        self.use_cuda_kernel = True  # the fused HIP activation kernel is always used
+        self.cfg = _cfg if _cfg is not None else load_config(cfg_path)
+        self.model_dir = model_dir
+
+        # precision: precision_config > config_inference.yaml > cfg.inference > is_fp16   (infer.py:213-304)
+        source = "Runtime Args" if precision_config is not None else None
+        if precision_config is None:
+            p = os.path.join(model_dir, "config_inference.yaml") if model_dir else None
+            if p and os.path.exists(p):
+                icfg = load_config(p)
+                if "inference" in icfg:
+                    precision_config, source = icfg["inference"], "config_inference.yaml"
+            elif "inference" in self.cfg:
+                precision_config, source = self.cfg["inference"], "config.yaml [inference]"
+        self.use_quantization = self.load_in_8bit = self.load_in_4bit = False
+        if precision_config and isinstance(precision_config, dict):
+            gpt_p = precision_config.get("gpt", "bf16")
+            quant = precision_config.get("quantization", {}) or {}
+            if quant.get("enabled", False) or gpt_p in ("int8", "int4"):
+                print(">> [warning] bitsandbytes quantisation is not available in this build; using BF16 weights")
+                self.gpt_dtype = torch.bfloat16
+            else:
+                self.gpt_dtype = _resolve_dtype(gpt_p)
+            self.vocoder_dtype = _resolve_dtype(precision_config.get("vocoder", "bf16"))
+            print(f">> [config] mixed precision ({source}): GPT={self.gpt_dtype} vocoder={self.vocoder_dtype}")
+        elif self.is_fp16:
+            self.gpt_dtype, self.vocoder_dtype = torch.bfloat16, torch.float32
+            print(">> [config] BF16 GPT / FP32 vocoder (legacy is_fp16)")
+        else:
+            self.gpt_dtype = self.vocoder_dtype = torch.float32
+            print(">> [config] FP32 (legacy)")
+        if self.gpt_dtype == torch.float16:
+            self.gpt_dtype = torch.bfloat16  # GPT kernels: fp32 | bf16
+        self.dvae_dtype = self.gpt_dtype
+        self.dtype = self.gpt_dtype if self.gpt_dtype != torch.float32 else None
+        self.stop_mel_token = self.cfg.gpt.stop_mel_token
+
+        if _weights is None:
+            if gpt_path is not None:
+                self.gpt_path = gpt_path if os.path.isabs(gpt_path) else os.path.join(model_dir, gpt_path)
+            else:
+                self.gpt_path = os.path.join(model_dir, self.cfg.gpt_checkpoint)
+        else:
+            self.gpt_path = None
+
+        self.gpt = UnifiedVoice(**self.cfg.gpt)
+        if _weights is None:
+            load_checkpoint(self.gpt, self.gpt_path)
+        else:
+            self.gpt.load_state_dict(_weights["gpt"])
+        self.gpt = self.gpt.to(self.device).to(self.gpt_dtype).eval()
+        self.gpt.post_init_gpt2_config(use_deepspeed=False, kv_cache=True, half=self.gpt_dtype != torch.float32)
+        print(f">> [system] GPT loaded ({self.gpt_dtype})")
+
+        self.bigvgan = Generator(self.cfg.bigvgan, use_cuda_kernel=True)
+        if _weights is None:
+            self.bigvgan_path = os.path.join(model_dir, self.cfg.bigvgan_checkpoint)
+            self.bigvgan.load_state_dict(torch.load(self.bigvgan_path, map_location="cpu")["generator"])
+        else:
+            self.bigvgan_path = None
+            self.bigvgan.load_state_dict(_weights["bigvgan"])
+        self.bigvgan = self.bigvgan.to(self.device).to(self.vocoder_dtype)
+        self.bigvgan.remove_weight_norm()
+        self.bigvgan.eval()
+        print(f">> [system] BigVGAN loaded ({self.vocoder_dtype})")
+
+        self.normalizer = TextNormalizer()
+        self.normalizer.load()
+        bpe = self.cfg.dataset["bpe_model"] if "dataset" in self.cfg else None
+        self.bpe_path = os.path.join(model_dir, bpe) if (bpe and model_dir) else None
+        self.tokenizer = TextTokenizer(self.bpe_path, self.normalizer, allow_synthetic=_weights is not None)
+
+        self.cache_audio_prompt = None
+        self.cache_cond_mel = None
+        self._cache_conds = None
+        self._cache_spk = None
+        self.gr_progress = None
+        self.model_version = self.cfg.version if "version" in self.cfg else None
+        self.speaker_list = []
+        if speaker_info_path and os.path.exists(speaker_info_path):
+            try:
+                with open(speaker_info_path, "r", encoding="utf-8") as f:
+                    self.speaker_list = [it["speaker"] for it in json.load(f) if "speaker" in it]
+                print(f">> [system] multi-speaker mode ({len(self.speaker_list)} speakers)")
+            except Exception as e:  # noqa: BLE001
+                print(f">> [error] could not read speaker info: {e}")
+        self.mel_extractor = MelSpectrogramFeatures()
+
+    @classmethod
+    def from_weights(cls, cfg, gpt_state_dict, bigvgan_state_dict, device="cuda:0", is_fp16=True, precision_config=None):
+        """Build from in-memory state dicts in the reference checkpoint key format (offline / synthetic weights)."""
+        cfg = cfg if isinstance(cfg, Config) else Config(cfg)
+        return cls(model_dir="", is_fp16=is_fp16, device=device, precision_config=precision_config, _cfg=cfg,
+                   _weights={"gpt": gpt_state_dict, "bigvgan": bigvgan_state_dict})
+
+    # ------------------------------------------------------------------------------------------------ helpers
+    def remove_long_silence(self, codes: torch.Tensor, silent_token=52, max_consecutive=30):
+        """infer.py:446-497: cut at the first stop token; when a row holds more than `max_consecutive` silent tokens,
+        keep at most 10 per run."""
+        c = codes.detach().cpu().numpy()
+        rows, lens, fixed = [], [], False
+        for code in c:
+            stops = np.nonzero(code == self.stop_mel_token)[0]
+            n = int(stops[0]) if stops.size else code.shape[0]
+            if int((code == silent_token).sum()) > max_consecutive:
+                keep, run = [], 0
+                for k in range(n):
+                    if code[k] != silent_token:
+                        keep.append(k)
+                        run = 0
+                    elif run < 10:
+                        keep.append(k)
+                        run += 1
+                rows.append(code[keep])
+                lens.append(len(keep))
+                fixed = True
+            else:
+                rows.append(code[:n])
+                lens.append(n)
+        if fixed:
+            if len(rows) > 1:
+                m = max(len(r) for r in rows)
+                out = np.full((len(rows), m), self.stop_mel_token, dtype=c.dtype)
+                for i, r in enumerate(rows):
+                    out[i, :len(r)] = r
+                c = out
+            else:
+                c = rows[0][None]
+        mx = max(lens)
+        if mx < c.shape[1]:
+            c = c[:, :mx]
+        return torch.from_numpy(np.ascontiguousarray(c)).to(codes.device), torch.tensor(lens, dtype=torch.long, device=codes.device)
+
+    def bucket_sentences(self, sentences, bucket_max_size=4) -> List[List[Dict]]:
+        """infer.py:499-550: sort by length, open a new bucket when a sentence is >= 1.5x the bucket median or the
+        bucket is full, then fold singleton buckets into buckets with room."""
+        items = [{"idx": i, "sent": s, "len": len(s)} for i, s in enumerate(sentences)]
+        if len(items) <= bucket_max_size:
+            return [items]
+        buckets, last, median = [], None, 0
+        for it in sorted(items, key=lambda x: x["len"]):
+            if it["len"] == 0:
+                continue
+            if last is None or it["len"] >= int(median * 1.5) or len(last) >= bucket_max_size:
+                last = [it]
+                buckets.append(last)
+                median = it["len"]
+            else:
+                last.append(it)
+                median = last[len(last) // 2]["len"]
+        out = [b for b in buckets if len(b) > 1]
+        ones = [b[0] for b in buckets if len(b) == 1]
+        if ones:
+            for b in out:
+                if len(b) < bucket_max_size:
+                    b.append(ones.pop(0))
+                    if not ones:
+                        break
+            if ones:
+                out.extend([ones[i:i + bucket_max_size] for i in range(0, len(ones), bucket_max_size)])
+        return out
+
+    def pad_tokens_cat(self, tokens: List[torch.Tensor]) -> torch.Tensor:
+        """infer.py:552-580: right-pad with the stop text token (v>=1.5), or 8 stops then start tokens (older)."""
+        stop, start = self.cfg.gpt.stop_text_token, self.cfg.gpt.start_text_token
+        if self.model_version and self.model_version >= 1.5:
+            ts = [t.squeeze(0) for t in tokens]
+            m = max(t.size(0) for t in ts)
+            return torch.stack([torch.cat([t, torch.full((m - t.size(0),), stop, dtype=t.dtype, device=t.device)]) for t in ts])
+        m = max(t.size(1) for t in tokens)
+        outs = []
+        for t in tokens:
+            padn = m - t.size(1)
+            if padn > 0:
+                n = min(8, padn)
+                t = torch.nn.functional.pad(t, (0, n), value=stop)
+                t = torch.nn.functional.pad(t, (0, padn - n), value=start)
+            outs.append(t[:, :m])
+        return torch.cat(outs, dim=0)
+
+    def torch_empty_cache(self):
+        try:
+            torch.cuda.empty_cache()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _set_gr_progress(self, value, desc):
+        if self.gr_progress is not None:
+            self.gr_progress(value, desc=desc)
+
+    def _prompt(self, audio_prompt):
+        """infer.py:789-800: mono mean -> 24 kHz -> log-mel, cached by path; plus (new) cached conditioner outputs."""
+        if self.cache_cond_mel is None or self.cache_audio_prompt != audio_prompt:
+            audio, sr = read_audio(audio_prompt)
+            audio = torch.from_numpy(audio.T if audio.ndim > 1 else audio.reshape(1, -1)).float()
+            audio = torch.mean(audio, dim=0, keepdim=True)
+            audio = resample(audio, sr, 24000)
+            self.cache_cond_mel = self.mel_extractor(audio).to(self.device)
+            self.cache_audio_prompt = audio_prompt
+            self._cache_conds = self._cache_spk = None
+        return self.cache_cond_mel
+
+    def _conds(self, cond_mel, speaker_id=None):
+        if speaker_id:
+            return self.gpt.get_conditioning(None, None, speaker_ids=[speaker_id])
+        if self._cache_conds is None:
+            self._cache_conds = self.gpt.get_conditioning(cond_mel, torch.tensor([cond_mel.shape[-1]], device=self.device))
+        return self._cache_conds
+
+    def _spk(self, cond_mel):
+        if self._cache_spk is None:
+            self._cache_spk = self.bigvgan.speaker_embedding(cond_mel.transpose(1, 2))
+        return self._cache_spk
+
+    @staticmethod
+    def _gen_kwargs(kw):
+        return dict(do_sample=kw.pop("do_sample", True), top_p=kw.pop("top_p", 0.8), top_k=kw.pop("top_k", 30),
+                    temperature=kw.pop("temperature", 1.0), length_penalty=kw.pop("length_penalty", 0.0),
+                    num_beams=kw.pop("num_beams", 3), repetition_penalty=kw.pop("repetition_penalty", 10.0)), \
+            kw.pop("max_mel_tokens", 600)
+
+    def _generate(self, conds, text_tokens, gen, max_mel_tokens, **extra):
+        """gpt.inference_speech with precomputed conditioning latents (same values as recomputing them per call)."""
+        g = self.gpt
+        _, emb, mask = g.prepare_gpt_inputs(conds, text_tokens)
+        pad = (mask == 0).sum(dim=1).to(torch.int32)
+        if gen.get("num_beams", 1) != 1:
+            warnings.warn("beam-sample (num_beams>1) is not implemented on device yet; decoding with num_beams=1", RuntimeWarning)
+        sp = dict(do_sample=bool(gen["do_sample"]), top_p=float(gen["top_p"]), top_k=int(gen["top_k"]),
+                  temperature=float(gen["temperature"]), repetition_penalty=float(gen["repetition_penalty"]),
+                  seed=int(extra.pop("seed", torch.initial_seed() & 0x7FFFFFFFFFFFFFFF)))
+        if not sp["do_sample"]:
+            sp["top_p"], sp["top_k"], sp["temperature"] = 1.0, 0, 1.0
+        g.engine.prefill(emb, pad, max_mel_tokens)
+        return g.engine.decode(max_mel_tokens, sp, force_stop=extra.pop("force_stop", None))
+
+    def _latents(self, conds, text_rows: List[torch.Tensor], code_rows: List[torch.Tensor]):
+        """Teacher-forced pass for several utterances at once (right-padded; causal attention makes padding inert).
+        Each row reproduces gpt(cond, text, [L], codes, code_len*1024, return_latent=True) of infer.py:864-874."""
+        g, eng, dev = self.gpt, self.gpt.engine, self.device
+        embs, spans = [], []
+        for t, c in zip(text_rows, code_rows):
+            t = t.reshape(-1).long().to(dev)
+            c = c.reshape(-1).long().to(dev)
+            ti = torch.cat([torch.tensor([g.start_text_token], device=dev), t, torch.tensor([g.stop_text_token], device=dev)])
+            mi = torch.cat([torch.tensor([g.start_mel_token], device=dev), c, torch.tensor([g.stop_mel_token], device=dev)])
+            te = eng.text_emb[ti] + eng.text_pos[: ti.numel()]
+            me = eng.mel_emb[mi] + eng.mel_pos[: mi.numel()]
+            e = torch.cat([conds[0].to(dev, torch.float32), te, me], dim=0)
+            embs.append(e)
+            spans.append((conds.shape[1] + ti.numel(), c.numel()))
+        S = max(e.shape[0] for e in embs)
+        batch = torch.zeros(len(embs), S, embs[0].shape[1], dtype=torch.float32, device=dev)
+        for i, e in enumerate(embs):
+            batch[i, : e.shape[0]] = e
+        enc = eng.latent(batch)
+        return [enc[i, s0: s0 + n] for i, (s0, n) in enumerate(spans)]
+
+    def _finish(self, wavs, output_path, start_time, gpt_gen_time, gpt_forward_time, bigvgan_time, sampling_rate=24000):
+        end_time = time.perf_counter()
+        wav = torch.cat(wavs, dim=1)
+        wav_length = wav.shape[-1] / sampling_rate
+        print(f">> [stats] total: {end_time - start_time:.2f}s (RTF: {(end_time - start_time) / max(wav_length, 1e-9):.4f})")
+        print(f"   - GPT generation: {gpt_gen_time:.2f}s")
+        print(f"   - GPT forward: {gpt_forward_time:.2f}s")
+        print(f"   - vocoder: {bigvgan_time:.2f}s")
+        wav = wav.cpu()
+        if output_path:
+            if os.path.isfile(output_path):
+                os.remove(output_path)
+            if os.path.dirname(output_path) != "":
+                os.makedirs(os.path.dirname(output_path), exist_ok=True)
+            write_pcm16(output_path, wav.squeeze(0).to(torch.float32).numpy().astype("int16"), sampling_rate)
+            print(f">> [output] saved to: {output_path}")
+            return output_path
+        return (sampling_rate, wav.type(torch.int16).numpy().T)
+
+    def _vocode(self, latent, spk):
+        wav, _ = self.bigvgan(latent, speaker_embedding=spk)
+        return torch.clamp(32767 * wav.squeeze(1), -32767.0, 32767.0)
+
+    # ------------------------------------------------------------------------------------------------ public API
+    def infer(self, audio_prompt, text, output_path, verbose=False, max_text_tokens_per_sentence=120, speaker_id=None,
+              **generation_kwargs):
+        """Sentence-by-sentence synthesis (infer.py:779-917)."""
+        if speaker_id is not None:
+            if not self.speaker_list:
+                raise ValueError("multi-speaker mode is not enabled; load speaker_info_path first")
+            if speaker_id not in self.speaker_list:
+                raise ValueError(f"invalid speaker_id: {speaker_id}")
+        start_time = time.perf_counter()
+        cond_mel = self._prompt(audio_prompt)
+        self._set_gr_progress(0.1, "text processing...")
+        sentences = self.tokenizer.split_sentences(self.tokenizer.tokenize(text), max_text_tokens_per_sentence)
+        gen, max_mel_tokens = self._gen_kwargs(generation_kwargs)
+        conds = self._conds(cond_mel, speaker_id)
+        spk = self._spk(cond_mel)
+        wavs, gpt_gen_time, gpt_forward_time, bigvgan_time, has_warned = [], 0.0, 0.0, 0.0, False
+        for n, sent in enumerate(sentences, 1):
+            text_tokens = torch.tensor(self.tokenizer.convert_tokens_to_ids(sent), dtype=torch.int32, device=self.device)[None]
+            self._set_gr_progress(0.2 + 0.4 * (n - 1) / len(sentences), f"generating... {n}/{len(sentences)}")
+            t0 = time.perf_counter()
+            codes = self._generate(conds, text_tokens, gen, max_mel_tokens)
+            torch.cuda.synchronize()
+            gpt_gen_time += time.perf_counter() - t0
+            if not has_warned and (codes[:, -1] != self.stop_mel_token).any():
+                warnings.warn(f"generation stopped at max_mel_tokens ({max_mel_tokens}); consider shorter sentences",
+                              category=RuntimeWarning)
+                has_warned = True
+            codes, code_lens = self.remove_long_silence(codes)
+            if verbose:
+                print(f">> codes {tuple(codes.shape)} lens {code_lens.tolist()}")
+            self._set_gr_progress(0.2 + 0.4 * n / len(sentences), f"synthesising... {n}/{len(sentences)}")
+            t0 = time.perf_counter()
+            latent = self._latents(conds, [text_tokens[0]], [codes[0, : int(code_lens[0])]])[0][None]
+            torch.cuda.synchronize()
+            gpt_forward_time += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            wav = self._vocode(latent, spk)
+            torch.cuda.synchronize()
+            bigvgan_time += time.perf_counter() - t0
+            wavs.append(wav.cpu())
+        self._set_gr_progress(0.9, "saving audio...")
+        return self._finish(wavs, output_path, start_time, gpt_gen_time, gpt_forward_time, bigvgan_time)
+
+    def infer_fast(self, audio_prompt, text, output_path, verbose=False, max_text_tokens_per_sentence=100,
+                   sentences_bucket_max_size=4, **generation_kwargs):
+        """Bucketed batch synthesis (infer.py:595-777): sentences of similar length are decoded as one left-padded batch;
+        latents are computed in one batched pass and vocoded in time-concatenated pairs (chunk_size 2)."""
+        print(">> [infer] fast mode")
+        self._set_gr_progress(0, "initialising...")
+        start_time = time.perf_counter()
+        cond_mel = self._prompt(audio_prompt)
+        sentences = self.tokenizer.split_sentences(self.tokenizer.tokenize(text), max_tokens_per_sentence=max_text_tokens_per_sentence)
+        gen, max_mel_tokens = self._gen_kwargs(generation_kwargs)
+        conds, spk = self._conds(cond_mel), self._spk(cond_mel)
+        self._set_gr_progress(0.1, "text processing...")
+        buckets = self.bucket_sentences(sentences, bucket_max_size=sentences_bucket_max_size)
+        all_tokens = [[torch.tensor(self.tokenizer.convert_tokens_to_ids(it["sent"]), dtype=torch.int32, device=self.device)[None]
+                       for it in b] for b in buckets]
+        gpt_gen_time = gpt_forward_time = bigvgan_time = 0.0
+        total = sum(len(b) for b in buckets)
+        done, all_codes = 0, []
+        for toks in all_tokens:
+            batch = self.pad_tokens_cat(toks) if len(toks) > 1 else toks[0]
+            done += len(toks)
+            self._set_gr_progress(0.2 + 0.3 * done / total, f"GPT generating... {done}/{total}")
+            t0 = time.perf_counter()
+            all_codes.append(self._generate(conds, batch, gen, max_mel_tokens))
+            torch.cuda.synchronize()
+            gpt_gen_time += time.perf_counter() - t0
+        self._set_gr_progress(0.5, "computing latents...")
+        idxs, text_rows, code_rows, has_warned = [], [], [], False
+        for codes_b, toks, b in zip(all_codes, all_tokens, buckets):
+            for i in range(codes_b.shape[0]):
+                codes = codes_b[i]
+                if not has_warned and codes[-1] != self.stop_mel_token:
+                    warnings.warn(f"generation stopped at max_mel_tokens ({max_mel_tokens})", category=RuntimeWarning)
+                    has_warned = True
+                codes, lens = self.remove_long_silence(codes[None])
+                idxs.append(b[i]["idx"])
+                text_rows.append(toks[i][0])
+                code_rows.append(codes[0, : int(lens[0])])
+        t0 = time.perf_counter()
+        lat = self._latents(conds, text_rows, code_rows)
+        torch.cuda.synchronize()
+        gpt_forward_time += time.perf_counter() - t0
+        lat = [lat[idxs.index(i)] for i in range(len(lat))]
+        self._set_gr_progress(0.7, "vocoding...")
+        wavs = []
+        for i in range(0, len(lat), 2):
+            t0 = time.perf_counter()
+            wav = self._vocode(torch.cat(lat[i:i + 2], dim=0)[None], spk)
+            torch.cuda.synchronize()
+            bigvgan_time += time.perf_counter() - t0
+            wavs.append(wav.cpu())
+        self.torch_empty_cache()
+        self._set_gr_progress(0.9, "saving audio...")
+        return self._finish(wavs, output_path, start_time, gpt_gen_time, gpt_forward_time, bigvgan_time)
+
+    def infer_batch(self, cond_mel: torch.Tensor, text_token_rows: List[torch.Tensor], max_mel_tokens=600, force_stop=None,
+                    seed=1234, return_codes=False, **generation_kwargs):
+        """Utterance-batch data path used by bench.py / the multi-GPU sharder (not in the reference API): one shared
+        prompt, N independent texts decoded as ONE left-padded batch, one batched latent pass, one batched vocoder
+        call.  Returns a list of fp32 waveforms (already scaled to the int16 range, like infer.py:892)."""
+        gen, _ = self._gen_kwargs(generation_kwargs)
+        conds = self.gpt.get_conditioning(cond_mel, torch.tensor([cond_mel.shape[-1]], device=self.device))
+        spk = self.bigvgan.speaker_embedding(cond_mel.transpose(1, 2))
+        L = max(int(t.numel()) for t in text_token_rows)
+        stop = self.cfg.gpt.stop_text_token
+        batch = torch.full((len(text_token_rows), L), stop, dtype=torch.int32, device=self.device)
+        for i, t in enumerate(text_token_rows):
+            batch[i, : t.numel()] = t.reshape(-1).to(self.device, torch.int32)
+        codes = self._generate(conds, batch, gen, max_mel_tokens, force_stop=force_stop, seed=seed)
+        codes_c, lens = self.remove_long_silence(codes)
+        rows = [codes_c[i, : int(lens[i])] for i in range(codes_c.shape[0])]
+        lat = self._latents(conds, [t.reshape(-1) for t in text_token_rows], rows)
+        Tm = max(int(x.shape[0]) for x in lat)
+        lb = torch.zeros(len(lat), Tm, lat[0].shape[1], dtype=torch.float32, device=self.device)
+        for i, x in enumerate(lat):
+            lb[i, : x.shape[0]] = x
+        wav = self._vocode(lb, spk)
+        outs = [wav[i, : int(lat[i].shape[0]) * 1024] for i in range(len(lat))]
+        return (outs, rows) if return_codes else outs
