@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""bench.py -- IndexTTS inference hot path on MI355X: audio-seconds per second at batch 32 (BASELINE.json metric).
+
+One "step" = one full pass of the hot path over one synthetic utterance batch (BASELINE config 3): 32 utterances that
+share a prompt, text lengths U{20..60}, top-k/top-p sampling (k=30, p=0.8, T=1.0, repetition penalty 10, num_beams=1),
+every row force-stopped after 140 acoustic tokens (random weights never emit EOS; 140 tokens = 5.97 s of audio):
+conditioner -> prefix -> prefill -> 140-step cached decode loop (CUDA-graph replay) -> teacher-forced latent pass ->
+BigVGAN vocoder -> PCM clamp.  GPT in bf16, vocoder in fp16, fp32 accumulation.  Weights are name-hashed synthetic
+tensors at the real shapes (no checkpoints exist offline), built on rank 0 and broadcast over RCCL to the other ranks;
+there is no collective inside the timed region (utterances are independent -> weak scaling, one process per GPU).
+
+Prints ONE JSON line on rank 0 (see the driver contract), including
+  roofline     -- the dominant kernel of the step: per-launch HIP-event timing of an identical instrumented step
+  cpu_baseline -- the oracle (CPU restatement, fp32) timed on the host cores on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "index-tts-lora_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+BATCH = 32
+MEL_TOKENS = 140
+PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PEAK_MFMA_TFLOPS = 2500.0  # dense bf16/fp16 MFMA
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_weights_rank0():
+    import weights
+    t0 = time.time()
+    gsd = weights.gpt_state_dict(24)
+    bsd = weights.bigvgan_state_dict()
+    log(f"[bench] synthesised weights in {time.time() - t0:.1f}s")
+    return gsd, bsd
+
+
+def broadcast_state(sd_or_none, rank, world, device):
+    """rank 0 -> all: one flat fp32 arena over RCCL (xGMI inside a node)."""
+    import torch.distributed as dist
+    import weights
+    if world == 1:
+        return sd_or_none
+    # every rank knows names/shapes (they are a function of the config), only rank 0 holds values
+    meta = [None]
+    if rank == 0:
+        meta[0] = [(k, tuple(v.shape), str(v.dtype)) for k, v in sd_or_none.items()]
+    dist.broadcast_object_list(meta, src=0)
+    meta = meta[0]
+    total = sum(int(np.prod(s)) if len(s) else 1 for _, s, _ in meta)
+    arena = torch.empty(total, dtype=torch.float32, device=device)
+    if rank == 0:
+        off = 0
+        for k, s, _ in meta:
+            n = int(np.prod(s)) if len(s) else 1
+            arena[off:off + n] = sd_or_none[k].reshape(-1).to(device, torch.float32)
+            off += n
+    dist.broadcast(arena, src=0)
+    out, off = {}, 0
+    for k, s, dt in meta:
+        n = int(np.prod(s)) if len(s) else 1
+        t = arena[off:off + n].view(s)
+        out[k] = t.to(torch.int64) if "int" in dt else t
+        off += n
+    return out
+
+
+class KernelTimer:
+    """Per-launch HIP-event timing of the C-ABI entry points (events are recorded on the stream the kernels run on)."""
+    NAMES = ("gemm_conv", "gemm_skinny", "aa_snake", "attn_decode", "attn_prefill", "layernorm", "sample", "embed_step",
+             "tanh_pcm")
+
+    def __init__(self, nat):
+        self.nat, self.rec, self.orig = nat, [], {}
+
+    def __enter__(self):
+        for n in self.NAMES:
+            f = getattr(self.nat, n)
+            self.orig[n] = f
+
+            def wrapped(*a, _f=f, _n=n, **k):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = _f(*a, **k)
+                e1.record()
+                self.rec.append((_n, e0, e1, self._work(_n, a, k)))
+                return r
+            setattr(self.nat, n, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        for n, f in self.orig.items():
+            setattr(self.nat, n, f)
+
+    @staticmethod
+    def _work(name, a, k):
+        """(flops, algorithmic bytes) of one launch."""
+        es = lambda dt: 4 if dt == torch.float32 else 2  # noqa: E731
+        if name == "gemm_conv":
+            dt, B, Tin, Tout, Cin, N = a[:6]
+            taps = k.get("taps", 1)
+            fl = 2.0 * B * Tout * N * Cin * taps
+            by = B * Tin * Cin * es(dt) + B * Tout * N * (4 if k.get("y_f32") else es(dt)) + taps * Cin * N * es(dt)
+            return fl, by
+        if name == "gemm_skinny":
+            dt, M, N, K = a[:4]
+            return 2.0 * M * N * K, K * N * es(dt) + M * K * 4 + M * N * 4
+        if name == "aa_snake":
+            x = a[0]
+            return 60.0 * x.numel(), 2 * x.numel() * x.element_size()
+        return 0.0, 0.0
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for n, e0, e1, (fl, by) in self.rec:
+            d = agg.setdefault(n, [0, 0.0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+            d[2] += fl
+            d[3] += by
+        return agg
+
+
+def make_inputs(rank, device):
+    g = torch.Generator().manual_seed(2 + 1000 * rank)
+    lens = torch.randint(20, 61, (BATCH,), generator=g)
+    texts = [torch.randint(2, 12000, (int(n),), generator=g).to(torch.int32) for n in lens]
+    import synth
+    cond_mel = torch.from_numpy(synth.uniform("bench.cond_mel", (1, 100, 300), -6.0, 2.0)).to(device)
+    return cond_mel, texts
+
+
+def cpu_baseline(gsd, bsd, cond_conds, n_tokens=8):
+    """Oracle (oracle/*.py, fp32, torch CPU) on ONE utterance of the same workload, n_tokens acoustic tokens:
+    prefill + cached greedy steps + latent pass + vocoder.  Returns (audio_s_per_s, cores, description)."""
+    from oracle import bigvgan_ref, gpt_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    W = {k: v.float() for k, v in gsd.items() if k.startswith(("gpt.", "final_norm", "mel_", "text_"))}
+    g = torch.Generator().manual_seed(2)
+    text = torch.randint(2, 12000, (1, 40), generator=g)
+    conds = cond_conds.cpu().float()
+    VW = bigvgan_ref.Weights({k: v.numpy() for k, v in bsd.items()})
+    spk = torch.zeros(1, 512, 1)
+    t0 = time.perf_counter()
+    emb, mask, _ = gpt_ref.prepare_gpt_inputs(conds, text, W)
+    lg, past = gpt_ref.decode_prefill(emb, mask, W)
+    codes = []
+    for s in range(1, n_tokens + 1):
+        tok = lg.argmax(-1)
+        codes.append(int(tok))
+        if s == n_tokens:
+            break
+        mask = torch.cat([mask, torch.ones(1, 1, dtype=torch.bool)], 1)
+        lg, past = gpt_ref.decode_step(tok, s, mask, past, W)
+    lat = gpt_ref.latent_pass(conds, text[0], torch.tensor(codes), W)
+    wav = bigvgan_ref.forward(lat, spk, VW)
+    dt = time.perf_counter() - t0
+    audio_s = wav.shape[-1] / 24000.0
+    return audio_s / dt, cores, (f"oracle fp32 on {cores} host threads: 1 utterance, 40 text tokens, {n_tokens} acoustic tokens "
+                                 f"(prefill + cached decode + latent pass + BigVGAN), {dt:.1f}s of CPU work")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    torch.set_grad_enabled(False)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+
+    import weights
+    from indextts import _native as nat
+    from indextts.infer import IndexTTS
+
+    gsd = bsd = None
+    if rank == 0:
+        gsd, bsd = build_weights_rank0()
+    gsd_d = broadcast_state(gsd, rank, world, device)
+    bsd_d = broadcast_state(bsd, rank, world, device)
+    cfg = weights.reference_config()
+    tts = IndexTTS.from_weights(cfg, gsd_d, bsd_d, device=device,
+                                precision_config={"gpt": "bf16", "vocoder": "fp16"})
+    del gsd_d, bsd_d
+    cond_mel, texts = make_inputs(rank, device)
+    force = [MEL_TOKENS] * BATCH
+    gen = dict(do_sample=True, top_k=30, top_p=0.8, temperature=1.0, repetition_penalty=10.0, num_beams=1)
+
+    def step(seed):
+        return tts.infer_batch(cond_mel, texts, max_mel_tokens=MEL_TOKENS + 1, force_stop=force, seed=seed, **gen)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        outs = step(1234 + w)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        outs = step(2000 + k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    samples = sum(int(o.numel()) for o in outs)
+    audio_s_step = samples / 24000.0
+    assert samples == BATCH * MEL_TOKENS * 1024, f"unexpected audio length {samples}"
+    value = audio_s_step * world * args.steps / elapsed
+
+    # p50 first-token latency: cached prompt mel -> conditioner + prefix + prefill + first sample
+    lat_ms = []
+    batch_tokens = torch.full((BATCH, max(int(t.numel()) for t in texts)), 1, dtype=torch.int32, device=device)
+    for i, t in enumerate(texts):
+        batch_tokens[i, : t.numel()] = t.to(device)
+    sp = dict(do_sample=True, top_p=0.8, top_k=30, temperature=1.0, repetition_penalty=10.0, seed=1)
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        conds = tts.gpt.get_conditioning(cond_mel, None)
+        _, emb, mask = tts.gpt.prepare_gpt_inputs(conds, batch_tokens)
+        tts.gpt.engine.prefill(emb, (mask == 0).sum(1).to(torch.int32), 4)
+        tts.gpt.engine._sample(BATCH, sp)
+        torch.cuda.synchronize()
+        lat_ms.append((time.perf_counter() - t1) * 1e3)
+    first_token_ms = float(np.median(lat_ms))
+
+    result = {
+        "metric": "audio-seconds/sec (RTF^-1) at batch 32, whole pipeline (GPT decode + latent pass + BigVGAN)",
+        "value": round(value, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "BASELINE config 3: batch=32 utterances/GPU, top-k sampling (k=30,p=0.8), 140 acoustic tokens "
+                               "(5.97 s) each, shared 3.2 s prompt, text U{20..60} tokens, random-init weights at real shapes",
+                   "gpt_dtype": "bf16", "vocoder_dtype": "fp16", "parallelism": f"dp{world} (utterance sharding, no collectives)",
+                   "audio_seconds_per_step_per_gpu": round(audio_s_step, 3)},
+        "first_token_ms_p50": round(first_token_ms, 2),
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # one more identical step with per-launch HIP events (eager launches instead of graph replay)
+        eng = tts.gpt.engine
+        real_get_graph = eng._get_graph
+        eng._get_graph = lambda B, sp_: None
+        t_phase = {}
+        with KernelTimer(nat) as kt:
+            torch.cuda.synchronize()
+            step(4242)
+            agg = kt.summary()
+        eng._get_graph = real_get_graph
+        tot = sum(v[1] for v in agg.values())
+        name, (cnt, ms, fl, by) = max(agg.items(), key=lambda kv: kv[1][1])
+        breakdown = {n: {"launches": v[0], "ms": round(v[1], 3), "share": round(v[1] / tot, 3)} for n, v in
+                     sorted(agg.items(), key=lambda kv: -kv[1][1])}
+        if name == "gemm_skinny":
+            ach = by / (ms * 1e-3) / 1e9
+            roof = {"kernel": "gemm_skinny_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None}
+        elif name == "gemm_conv":
+            ach = fl / (ms * 1e-3) / 1e12
+            roof = {"kernel": "gemm_conv_kernel", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": None}
+        else:
+            ach = by / (ms * 1e-3) / 1e9
+            roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None}
+        roof["launches"] = cnt
+        roof["avg_launch_us"] = round(1e3 * ms / cnt, 2)
+        # the HBM-bound decode GEMM is always reported beside it
+        if "gemm_skinny" in agg:
+            c2, ms2, _, by2 = agg["gemm_skinny"]
+            roof["decode_gemm_hbm"] = {"achieved_GBs": round(by2 / (ms2 * 1e-3) / 1e9, 1), "frac": round(by2 / (ms2 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                       "avg_launch_us": round(1e3 * ms2 / c2, 2), "launches": c2}
+        result["roofline"] = roof
+        result["kernel_breakdown"] = breakdown
+        log("[bench] kernel breakdown (instrumented eager step):", json.dumps(breakdown))
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        conds = tts.gpt.get_conditioning(cond_mel, None)
+        v, cores, desc = cpu_baseline(gsd, bsd, conds)
+        result["cpu_baseline"] = {"value": round(v, 4), "unit": "audio-seconds/sec", "cores": cores, "kind": "port", "sample": desc}
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
