@@ -48,32 +48,10 @@ def build_weights_rank0():
 
 def broadcast_state(sd_or_none, rank, world, device):
     """rank 0 -> all: one flat fp32 arena over RCCL (xGMI inside a node)."""
-    import torch.distributed as dist
-    import weights
+    from indextts.utils.dist import broadcast_state_dict
     if world == 1:
         return sd_or_none
-    # every rank knows names/shapes (they are a function of the config), only rank 0 holds values
-    meta = [None]
-    if rank == 0:
-        meta[0] = [(k, tuple(v.shape), str(v.dtype)) for k, v in sd_or_none.items()]
-    dist.broadcast_object_list(meta, src=0)
-    meta = meta[0]
-    total = sum(int(np.prod(s)) if len(s) else 1 for _, s, _ in meta)
-    arena = torch.empty(total, dtype=torch.float32, device=device)
-    if rank == 0:
-        off = 0
-        for k, s, _ in meta:
-            n = int(np.prod(s)) if len(s) else 1
-            arena[off:off + n] = sd_or_none[k].reshape(-1).to(device, torch.float32)
-            off += n
-    dist.broadcast(arena, src=0)
-    out, off = {}, 0
-    for k, s, dt in meta:
-        n = int(np.prod(s)) if len(s) else 1
-        t = arena[off:off + n].view(s)
-        out[k] = t.to(torch.int64) if "int" in dt else t
-        off += n
-    return out
+    return broadcast_state_dict(sd_or_none, src=0, device=device)
 
 
 class KernelTimer:

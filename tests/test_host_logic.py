@@ -1,0 +1,192 @@
+"""CPU tests of the host logic around the hot path: silence trimming, bucketing/padding, tokenizer glue, config and
+checkpoint formats, weight-norm folding, transposed-conv rewrite, mel front-end, WAV I/O, sharding."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from indextts.BigVGAN.models import convtr_as_conv, fold_weight_norm, kaiser_sinc_filter
+from indextts.utils.audio import read_audio, write_pcm16
+from indextts.utils.checkpoint import load_checkpoint
+from indextts.utils.config import Config, load_config
+from indextts.utils.dist import shard_utterances
+from indextts.utils.feature_extractors import MelSpectrogramFeatures, mel_filterbank, resample
+from indextts.utils.front import TextNormalizer, TextTokenizer, tokenize_by_CJK_char
+from oracle import silence_ref
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+class _Stub:
+    """IndexTTS methods that need no GPU, bound to a minimal object."""
+    from indextts.infer import IndexTTS as _I
+    remove_long_silence = _I.remove_long_silence
+    bucket_sentences = _I.bucket_sentences
+    pad_tokens_cat = _I.pad_tokens_cat
+    stop_mel_token = 8193
+    model_version = 1.5
+    cfg = Config({"gpt": {"stop_text_token": 1, "start_text_token": 0}})
+
+
+def test_remove_long_silence_cases():
+    s = _Stub()
+    # (1) cut at first stop token, nothing else
+    codes = np.array([[5, 6, 7, 8193, 8193, 8193], [1, 2, 3, 4, 5, 6]])
+    out, lens = silence_ref.remove_long_silence(codes)
+    assert lens.tolist() == [3, 6] and out.shape == (2, 6)
+    o2, l2 = s.remove_long_silence(torch.from_numpy(codes))
+    assert np.array_equal(o2.numpy(), out) and l2.tolist() == lens.tolist()
+    # (2) >30 silent tokens: runs are capped at 10, row is cut at the stop token, other rows padded with stop
+    row = [9] * 3 + [52] * 25 + [7] + [52] * 12 + [11, 8193, 8193]
+    codes = np.array([row, list(range(100, 100 + len(row)))])
+    out, lens = silence_ref.remove_long_silence(codes)
+    assert lens.tolist() == [3 + 10 + 1 + 10 + 1, len(row)]
+    assert out[0, :lens[0]].tolist() == [9] * 3 + [52] * 10 + [7] + [52] * 10 + [11]
+    assert (out[0, lens[0]:] == 8193).all()
+    o2, l2 = s.remove_long_silence(torch.from_numpy(codes))
+    assert np.array_equal(o2.numpy(), out) and l2.tolist() == lens.tolist()
+    # (3) single row with silence fix and no stop token
+    codes = np.array([[52] * 40])
+    out, lens = silence_ref.remove_long_silence(codes)
+    assert out.shape == (1, 10) and lens.tolist() == [10]
+    o2, l2 = s.remove_long_silence(torch.from_numpy(codes))
+    assert np.array_equal(o2.numpy(), out)
+    # (4) exactly 30 silent tokens: untouched
+    codes = np.array([[52] * 30 + [3]])
+    out, lens = silence_ref.remove_long_silence(codes)
+    assert out.shape == (1, 31) and lens.tolist() == [31]
+
+
+def test_bucket_and_pad():
+    s = _Stub()
+    sents = [["a"] * n for n in (5, 30, 6, 7, 31, 90, 8, 29)]
+    b = s.bucket_sentences(sents, bucket_max_size=4)
+    assert sorted(i["idx"] for bb in b for i in bb) == list(range(8))
+    assert all(len(bb) <= 4 for bb in b)
+    assert s.bucket_sentences(sents[:3], bucket_max_size=4)[0][2]["len"] == 6
+    toks = [torch.tensor([[5, 6, 7]]), torch.tensor([[8]]), torch.tensor([[9, 10]])]
+    p = s.pad_tokens_cat(toks)
+    assert p.tolist() == [[5, 6, 7], [8, 1, 1], [9, 10, 1]]
+    s.model_version = 1.0
+    assert s.pad_tokens_cat(toks).tolist() == [[5, 6, 7], [8, 1, 1], [9, 10, 1]]
+    long = [torch.tensor([[5] * 12]), torch.tensor([[8]])]
+    assert s.pad_tokens_cat(long)[1].tolist() == [8] + [1] * 8 + [0] * 3
+    s.model_version = 1.5
+
+
+def test_tokenizer_glue_and_sentence_split():
+    assert tokenize_by_CJK_char("你好世界是 hello world 的中文") == "你 好 世 界 是 HELLO WORLD 的 中 文"
+    tk = TextTokenizer(None, TextNormalizer(), allow_synthetic=True)
+    with pytest.raises(ValueError):
+        TextTokenizer("/nonexistent/bpe.model", TextNormalizer())
+    toks = tk.tokenize("今天天气真好。我们去公园吧！")
+    ids = tk.convert_tokens_to_ids(toks)
+    assert len(ids) == len(toks) and all(7 <= i < 12000 for i in ids)
+    sp = TextTokenizer.split_sentences_by_token
+    t = list("abc.") + list("de.") + list("fghij.")
+    assert sp(t, ["."], 100) == [t]                               # everything merges back under the limit
+    assert sp(t, ["."], 6) == [list("abc."), list("de."), list("fghij.")]
+    assert sp(list("ab.cd."), ["."], 100) == [list("ab.cd.")]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert sp(list("abcdefghij"), ["."], 4) == [list("abcd"), list("e"), list("fghi"), list("j")]
+        assert any(issubclass(x.category, RuntimeWarning) for x in w)
+    assert sp(list("aaaa,bbbb,cc."), ["."], 6) == [list("aaaa,"), list("bb"), list("bb,cc.")]
+    assert sp([], ["."], 5) == []
+
+
+def test_config_and_checkpoint_formats(tmp_path):
+    cfgp = tmp_path / "config.yaml"
+    cfgp.write_text("gpt:\n  layers: 2\n  stop_mel_token: 8193\nversion: 1.5\nlist: [{a: 1}]\n")
+    cfg = load_config(str(cfgp))
+    assert cfg.gpt.layers == 2 and cfg["gpt"]["stop_mel_token"] == 8193 and cfg.version == 1.5
+    assert dict(**cfg.gpt) == {"layers": 2, "stop_mel_token": 8193} and cfg.list[0].a == 1 and "inference" not in cfg
+
+    class M:
+        mean_condition = None
+
+        def load_state_dict(self, sd, strict=False):
+            self.sd = sd
+    sd = {"a.weight": torch.ones(2, 2).half(), "mean_condition": torch.zeros(1, 32, 4)}
+    torch.save({"model": sd, "speaker_conditions": {"spk1": np.ones((32, 4), np.float32)}, "speakers": ["spk1"]},
+               tmp_path / "gpt.pth")
+    (tmp_path / "gpt.yaml").write_text("foo: 1\n")
+    m = M()
+    info = load_checkpoint(m, str(tmp_path / "gpt.pth"))
+    assert info == {"foo": 1, "speakers": ["spk1"]}
+    assert list(m.sd) == ["a.weight"] and m.mean_condition.shape == (1, 32, 4)
+    assert m.mean_condition_spk1.shape == (1, 32, 4)
+    torch.save({"a.weight": torch.ones(1)}, tmp_path / "bare.pt")
+    m2 = M()
+    assert load_checkpoint(m2, str(tmp_path / "bare.pt")) == {} and list(m2.sd) == ["a.weight"]
+
+
+def test_weight_norm_fold_and_filters():
+    g = np.load(os.path.join(G, "act1d.npz"))
+    np.testing.assert_allclose(kaiser_sinc_filter(), g["up_filter"], atol=2e-8)
+    v = torch.randn(6, 4, 3)
+    gg = torch.rand(6, 1, 1) + 0.5
+    w = fold_weight_norm(gg, v)
+    np.testing.assert_allclose(w.flatten(1).norm(dim=1).numpy(), gg.flatten().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(w.numpy(), torch._weight_norm(v, gg, 0).numpy(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("k,u", [(8, 4), (4, 4), (4, 2)])
+def test_transposed_conv_rewrite(k, u):
+    """y[t'] = x[q] W[..,s] + x[q-1] W[..,s+u] with t' + pad = q*u + s  (the identity the HIP path relies on)."""
+    Cin, Cout, T = 5, 3, 7
+    x = torch.randn(1, Cin, T)
+    w = torch.randn(Cin, Cout, k)
+    ref = F.conv_transpose1d(x, w, stride=u, padding=(k - u) // 2)[0].t()          # [T*u, Cout]
+    taps, off0, shift = convtr_as_conv(w, u)
+    rows = T + 1 if taps.shape[0] == 2 else T
+    xt = x[0].t()                                                                   # [T, Cin]
+    z = torch.zeros(rows, u * Cout)
+    for j in range(taps.shape[0]):
+        for q in range(rows):
+            i = q + off0 + j
+            if 0 <= i < T:
+                z[q] += xt[i] @ taps[j]
+    flat = torch.zeros(T * u * Cout)
+    zf = z.reshape(-1)
+    for idx in range(zf.numel()):
+        o = idx + shift
+        if 0 <= o < flat.numel():
+            flat[o] = zf[idx]
+    np.testing.assert_allclose(flat.view(T * u, Cout).numpy(), ref.numpy(), atol=1e-5)
+
+
+def test_mel_frontend_properties(tmp_path):
+    fb = mel_filterbank(513, 0.0, 12000.0, 100, 24000)
+    assert fb.shape == (513, 100) and (fb >= 0).all() and fb.max() <= 1.0 + 1e-6
+    assert (fb.argmax(0)[1:] >= fb.argmax(0)[:-1]).all()                           # centres increase
+    sr = 44100
+    t = torch.arange(sr) / sr
+    tone = torch.sin(2 * np.pi * 1000 * t)[None]
+    y = resample(tone, sr, 24000)
+    assert y.shape[-1] == 24000
+    ref = torch.sin(2 * np.pi * 1000 * torch.arange(24000) / 24000)
+    assert (y[0, 200:-200] - ref[200:-200]).abs().max() < 2e-3                      # band-limited tone survives resampling
+    mel = MelSpectrogramFeatures()(y)
+    assert mel.shape == (1, 100, 24000 // 256 + 1)
+    peak = mel[0, :, 10:-10].mean(-1).argmax().item()
+    centre_hz = 700 * (10 ** (np.linspace(0, 2595 * np.log10(1 + 12000 / 700), 102)[peak + 1] / 2595) - 1)
+    assert abs(centre_hz - 1000) < 80
+    assert mel.min() >= np.log(1e-7) - 1e-6
+    pcm = (np.clip(y[0].numpy(), -1, 1) * 32767).astype(np.int16)
+    write_pcm16(str(tmp_path / "a.wav"), pcm, 24000)
+    a, sr2 = read_audio(str(tmp_path / "a.wav"))
+    assert sr2 == 24000 and np.array_equal((a * 32768).round().astype(np.int16), pcm)
+
+
+def test_shard_utterances():
+    lens = [50, 10, 40, 40, 5, 90, 20, 20]
+    sh = shard_utterances(lens, 3)
+    assert sorted(i for s in sh for i in s) == list(range(8))
+    loads = [sum(lens[i] for i in s) for s in sh]
+    assert max(loads) - min(loads) <= 25 and sh[0][0] == 5
+    assert shard_utterances([3, 2, 1], 1) == [[0, 1, 2]]
+    assert shard_utterances([], 2) == [[], []]
