@@ -99,13 +99,27 @@ class KernelTimer:
             return 60.0 * x.numel(), 2 * x.numel() * x.element_size()
         return 0.0, 0.0
 
+    @staticmethod
+    def event_overhead_ms(n=200):
+        """Median elapsed time of an EMPTY event pair: what a start/stop pair adds on top of the kernel it brackets."""
+        pairs = []
+        for _ in range(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            e1.record()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize()
+        return float(np.median([a.elapsed_time(b) for a, b in pairs]))
+
     def summary(self):
         torch.cuda.synchronize()
+        ovh = self.event_overhead_ms()
+        self.overhead_ms = ovh
         agg = {}
         for n, e0, e1, (fl, by) in self.rec:
             d = agg.setdefault(n, [0, 0.0, 0.0, 0.0])
             d[0] += 1
-            d[1] += e0.elapsed_time(e1)
+            d[1] += max(e0.elapsed_time(e1) - ovh, 0.0)
             d[2] += fl
             d[3] += by
         return agg
@@ -124,7 +138,7 @@ def cpu_baseline(gsd, bsd, cond_conds, n_tokens=8):
     """Oracle (oracle/*.py, fp32, torch CPU) on ONE utterance of the same workload, n_tokens acoustic tokens:
     prefill + cached greedy steps + latent pass + vocoder.  Returns (audio_s_per_s, cores, description)."""
     from oracle import bigvgan_ref, gpt_ref
-    cores = os.cpu_count() or 1
+    cores = min(len(os.sched_getaffinity(0)), 16)  # the box's CPU share, not the host's core count
     torch.set_num_threads(cores)
     W = {k: v.float() for k, v in gsd.items() if k.startswith(("gpt.", "final_norm", "mel_", "text_"))}
     g = torch.Generator().manual_seed(2)
@@ -182,15 +196,18 @@ def main():
     gsd_d = broadcast_state(gsd, rank, world, device)
     bsd_d = broadcast_state(bsd, rank, world, device)
     cfg = weights.reference_config()
-    tts = IndexTTS.from_weights(cfg, gsd_d, bsd_d, device=device,
-                                precision_config={"gpt": "bf16", "vocoder": "fp16"})
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):  # keep stdout for the single JSON line
+        tts = IndexTTS.from_weights(cfg, gsd_d, bsd_d, device=device,
+                                    precision_config={"gpt": "bf16", "vocoder": "fp16"})
     del gsd_d, bsd_d
     cond_mel, texts = make_inputs(rank, device)
     force = [MEL_TOKENS] * BATCH
     gen = dict(do_sample=True, top_k=30, top_p=0.8, temperature=1.0, repetition_penalty=10.0, num_beams=1)
 
-    def step(seed):
-        return tts.infer_batch(cond_mel, texts, max_mel_tokens=MEL_TOKENS + 1, force_stop=force, seed=seed, **gen)
+    def step(seed, phase_events=None):
+        return tts.infer_batch(cond_mel, texts, max_mel_tokens=MEL_TOKENS + 1, force_stop=force, seed=seed,
+                               phase_events=phase_events, **gen)
 
     def barrier():
         torch.cuda.synchronize()
@@ -210,10 +227,26 @@ def main():
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    log(f"[bench] rank {rank}: {args.steps} steps in {elapsed:.3f}s")
     samples = sum(int(o.numel()) for o in outs)
     audio_s_step = samples / 24000.0
     assert samples == BATCH * MEL_TOKENS * 1024, f"unexpected audio length {samples}"
     value = audio_s_step * world * args.steps / elapsed
+
+    # phase split of one more (un-instrumented, graph-replayed) step
+    pe = {}
+    step(3000, pe)
+    torch.cuda.synchronize()
+    names = ["start", "conditioned", "prefilled", "decoded", "latents", "vocoded"]
+    phases = {f"{a}->{b}": round(pe[a].elapsed_time(pe[b]), 3) for a, b in zip(names[:-1], names[1:])}
+    eng = tts.gpt.engine
+    S0 = eng._S
+    dec_ms = phases["prefilled->decoded"]
+    step_us = 1e3 * dec_ms / MEL_TOKENS
+    ctx_mid = S0 + MEL_TOKENS // 2
+    dec_bytes = eng.step_bytes(BATCH, ctx_mid)
+    log(f"[bench] phases (ms): {phases}; decode step {step_us:.1f} us, {dec_bytes / 1e6:.0f} MB/step -> "
+        f"{dec_bytes / (step_us * 1e-6) / 1e9:.0f} GB/s")
 
     # p50 first-token latency: cached prompt mel -> conditioner + prefix + prefill + first sample
     lat_ms = []
@@ -242,6 +275,10 @@ def main():
                    "gpt_dtype": "bf16", "vocoder_dtype": "fp16", "parallelism": f"dp{world} (utterance sharding, no collectives)",
                    "audio_seconds_per_step_per_gpu": round(audio_s_step, 3)},
         "first_token_ms_p50": round(first_token_ms, 2),
+        "phases_ms": phases,
+        "decode_step": {"us": round(step_us, 2), "algorithmic_MB": round(dec_bytes / 1e6, 1), "ctx": ctx_mid,
+                        "GBps": round(dec_bytes / (step_us * 1e-6) / 1e9, 1),
+                        "frac_of_hbm_peak": round(dec_bytes / (step_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)},
     }
 
     if rank == 0 and not args.no_roofline:
@@ -280,6 +317,7 @@ def main():
                                        "avg_launch_us": round(1e3 * ms2 / c2, 2), "launches": c2}
         result["roofline"] = roof
         result["kernel_breakdown"] = breakdown
+        result["event_pair_overhead_us"] = round(1e3 * kt.overhead_ms, 2)
         log("[bench] kernel breakdown (instrumented eager step):", json.dumps(breakdown))
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

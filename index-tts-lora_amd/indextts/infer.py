@@ -438,11 +438,19 @@ class IndexTTS:
         return self._finish(wavs, output_path, start_time, gpt_gen_time, gpt_forward_time, bigvgan_time)
 
     def infer_batch(self, cond_mel: torch.Tensor, text_token_rows: List[torch.Tensor], max_mel_tokens=600, force_stop=None,
-                    seed=1234, return_codes=False, **generation_kwargs):
+                    seed=1234, return_codes=False, phase_events: dict | None = None, **generation_kwargs):
         """Utterance-batch data path used by bench.py / the multi-GPU sharder (not in the reference API): one shared
-        prompt, N independent texts decoded as ONE left-padded batch, one batched latent pass, one batched vocoder
-        call.  Returns a list of fp32 waveforms (already scaled to the int16 range, like infer.py:892)."""
+        prompt, N independent texts decoded as ONE left-padded batch, one batched latent pass, and one vocoder call per
+        group of equal-length utterances (batching unequal lengths would change the tail of the shorter waveforms).
+        Returns a list of fp32 waveforms already scaled to the int16 range, like infer.py:892.
+        phase_events, if given, receives torch.cuda.Event marks at the phase boundaries."""
+        def mark(name):
+            if phase_events is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                phase_events[name] = e
         gen, _ = self._gen_kwargs(generation_kwargs)
+        mark("start")
         conds = self.gpt.get_conditioning(cond_mel, torch.tensor([cond_mel.shape[-1]], device=self.device))
         spk = self.bigvgan.speaker_embedding(cond_mel.transpose(1, 2))
         L = max(int(t.numel()) for t in text_token_rows)
@@ -450,14 +458,33 @@ class IndexTTS:
         batch = torch.full((len(text_token_rows), L), stop, dtype=torch.int32, device=self.device)
         for i, t in enumerate(text_token_rows):
             batch[i, : t.numel()] = t.reshape(-1).to(self.device, torch.int32)
-        codes = self._generate(conds, batch, gen, max_mel_tokens, force_stop=force_stop, seed=seed)
+        g = self.gpt
+        _, emb, mask = g.prepare_gpt_inputs(conds, batch)
+        pad = (mask == 0).sum(dim=1).to(torch.int32)
+        sp = dict(do_sample=bool(gen["do_sample"]), top_p=float(gen["top_p"]), top_k=int(gen["top_k"]),
+                  temperature=float(gen["temperature"]), repetition_penalty=float(gen["repetition_penalty"]), seed=int(seed))
+        if not sp["do_sample"]:
+            sp["top_p"], sp["top_k"], sp["temperature"] = 1.0, 0, 1.0
+        mark("conditioned")
+        g.engine.prefill(emb, pad, max_mel_tokens)
+        mark("prefilled")
+        codes = g.engine.decode(max_mel_tokens, sp, force_stop=force_stop)
+        mark("decoded")
         codes_c, lens = self.remove_long_silence(codes)
         rows = [codes_c[i, : int(lens[i])] for i in range(codes_c.shape[0])]
         lat = self._latents(conds, [t.reshape(-1) for t in text_token_rows], rows)
-        Tm = max(int(x.shape[0]) for x in lat)
-        lb = torch.zeros(len(lat), Tm, lat[0].shape[1], dtype=torch.float32, device=self.device)
+        mark("latents")
+        outs = [None] * len(lat)
+        groups: Dict[int, List[int]] = {}
         for i, x in enumerate(lat):
-            lb[i, : x.shape[0]] = x
-        wav = self._vocode(lb, spk)
-        outs = [wav[i, : int(lat[i].shape[0]) * 1024] for i in range(len(lat))]
+            groups.setdefault(int(x.shape[0]), []).append(i)
+        for T, idx in groups.items():
+            if T == 0:
+                for i in idx:
+                    outs[i] = torch.zeros(0, device=self.device)
+                continue
+            wav = self._vocode(torch.stack([lat[i] for i in idx], 0), spk)
+            for j, i in enumerate(idx):
+                outs[i] = wav[j]
+        mark("vocoded")
         return (outs, rows) if return_codes else outs
