@@ -17,6 +17,7 @@
  *                             anti_alias_activation.cpp:19-22 / anti_alias_activation_cuda.cu:44-181,214-256, and its
  *                             torch twin alias_free_torch/act.py:10-28 (the numerical oracle).
  *   itts_gemm_skinny,
+ *   itts_ln_reduce,
  *   itts_attn_decode,
  *   itts_embed_step,
  *   itts_sample            <- one cached decode step of GPT2InferenceModel.forward (indextts/gpt/model.py:163-193)
@@ -76,29 +77,25 @@ int itts_aa_snake_fwd(const void* x, void* y, const float* alpha_log, const floa
                       const float* down_filter12, int B, int T, int C, int dtype, int layout, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
- * Skinny GEMM for the decode step: Y[M][N] = epi( pro(X)[M][K] @ W[K][N] + bias ), M <= 32 (bf16/f16) or <= 16 (f32)
- * rows per launch (larger M is processed in row chunks by the entry point).  One 16-column tile per workgroup,
- * the K range split over the workgroup's waves and reduced deterministically through LDS.
+ * Skinny GEMM for the decode step: Y[M][N] = epi( X[M][K] @ W[K][N] + bias ), M <= 32 (bf16/f16) or <= 16 (f32)
+ * rows per launch (larger M is processed in row chunks by the entry point).  One 16-column tile (x one K slice) per
+ * workgroup, the K range split over the workgroup's waves and reduced deterministically through LDS; every global
+ * load is issued before its first use (one memory round trip per launch).
  * ------------------------------------------------------------------------------------------------------------------ */
-#define ITTS_PRO_NONE 0 /* A = x (T [M][K]) */
-#define ITTS_PRO_LN 1   /* A = LayerNorm(h; ln_w, ln_b), h fp32 [M][K], eps 1e-5 */
-#define ITTS_PRO_LN2 2  /* A = LayerNorm(LayerNorm(h; ln_w, ln_b); ln2_w, ln2_b)  (ln_f then final_norm) */
-
 #define ITTS_EPI_STORE 0      /* y (T [M][N]) = v */
 #define ITTS_EPI_GELU_STORE 1 /* y (T [M][N]) = gelu_new(v) */
 #define ITTS_EPI_RESID_F32 2  /* yf (fp32 [M][N]) += v              (residual stream update) */
 #define ITTS_EPI_QKV_CACHE 3  /* cols [0,D): y (T [M][D]) = v ; [D,2D): K cache ; [2D,3D): V cache, at position *pos */
 #define ITTS_EPI_STORE_F32 4  /* yf (fp32 [M][N]) = v               (logits) */
+#define ITTS_EPI_SLAB_F32 5   /* yf (fp32 [ksplit][M][N]): slice ks stores its partial product (bias added by slice 0);
+                                 the slabs are summed in order by itts_ln_reduce */
 
 typedef struct itts_skinny_args {
   int dtype;
   int M, N, K;
   const void* wp;    /* packed W */
   const float* bias; /* [N] or NULL */
-  int pro;
-  const void* x;  /* PRO_NONE */
-  const float* h; /* PRO_LN / PRO_LN2 */
-  const float *ln_w, *ln_b, *ln2_w, *ln2_b;
+  const void* x;     /* T [M][K] */
   int epi;
   void* y;
   float* yf;
@@ -106,6 +103,7 @@ typedef struct itts_skinny_args {
   void* vcache;
   const int32_t* pos; /* device scalar: cache row to write */
   int heads, smax;
+  int ksplit; /* split-K over workgroups (grid.y); > 1 only with ITTS_EPI_SLAB_F32 */
 } itts_skinny_args;
 int itts_gemm_skinny(const itts_skinny_args* a, void* stream);
 
@@ -141,6 +139,13 @@ int itts_gemm_conv(const itts_conv_args* a, void* stream);
  * (w2,b2) is applied to the result of the first (ln_f followed by final_norm). */
 int itts_layernorm(const float* h, const float* w, const float* b, const float* w2, const float* b2, void* y, int y_f32,
                    int M, int D, int dtype, void* stream);
+
+/* Residual update + LayerNorm for the decode step, one wave per row:
+ *   if (nslab > 0)  h[m][:] += bias[:] + slab[0][m][:] + ... + slab[nslab-1][m][:]      (fixed order; h updated in place)
+ *   y[m][:] = LN(h[m][:]; w, b)   (then LN(.; w2, b2) if w2 != NULL),  y is T [M][D].
+ * slab is fp32 [nslab][M][D] as written by itts_gemm_skinny(ITTS_EPI_SLAB_F32). */
+int itts_ln_reduce(float* h, const float* slab, int nslab, const float* bias, const float* w, const float* b,
+                   const float* w2, const float* b2, void* y, int M, int D, int dtype, void* stream);
 
 /* h[b][:] = table[tokens[b]][:] + pos_table[*step + pos_add][:]   (fp32 tables, fp32 h) */
 int itts_embed_step(const int32_t* tokens, const float* table, const float* pos_table, const int32_t* step, int pos_add,

@@ -11,10 +11,21 @@ constexpr int HD = 64;  // head dim
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Decode: workgroup = (b, h), 4 waves.  Each lane owns a 16-byte slice of a key/value row (8 bf16 / 4 fp32 dims);
-// LPR = 64/E lanes cover one row, a wave-load covers 64/LPR rows (1 KiB, contiguous).  Pass A: scores -> LDS.
-// Pass B: softmax statistics.  Pass C: P.V with per-lane partial sums, reduced across row groups and waves.
+// LPR = 64/E lanes cover one row, a wave-load covers RPW = 64/LPR rows (1 KiB, contiguous).  Single pass with online
+// softmax: for a chunk of CH row groups the K AND V fragments are all requested before the first use (one memory round
+// trip per chunk; a typical 100-300 token context is one chunk), every lane keeps a running (max, sum, o[E]) for the
+// rows it saw, and the partial states are merged across row groups (shuffles) and waves (LDS) at the end.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int AD_MAXCTX = 2048;
+constexpr int AD_CH = 8;
+
+__device__ __forceinline__ void softmax_merge(float& m, float& l, float m2, float l2, float& sa, float& sb) {
+  float M = fmaxf(m, m2);
+  sa = (m == -INFINITY) ? 0.f : __expf(m - M);
+  sb = (m2 == -INFINITY) ? 0.f : __expf(m2 - M);
+  l = l * sa + l2 * sb;
+  m = M;
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ kc,
@@ -26,78 +37,95 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
   constexpr int E = EL::E;
   constexpr int LPR = HD / E;        // lanes per row: 8 (16-bit) / 16 (fp32)
   constexpr int RPW = 64 / LPR;      // rows per wave-load: 8 / 4
-  __shared__ float sc[AD_MAXCTX];
-  __shared__ float redm[4];
-  __shared__ float reds[4];
-  __shared__ float ored[4][HD];
+  __shared__ float w_m[4], w_l[4];
+  __shared__ float w_o[4][HD];
   const int h = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int part = lane % LPR, rg = lane / LPR;
   const int j0 = pad[b];
   const int ctx = pos[0] + 1;  // keys [j0, ctx)
-  const T* kb = kc + ((int64_t)b * H + h) * smax * HD;
-  const T* vb = vc + ((int64_t)b * H + h) * smax * HD;
+  const T* kb = kc + ((int64_t)b * H + h) * smax * HD + part * E;
+  const T* vb = vc + ((int64_t)b * H + h) * smax * HD + part * E;
 
-  // q slice (pre-scaled by 1/8)
   float qf[E];
   {
     frag qv = ld16<frag>(q + ((int64_t)b * H + h) * HD + part * E);
 #pragma unroll
     for (int e = 0; e < E; ++e) qf[e] = EL::to_f(qv[e]) * 0.125f;
   }
-  // pass A
-  float lmax = -INFINITY;
-  for (int j = j0 + wave * RPW + rg; j < ctx; j += 4 * RPW) {
-    // the LPR lanes of a row group share j, so the xor-shuffles below only pair lanes with the same trip count
-    frag kv = ld16<frag>(kb + (int64_t)j * HD + part * E);
-    float d = 0.f;
-#pragma unroll
-    for (int e = 0; e < E; ++e) d = fmaf(qf[e], EL::to_f(kv[e]), d);
-#pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) d += __shfl_xor(d, o, 64);
-    if (part == 0) sc[j - j0] = d;
-    lmax = fmaxf(lmax, d);
-  }
-  lmax = wave_max(lmax);
-  if (lane == 0) redm[wave] = lmax;
-  __syncthreads();
-  const float m = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
-  const int n = ctx - j0;
-  // pass B: p = exp(s - m), sum
-  float lsum = 0.f;
-  for (int i = tid; i < n; i += 256) {
-    float pv = __expf(sc[i] - m);
-    sc[i] = pv;
-    lsum += pv;
-  }
-  lsum = wave_sum(lsum);
-  if (lane == 0) reds[wave] = lsum;
-  __syncthreads();
-  const float inv = (n > 0) ? 1.0f / (reds[0] + reds[1] + reds[2] + reds[3]) : 0.f;
-  // pass C
-  float o[E];
+  float m = -INFINITY, l = 0.f, o[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) o[e] = 0.f;
-  for (int j = j0 + wave * RPW + rg; j < ctx; j += 4 * RPW) {
-    frag vv = ld16<frag>(vb + (int64_t)j * HD + part * E);
-    float pv = sc[j - j0];
+
+  for (int base = j0; base < ctx; base += 4 * RPW * AD_CH) {
+    frag kf[AD_CH], vf[AD_CH];
 #pragma unroll
-    for (int e = 0; e < E; ++e) o[e] = fmaf(pv, EL::to_f(vv[e]), o[e]);
+    for (int i = 0; i < AD_CH; ++i) {
+      int j = base + (i * 4 + wave) * RPW + rg;
+      bool ok = j < ctx;
+      kf[i] = ok ? ld16<frag>(kb + (int64_t)j * HD) : zero_frag<frag>();
+      vf[i] = ok ? ld16<frag>(vb + (int64_t)j * HD) : zero_frag<frag>();
+    }
+    float sc[AD_CH];
+    float cmax = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < AD_CH; ++i) {
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) d = fmaf(qf[e], EL::to_f(kf[i][e]), d);
+#pragma unroll
+      for (int off = 1; off < LPR; off <<= 1) d += __shfl_xor(d, off, 64);
+      int j = base + (i * 4 + wave) * RPW + rg;
+      sc[i] = (j < ctx) ? d : -INFINITY;
+      cmax = fmaxf(cmax, sc[i]);
+    }
+    if (cmax > -INFINITY) {
+      float M = fmaxf(m, cmax);
+      float corr = (m == -INFINITY) ? 0.f : __expf(m - M);
+      l *= corr;
+#pragma unroll
+      for (int e = 0; e < E; ++e) o[e] *= corr;
+#pragma unroll
+      for (int i = 0; i < AD_CH; ++i) {
+        float pv = __expf(sc[i] - M);  // -inf -> 0
+        l += pv;
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = fmaf(pv, EL::to_f(vf[i][e]), o[e]);
+      }
+      m = M;
+    }
   }
-  // reduce over row groups (lane bits above LPR)
+  // merge across the row groups of the wave (lanes that share `part`)
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
+  for (int off = LPR; off < 64; off <<= 1) {
+    float m2 = __shfl_xor(m, off, 64), l2 = __shfl_xor(l, off, 64);
+    float sa, sb;
+    softmax_merge(m, l, m2, l2, sa, sb);
 #pragma unroll
-    for (int off = LPR; off < 64; off <<= 1) o[e] += __shfl_xor(o[e], off, 64);
+    for (int e = 0; e < E; ++e) {
+      float o2 = __shfl_xor(o[e], off, 64);
+      o[e] = o[e] * sa + o2 * sb;
+    }
   }
   if (rg == 0) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) ored[wave][part * E + e] = o[e];
+    for (int e = 0; e < E; ++e) w_o[wave][part * E + e] = o[e];
+    if (part == 0) {
+      w_m[wave] = m;
+      w_l[wave] = l;
+    }
   }
   __syncthreads();
   if (tid < HD) {
-    float v = (ored[0][tid] + ored[1][tid]) + (ored[2][tid] + ored[3][tid]);
-    out[((int64_t)b * H + h) * HD + tid] = EL::from_f(v * inv);
+    float M = fmaxf(fmaxf(w_m[0], w_m[1]), fmaxf(w_m[2], w_m[3]));
+    float L = 0.f, acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      float sw = (w_m[w] == -INFINITY) ? 0.f : __expf(w_m[w] - M);
+      L += w_l[w] * sw;
+      acc += w_o[w][tid] * sw;
+    }
+    out[((int64_t)b * H + h) * HD + tid] = EL::from_f(L > 0.f ? acc / L : 0.f);
   }
 }
 

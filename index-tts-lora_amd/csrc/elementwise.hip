@@ -21,67 +21,111 @@ struct Fir24 {
 // window per thread from global memory).
 // -------------------------------------------------------------------------------------------------------------------
 constexpr int AA_TT = 32;
-constexpr int AA_CS_MAX = 64;
 
+// sin for the periodic term: exact library sinf in fp32 (parity) mode, hardware v_sin_f32 for 16-bit storage types
 template <typename T>
+__device__ __forceinline__ float aa_sin(float x) {
+  if constexpr (sizeof(T) == 4) return sinf(x);
+  else return __sinf(x);
+}
+
+// Work is vectorised over 4 adjacent channels everywhere (16-byte LDS accesses, 8/16-byte global accesses):
+//   x tile  rows  t0-6 .. t0+TT+5        (XR = TT+12, replicate-clamped at load)
+//   s tile  rows  m = 2*t0-6 .. 2*t0+2*TT+5  (SR = 2*TT+12), row pair (2i, 2i+1) from x rows i .. i+6
+//   y[t0+tt] = sum_j down[j] * s_tile[2*tt + 1 + j]
+template <typename T, int CS>
 __global__ __launch_bounds__(256) void aa_snake_btc_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                             const float* __restrict__ alpha_log,
-                                                            const float* __restrict__ beta_log, Fir24 f, int T_len, int C,
-                                                            int CS) {
-  __shared__ float xs[(AA_TT + 10) * AA_CS_MAX];
-  __shared__ float ss[(2 * AA_TT + 10) * AA_CS_MAX];
+                                                            const float* __restrict__ beta_log, Fir24 f, int T_len, int C) {
+  constexpr int XR = AA_TT + 12, SR = 2 * AA_TT + 12, NQ = AA_TT + 6, C4 = CS / 4;
+  __shared__ __attribute__((aligned(16))) float xs[XR * CS];
+  __shared__ __attribute__((aligned(16))) float ss[SR * CS];
+  __shared__ __attribute__((aligned(16))) float ca[CS];
+  __shared__ __attribute__((aligned(16))) float cb[CS];
+  typedef T t4 __attribute__((ext_vector_type(4)));
   const int t0 = blockIdx.x * AA_TT;
   const int c0 = blockIdx.y * CS;
   const int b = blockIdx.z;
   const int tid = threadIdx.x;
-  const T* xb = x + (int64_t)b * T_len * C;
-  T* yb = y + (int64_t)b * T_len * C;
-  const int cs = min(CS, C - c0);  // channels in this slab
+  const T* xb = x + (int64_t)b * T_len * C + c0;
+  T* yb = y + (int64_t)b * T_len * C + c0;
 
-  // phase 1: x tile, rows t0-5 .. t0+TT+4, replicate-clamped
-  for (int idx = tid; idx < (AA_TT + 10) * cs; idx += 256) {
-    int i = idx / cs, c = idx - i * cs;
-    int row = min(max(t0 - 5 + i, 0), T_len - 1);
-    xs[i * AA_CS_MAX + c] = Elem<T>::to_f(xb[(int64_t)row * C + c0 + c]);
+  if (tid < CS) {
+    ca[tid] = expf(alpha_log[c0 + tid]);
+    cb[tid] = 1.0f / (expf(beta_log[c0 + tid]) + 1e-9f);
+  }
+  // phase 1: x tile
+  for (int idx = tid; idx < XR * C4; idx += 256) {
+    int i = idx / C4, c4 = idx - i * C4;
+    int row = min(max(t0 - 6 + i, 0), T_len - 1);
+    t4 v = *reinterpret_cast<const t4*>(xb + (int64_t)row * C + c4 * 4);
+    f32x4 o = {Elem<T>::to_f(v[0]), Elem<T>::to_f(v[1]), Elem<T>::to_f(v[2]), Elem<T>::to_f(v[3])};
+    *reinterpret_cast<f32x4*>(&xs[i * CS + c4 * 4]) = o;
   }
   __syncthreads();
-
-  // phase 2: s[m] for m = 2*t0-5 .. 2*t0+2*TT+4
-  for (int idx = tid; idx < (2 * AA_TT + 10) * cs; idx += 256) {
-    int mi = idx / cs, c = idx - mi * cs;
-    int m = min(max(2 * t0 - 5 + mi, 0), 2 * T_len - 1);
-    int q = m >> 1;
-    float u = 0.f;
-    if (m & 1) {
+  // phase 2: upsample (polyphase, gain 2) + SnakeBeta -> s tile
+  for (int idx = tid; idx < NQ * C4; idx += 256) {
+    int i = idx / C4, c4 = idx - i * C4;
+    f32x4 xv[7];
 #pragma unroll
-      for (int d = -2; d <= 3; ++d) {
-        int row = min(max(q + d, 0), T_len - 1) - (t0 - 5);
-        u = fmaf(xs[row * AA_CS_MAX + c], f.up[6 - 2 * d], u);
-      }
-    } else {
+    for (int k = 0; k < 7; ++k) xv[k] = *reinterpret_cast<const f32x4*>(&xs[(i + k) * CS + c4 * 4]);
+    f32x4 ue = {0.f, 0.f, 0.f, 0.f}, uo = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int d = -3; d <= 2; ++d) {
-        int row = min(max(q + d, 0), T_len - 1) - (t0 - 5);
-        u = fmaf(xs[row * AA_CS_MAX + c], f.up[5 - 2 * d], u);
+    for (int k = 0; k < 6; ++k) {
+      float we = f.up[11 - 2 * k], wo = f.up[10 - 2 * k];  // even: x[q-3+k]*up[11-2k]; odd: x[q-2+k]*up[10-2k]
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ue[e] = fmaf(xv[k][e], we, ue[e]);
+        uo[e] = fmaf(xv[k + 1][e], wo, uo[e]);
       }
     }
-    u *= 2.0f;
-    float a = expf(alpha_log[c0 + c]);
-    float ib = 1.0f / (expf(beta_log[c0 + c]) + 1e-9f);
-    float sn = sinf(u * a);
-    ss[mi * AA_CS_MAX + c] = u + ib * sn * sn;
+    f32x4 a = *reinterpret_cast<const f32x4*>(&ca[c4 * 4]);
+    f32x4 ib = *reinterpret_cast<const f32x4*>(&cb[c4 * 4]);
+    f32x4 se, so;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float u = 2.0f * ue[e];
+      float sn = aa_sin<T>(u * a[e]);
+      se[e] = u + ib[e] * sn * sn;
+      u = 2.0f * uo[e];
+      sn = aa_sin<T>(u * a[e]);
+      so[e] = u + ib[e] * sn * sn;
+    }
+    *reinterpret_cast<f32x4*>(&ss[(2 * i) * CS + c4 * 4]) = se;
+    *reinterpret_cast<f32x4*>(&ss[(2 * i + 1) * CS + c4 * 4]) = so;
   }
   __syncthreads();
-
-  // phase 3: stride-2 low-pass
-  for (int idx = tid; idx < AA_TT * cs; idx += 256) {
-    int tt = idx / cs, c = idx - tt * cs;
+  // phase 2b: replicate padding of the UPSAMPLED signal at the sequence ends (block-uniform conditions)
+  const int m_base = 2 * t0 - 6;
+  if (m_base < 0) {
+    for (int idx = tid; idx < (-m_base) * CS; idx += 256) {
+      int mi = idx / CS, c = idx - mi * CS;
+      ss[mi * CS + c] = ss[(-m_base) * CS + c];
+    }
+    __syncthreads();
+  }
+  if (m_base + SR > 2 * T_len) {
+    const int last = 2 * T_len - 1 - m_base;  // tile row of m = 2T-1
+    for (int idx = tid; idx < (SR - 1 - last) * CS; idx += 256) {
+      int mi = last + 1 + idx / CS, c = idx % CS;
+      ss[mi * CS + c] = ss[last * CS + c];
+    }
+    __syncthreads();
+  }
+  // phase 3: 12-tap low-pass, stride 2
+  for (int idx = tid; idx < AA_TT * C4; idx += 256) {
+    int tt = idx / C4, c4 = idx - tt * C4;
     int t = t0 + tt;
     if (t >= T_len) break;
-    float acc = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 12; ++j) acc = fmaf(f.down[j], ss[(2 * tt + j) * AA_CS_MAX + c], acc);
-    yb[(int64_t)t * C + c0 + c] = Elem<T>::from_f(acc);
+    for (int j = 0; j < 12; ++j) {
+      f32x4 sv = *reinterpret_cast<const f32x4*>(&ss[(2 * tt + 1 + j) * CS + c4 * 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = fmaf(f.down[j], sv[e], acc[e]);
+    }
+    t4 o = {Elem<T>::from_f(acc[0]), Elem<T>::from_f(acc[1]), Elem<T>::from_f(acc[2]), Elem<T>::from_f(acc[3])};
+    *reinterpret_cast<t4*>(yb + (int64_t)t * C + c4 * 4) = o;
   }
 }
 
@@ -229,6 +273,98 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+// Residual update (sum of split-K slabs + bias, fixed order) fused with LayerNorm (optionally two in sequence);
+// one wave per row, every load issued up front.
+template <typename T>
+__global__ __launch_bounds__(64) void ln_reduce_kernel(float* __restrict__ h, const float* __restrict__ slab, int nslab,
+                                                        const float* __restrict__ bias, const float* __restrict__ w,
+                                                        const float* __restrict__ b, const float* __restrict__ w2,
+                                                        const float* __restrict__ b2, T* __restrict__ y, int M, int D) {
+  const int row = blockIdx.x, lane = threadIdx.x;
+  float* hr = h + (int64_t)row * D;
+  const int nv = D / 4;
+  f32x4 v[LN_MAXV];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    int idx = lane + i * 64;
+    v[i] = idx < nv ? ld16<f32x4>(hr + idx * 4) : f32x4{0, 0, 0, 0};
+  }
+  if (nslab > 0) {
+    if (bias != nullptr) {
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i) {
+        int idx = lane + i * 64;
+        if (idx < nv) {
+          f32x4 t = ld16<f32x4>(bias + idx * 4);
+          v[i] += t;
+        }
+      }
+    }
+    for (int sidx = 0; sidx < nslab; ++sidx) {
+      const float* sr = slab + ((int64_t)sidx * M + row) * D;
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i) {
+        int idx = lane + i * 64;
+        if (idx < nv) {
+          f32x4 t = ld16<f32x4>(sr + idx * 4);
+          v[i] += t;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      int idx = lane + i * 64;
+      if (idx < nv) st16(hr + idx * 4, v[i]);
+    }
+  }
+  for (int pass = 0; pass < 2; ++pass) {
+    const float* lw = pass == 0 ? w : w2;
+    const float* lb = pass == 0 ? b : b2;
+    if (lw == nullptr) break;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i)
+      if (lane + i * 64 < nv) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i)
+      if (lane + i * 64 < nv) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float d = v[i][e] - mean;
+          q = fmaf(d, d, q);
+        }
+      }
+    float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      int idx = lane + i * 64;
+      if (idx < nv) {
+        f32x4 ww = ld16<f32x4>(lw + idx * 4), bb = ld16<f32x4>(lb + idx * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mean) * rstd * ww[e] + bb[e];
+      }
+    }
+  }
+  T* yr = y + (int64_t)row * D;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    int idx = lane + i * 64;
+    if (idx < nv) {
+      if constexpr (sizeof(T) == 4) {
+        st16(yr + idx * 4, v[i]);
+      } else {
+        typedef T t4 __attribute__((ext_vector_type(4)));
+        t4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f(v[i][e]);
+        *reinterpret_cast<t4*>(yr + idx * 4) = o;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void embed_step_kernel(const int32_t* __restrict__ tokens, const float* __restrict__ table,
                                                           const float* __restrict__ pos_table,
                                                           const int32_t* __restrict__ step, int pos_add,
@@ -274,23 +410,35 @@ extern "C" int itts_aa_snake_fwd(const void* x, void* y, const float* alpha_log,
   }
   hipStream_t s = (hipStream_t)stream;
   if (layout == 0) {
-    int CS = C >= 64 ? 64 : C;
-    if (C > 64 && C % 64 != 0) CS = (C % 48 == 0) ? 48 : ((C % 32 == 0) ? 32 : 64);
-    dim3 grid((T + AA_TT - 1) / AA_TT, (C + CS - 1) / CS, B), block(256);
+    ITTS_REQUIRE(C % 4 == 0, "itts_aa_snake_fwd: C=%d must be a multiple of 4", C);
+    int CS = (C % 64 == 0) ? 64 : (C % 48 == 0) ? 48 : (C % 32 == 0) ? 32 : (C % 24 == 0) ? 24 : 0;
+    ITTS_REQUIRE(CS != 0, "itts_aa_snake_fwd: unsupported channel count %d (need a multiple of 24 or 32)", C);
+    dim3 grid((T + AA_TT - 1) / AA_TT, C / CS, B), block(256);
     ITTS_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "itts_aa_snake_fwd: grid too large");
+#define ITTS_AA_LAUNCH(TT_, CS_) \
+  hipLaunchKernelGGL((aa_snake_btc_kernel<TT_, CS_>), grid, block, 0, s, (const TT_*)x, (TT_*)y, alpha_log, beta_log, f, T, C)
+#define ITTS_AA_BY_CS(TT_)                         \
+  switch (CS) {                                    \
+    case 64: ITTS_AA_LAUNCH(TT_, 64); break;       \
+    case 48: ITTS_AA_LAUNCH(TT_, 48); break;       \
+    case 32: ITTS_AA_LAUNCH(TT_, 32); break;       \
+    default: ITTS_AA_LAUNCH(TT_, 24); break;       \
+  }
     switch (dtype) {
       case ITTS_F32:
-        hipLaunchKernelGGL(aa_snake_btc_kernel<float>, grid, block, 0, s, (const float*)x, (float*)y, alpha_log, beta_log, f, T, C, CS);
+        ITTS_AA_BY_CS(float);
         break;
       case ITTS_BF16:
-        hipLaunchKernelGGL(aa_snake_btc_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, (bf16_t*)y, alpha_log, beta_log, f, T, C, CS);
+        ITTS_AA_BY_CS(bf16_t);
         break;
       case ITTS_F16:
-        hipLaunchKernelGGL(aa_snake_btc_kernel<f16_t>, grid, block, 0, s, (const f16_t*)x, (f16_t*)y, alpha_log, beta_log, f, T, C, CS);
+        ITTS_AA_BY_CS(f16_t);
         break;
       default:
         ITTS_REQUIRE(false, "itts_aa_snake_fwd: unknown dtype %d", dtype);
     }
+#undef ITTS_AA_BY_CS
+#undef ITTS_AA_LAUNCH
   } else {
     ITTS_REQUIRE((int64_t)B * C <= 65535, "itts_aa_snake_fwd: B*C too large for layout 1");
     dim3 grid((T + 255) / 256, B * C), block(256);
@@ -332,6 +480,30 @@ extern "C" int itts_layernorm(const float* h, const float* w, const float* b, co
       ITTS_REQUIRE(false, "itts_layernorm: unknown dtype %d", dtype);
   }
   return check_launch("itts_layernorm");
+}
+
+extern "C" int itts_ln_reduce(float* h, const float* slab, int nslab, const float* bias, const float* w, const float* b,
+                              const float* w2, const float* b2, void* y, int M, int D, int dtype, void* stream) {
+  ITTS_REQUIRE(h && w && b && y, "itts_ln_reduce: null pointer");
+  ITTS_REQUIRE(nslab >= 0 && (nslab == 0 || slab != nullptr), "itts_ln_reduce: slab missing");
+  ITTS_REQUIRE(D % 4 == 0 && D <= 4 * 64 * LN_MAXV && D > 0, "itts_ln_reduce: unsupported D=%d", D);
+  if (M == 0) return ITTS_OK;
+  dim3 grid(M), block(64);
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case ITTS_F32:
+      hipLaunchKernelGGL(ln_reduce_kernel<float>, grid, block, 0, s, h, slab, nslab, bias, w, b, w2, b2, (float*)y, M, D);
+      break;
+    case ITTS_BF16:
+      hipLaunchKernelGGL(ln_reduce_kernel<bf16_t>, grid, block, 0, s, h, slab, nslab, bias, w, b, w2, b2, (bf16_t*)y, M, D);
+      break;
+    case ITTS_F16:
+      hipLaunchKernelGGL(ln_reduce_kernel<f16_t>, grid, block, 0, s, h, slab, nslab, bias, w, b, w2, b2, (f16_t*)y, M, D);
+      break;
+    default:
+      ITTS_REQUIRE(false, "itts_ln_reduce: unknown dtype %d", dtype);
+  }
+  return check_launch("itts_ln_reduce");
 }
 
 extern "C" int itts_embed_step(const int32_t* tokens, const float* table, const float* pos_table, const int32_t* step,

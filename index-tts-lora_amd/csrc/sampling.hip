@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
   __shared__ int si[SM_MAXC];
   __shared__ float rv[4];
   __shared__ int ri[4];
-  __shared__ int sh_n, sh_sel, sh_rem, sh_tok, sh_keep;
+  __shared__ int sh_n, sh_tok, sh_keep;
   __shared__ uint32_t sh_prefix;
 
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -120,33 +120,32 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
       for (int i = tid; i < V; i += 256) p.dbg_scores[(int64_t)b * V + i] = sv[i];
     __syncthreads();
   } else {
-    // ---- top-k threshold by 4-pass radix select on order-preserving keys
+    // ---- top-k threshold: the k-th largest order-preserving key, built bit by bit (32 counting rounds over the
+    //      register-resident keys; no LDS atomics -- random logits share their exponent bits, which serialises a radix
+    //      histogram on a handful of bins)
     int kk = p.top_k > 0 ? min(p.top_k, V) : min(V, SM_MAXC);
     if (kk > SM_MAXC) kk = SM_MAXC;
-    if (tid == 0) { sh_prefix = 0u; sh_rem = kk; }
-    __syncthreads();
-    for (int pass = 0; pass < 4; ++pass) {
-      const int shift = 24 - 8 * pass;
-      hist[tid] = 0;
-      __syncthreads();
-      const uint32_t prefix = sh_prefix;
-      const uint32_t himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-      for (int i = tid; i < V; i += 256) {
-        uint32_t key = fkey(sv[i]);
-        if ((key & himask) == (prefix & himask)) atomicAdd(&hist[(key >> shift) & 255], 1);
-      }
-      __syncthreads();
-      if (tid == 0) {
-        int rem = sh_rem, cum = 0, bin = 255;
-        for (; bin > 0; --bin) {
-          if (cum + hist[bin] >= rem) break;
-          cum += hist[bin];
-        }
-        sh_rem = rem - cum;
-        sh_prefix = prefix | ((uint32_t)bin << shift);
-      }
-      __syncthreads();
+    uint32_t keys[SM_MAXV / 256];
+#pragma unroll
+    for (int i = 0; i < SM_MAXV / 256; ++i) {
+      int idx = tid + i * 256;
+      keys[i] = idx < V ? fkey(sv[idx]) : 0u;  // key 0 is below every real float key
     }
+    uint32_t thr = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+      const uint32_t cand = thr | (1u << bit);
+      int cnt = 0;
+#pragma unroll
+      for (int i = 0; i < SM_MAXV / 256; ++i) cnt += keys[i] >= cand ? 1 : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+      int* slot = &hist[(bit & 1) * 4];
+      if (lane == 0) slot[wave] = cnt;
+      __syncthreads();
+      if (slot[0] + slot[1] + slot[2] + slot[3] >= kk) thr = cand;
+    }
+    if (tid == 0) sh_prefix = thr;
+    __syncthreads();
     const uint32_t kth = sh_prefix;  // key of the k-th largest score; ties with it are kept (HF: scores < kth removed)
     for (int i = tid; i < V; i += 256) {
       if (fkey(sv[i]) >= kth) {

@@ -11,8 +11,7 @@ import os
 import torch
 
 F32, BF16, F16 = 0, 1, 2
-PRO_NONE, PRO_LN, PRO_LN2 = 0, 1, 2
-EPI_STORE, EPI_GELU_STORE, EPI_RESID_F32, EPI_QKV_CACHE, EPI_STORE_F32 = 0, 1, 2, 3, 4
+EPI_STORE, EPI_GELU_STORE, EPI_RESID_F32, EPI_QKV_CACHE, EPI_STORE_F32, EPI_SLAB_F32 = 0, 1, 2, 3, 4, 5
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libindextts_hip.so")
@@ -24,10 +23,9 @@ class NativeError(RuntimeError):
 
 class SkinnyArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("wp", C.c_void_p),
-                ("bias", C.c_void_p), ("pro", C.c_int), ("x", C.c_void_p), ("h", C.c_void_p), ("ln_w", C.c_void_p),
-                ("ln_b", C.c_void_p), ("ln2_w", C.c_void_p), ("ln2_b", C.c_void_p), ("epi", C.c_int),
-                ("y", C.c_void_p), ("yf", C.c_void_p), ("kcache", C.c_void_p), ("vcache", C.c_void_p),
-                ("pos", C.c_void_p), ("heads", C.c_int), ("smax", C.c_int)]
+                ("bias", C.c_void_p), ("x", C.c_void_p), ("epi", C.c_int), ("y", C.c_void_p), ("yf", C.c_void_p),
+                ("kcache", C.c_void_p), ("vcache", C.c_void_p), ("pos", C.c_void_p), ("heads", C.c_int),
+                ("smax", C.c_int), ("ksplit", C.c_int)]
 
 
 class ConvArgs(C.Structure):
@@ -58,6 +56,8 @@ _SIGNATURES = {
     "itts_gemm_conv": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "itts_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "itts_ln_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_embed_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                   C.c_int, C.c_void_p]),
     "itts_attn_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -146,16 +146,13 @@ def aa_snake(x, alpha_log, beta_log, up_f, down_f, layout=0, out=None):
     return y
 
 
-def gemm_skinny(dtype, M, N, K, wp, bias=None, pro=PRO_NONE, x=None, h=None, ln=None, ln2=None, epi=EPI_STORE, y=None,
-                yf=None, kcache=None, vcache=None, pos=None, heads=0, smax=0):
+def gemm_skinny(dtype, M, N, K, wp, bias=None, x=None, epi=EPI_STORE, y=None, yf=None, kcache=None, vcache=None, pos=None,
+                heads=0, smax=0, ksplit=1):
     a = SkinnyArgs()
     a.dtype, a.M, a.N, a.K = dt(dtype), M, N, K
-    a.wp, a.bias, a.pro = _p(wp), _p(bias), pro
-    a.x, a.h = _p(x), _p(h)
-    a.ln_w, a.ln_b = (_p(ln[0]), _p(ln[1])) if ln else (None, None)
-    a.ln2_w, a.ln2_b = (_p(ln2[0]), _p(ln2[1])) if ln2 else (None, None)
+    a.wp, a.bias, a.x = _p(wp), _p(bias), _p(x)
     a.epi, a.y, a.yf = epi, _p(y), _p(yf)
-    a.kcache, a.vcache, a.pos, a.heads, a.smax = _p(kcache), _p(vcache), _p(pos), heads, smax
+    a.kcache, a.vcache, a.pos, a.heads, a.smax, a.ksplit = _p(kcache), _p(vcache), _p(pos), heads, smax, ksplit
     _check(lib().itts_gemm_skinny(C.byref(a), _stream()), "itts_gemm_skinny")
 
 
@@ -182,6 +179,14 @@ def layernorm(h, w, b, out, w2=None, b2=None):
     d = F32 if y_f32 else dt(out.dtype)
     _check(lib().itts_layernorm(_p(h), _p(w), _p(b), _p(w2), _p(b2), _p(out), int(y_f32), M, D, d, _stream()),
            "itts_layernorm")
+    return out
+
+
+def ln_reduce(h, w, b, out, slab=None, nslab=0, bias=None, w2=None, b2=None):
+    """h fp32 [M,D] (updated in place when nslab > 0) -> out T [M,D] = LN(h + bias + sum(slabs))."""
+    M, D = h.shape
+    _check(lib().itts_ln_reduce(_p(h), _p(slab), nslab, _p(bias), _p(w), _p(b), _p(w2), _p(b2), _p(out), M, D,
+                                dt(out.dtype), _stream()), "itts_ln_reduce")
     return out
 
 

@@ -57,6 +57,7 @@ class GPTEngine:
         self.extra_ids = torch.tensor([1, start_mel_token], dtype=torch.int32, device=dev)  # fake prefix ids (model.py:658-667)
         self._cap_b = self._cap_s = 0
         self._graphs = {}
+        self.KSPLIT = 4  # split-K of the two N=1280 GEMMs of a block (80 column tiles -> 320 workgroups)
         self.weight_bytes = sum(t.numel() * t.element_size() for l in self.layers for t in
                                 (l["w_qkv"], l["w_o"], l["w_fc"], l["w_pr"])) + self.w_head.numel()
 
@@ -76,6 +77,8 @@ class GPTEngine:
         self.q = torch.zeros(B, self.D, dtype=T, device=dev)
         self.a = torch.zeros(B, self.D, dtype=T, device=dev)
         self.f = torch.zeros(B, 4 * self.D, dtype=T, device=dev)
+        self.xn = torch.zeros(B, self.D, dtype=T, device=dev)
+        self.slab = torch.zeros(self.KSPLIT, B, self.D, dtype=torch.float32, device=dev)
         self.logits = torch.zeros(B, self.V, dtype=torch.float32, device=dev)
         self.tokens = torch.zeros(B, dtype=torch.int32, device=dev)
         self.finished = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -107,9 +110,15 @@ class GPTEngine:
             nat.gemm_conv(T, 1, M, M, 4 * D, D, l["w_pr"], ff, h, bias=l["b_pr"], y_f32=True, resid=h)
         return h
 
-    def _head(self, h_rows, B):
-        nat.gemm_skinny(self.dtype, B, self.V, self.D, self.w_head, self.b_head, pro=nat.PRO_LN2, h=h_rows, ln=self.ln_f,
-                        ln2=self.final_norm, epi=nat.EPI_STORE_F32, yf=self.logits)
+    def _head(self, h_rows, B, pending=None):
+        """ln_f -> final_norm -> mel_head on fp32 rows.  `pending` = (slab, nslab, bias): a residual update still to apply."""
+        if pending is None:
+            nat.ln_reduce(h_rows, self.ln_f[0], self.ln_f[1], self.xn[:B], w2=self.final_norm[0], b2=self.final_norm[1])
+        else:
+            nat.ln_reduce(h_rows, self.ln_f[0], self.ln_f[1], self.xn[:B], slab=pending[0], nslab=pending[1], bias=pending[2],
+                          w2=self.final_norm[0], b2=self.final_norm[1])
+        nat.gemm_skinny(self.dtype, B, self.V, self.D, self.w_head, self.b_head, x=self.xn, epi=nat.EPI_STORE_F32,
+                        yf=self.logits)
 
     def prefill(self, prefix_emb: torch.Tensor, pad: torch.Tensor, max_new: int):
         """prefix_emb fp32 [B,P,D] (left-padded with zeros), pad int [B].  Runs prefix + start token (mel position 0,
@@ -147,21 +156,34 @@ class GPTEngine:
                    sp["repetition_penalty"], sp["temperature"], sp["top_k"], sp["top_p"], sp["do_sample"], sp["seed"],
                    self.stop_mel, dbg)
 
-    def _step_kernels(self, B, sp):
-        """One cached decode step (model.py:163-193): embed token k at mel position k+1, 24 blocks, head, sample."""
-        T, D, H = self.dtype, self.D, self.H
+    def _step_transformer(self, B):
+        """Transformer part of one cached decode step (model.py:163-193): embed token k at mel position k+1, 24 blocks,
+        head.  Seven launches per block: [residual-reduce + LN1] -> QKV (+K/V append) -> attention -> out-proj (split-K
+        slabs) -> [residual-reduce + LN2] -> FC + gelu -> FC2 (split-K slabs); the slabs of FC2 are folded into the next
+        block's LN1 launch (or the head's)."""
+        T, D, H, KS = self.dtype, self.D, self.H, self.KSPLIT
         step, pos = self.state[0:1], self.state[1:2]
-        nat.embed_step(self.tokens, self.mel_emb, self.mel_pos, step, 1, self.h[:B])
+        h, xn = self.h[:B], self.xn[:B]
+        slab = self.slab.view(-1)[: KS * B * D].view(KS, B, D)  # [ks][B][D] on a contiguous prefix of the buffer
+        nat.embed_step(self.tokens, self.mel_emb, self.mel_pos, step, 1, h)
+        pending = None
         for i, l in enumerate(self.layers):
-            nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv"], l["b_qkv"], pro=nat.PRO_LN, h=self.h, ln=l["ln1"],
-                            epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i], vcache=self.vc[i], pos=pos, heads=H,
-                            smax=self._cap_s)
+            if pending is None:
+                nat.ln_reduce(h, l["ln1"][0], l["ln1"][1], xn)
+            else:
+                nat.ln_reduce(h, l["ln1"][0], l["ln1"][1], xn, slab=slab, nslab=KS, bias=pending)
+            nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv"], l["b_qkv"], x=xn, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
+                            vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s)
             nat.attn_decode(self.q, self.kc[i], self.vc[i], self.a, self.pad, pos, B, H, self._cap_s)
-            nat.gemm_skinny(T, B, D, D, l["w_o"], l["b_o"], x=self.a, epi=nat.EPI_RESID_F32, yf=self.h)
-            nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], pro=nat.PRO_LN, h=self.h, ln=l["ln2"],
-                            epi=nat.EPI_GELU_STORE, y=self.f)
-            nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], l["b_pr"], x=self.f, epi=nat.EPI_RESID_F32, yf=self.h)
-        self._head(self.h, B)
+            nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS)
+            nat.ln_reduce(h, l["ln2"][0], l["ln2"][1], xn, slab=slab, nslab=KS, bias=l["b_o"])
+            nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f)
+            nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], None, x=self.f, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS)
+            pending = l["b_pr"]
+        self._head(h, B, pending=(slab, KS, pending))
+
+    def _step_kernels(self, B, sp):
+        self._step_transformer(B)
         self._sample(B, sp)
 
     def decode(self, max_new: int, sp: dict, force_stop=None, use_graph=True, check_every=16, return_logits=False):

@@ -56,8 +56,7 @@ def test_gpt_decode_logits_and_latent_fp32(tag, layers, gpt_small_fp32):
         eng.tokens[:3] = torch.from_numpy(g["codes"][:, s - 1]).to(torch.int32).to(DEV)  # teacher forcing
         eng.history[:3, s - 1] = eng.tokens[:3]
         # the sample kernel already advanced state; run the transformer part of the step only
-        sp_nosample = None
-        eng_step_no_sample(eng, 3)
+        eng._step_transformer(3)
         errs.append((eng.logits[:3].cpu() - torch.from_numpy(g["logits"][s])).abs().max().item())
     assert max(errs) < 1e-3, errs
     # greedy choices equal the reference's wherever the decision margin is not razor thin
@@ -71,23 +70,6 @@ def test_gpt_decode_logits_and_latent_fp32(tag, layers, gpt_small_fp32):
     lat = m(cond_mel, text[0:1, :n], torch.tensor([n]), torch.from_numpy(g["codes"][0:1]).to(DEV),
             torch.tensor([steps * 1024]), cond_mel_lengths=torch.tensor([120], device=DEV), return_latent=True)
     assert (lat.cpu() - torch.from_numpy(g["latent_row0"])).abs().max().item() < 1e-3
-
-
-def eng_step_no_sample(eng, B):
-    """One decode step without the sampling kernel (state was advanced by the preceding _sample call)."""
-    from indextts import _native as nat
-    T, D, H = eng.dtype, eng.D, eng.H
-    step, pos = eng.state[0:1], eng.state[1:2]
-    nat.embed_step(eng.tokens, eng.mel_emb, eng.mel_pos, step, 1, eng.h[:B])
-    for i, l in enumerate(eng.layers):
-        nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv"], l["b_qkv"], pro=nat.PRO_LN, h=eng.h, ln=l["ln1"], epi=nat.EPI_QKV_CACHE,
-                        y=eng.q, kcache=eng.kc[i], vcache=eng.vc[i], pos=pos, heads=H, smax=eng._cap_s)
-        nat.attn_decode(eng.q, eng.kc[i], eng.vc[i], eng.a, eng.pad, pos, B, H, eng._cap_s)
-        nat.gemm_skinny(T, B, D, D, l["w_o"], l["b_o"], x=eng.a, epi=nat.EPI_RESID_F32, yf=eng.h)
-        nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], pro=nat.PRO_LN, h=eng.h, ln=l["ln2"], epi=nat.EPI_GELU_STORE,
-                        y=eng.f)
-        nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], l["b_pr"], x=eng.f, epi=nat.EPI_RESID_F32, yf=eng.h)
-    eng._head(eng.h, B)
 
 
 def test_decode_loop_graph_equals_eager_and_pad_invariance(gpt_small_fp32):

@@ -115,44 +115,54 @@ def test_gemm_skinny_plain(nat, dtype, M, N, K):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M", [1, 13, 32])
-def test_gemm_skinny_layernorm(nat, dtype, M):
-    K, N = 1280, 3840
-    h = rnd(M, K, seed=20, scale=2.0) + 0.3
-    lw, lb = 1 + 0.1 * rnd(K, seed=21), 0.1 * rnd(K, seed=22)
-    lw2, lb2 = 1 + 0.1 * rnd(K, seed=23), 0.1 * rnd(K, seed=24)
+def test_ln_reduce_and_splitk_slabs(nat, dtype, M):
+    """out-proj with split-K slabs, then residual-reduce + LayerNorm (+ second LayerNorm), as in one decode block."""
+    K, N, KSP = 5120, 1280, 4
+    x = rnd(M, K, seed=20).to(dtype)
     w = (rnd(K, N, seed=25) * 0.03).to(dtype)
     bias = rnd(N, seed=26)
     wp = nat.pack_weight(w)
-    xn = F.layer_norm(h, (K,), lw, lb, 1e-5)
-    xn_r = xn.to(dtype).float()  # the kernel rounds the normalised activations to T before the MFMA
-    ref = xn_r @ w.float() + bias
-    y = torch.empty(M, N, dtype=dtype, device=DEV)
-    nat.gemm_skinny(dtype, M, N, K, wp, bias, pro=nat.PRO_LN, h=h, ln=(lw, lb), epi=nat.EPI_STORE, y=y)
-    tol = 3e-4 if dtype == torch.float32 else 3e-2
-    assert (y.float() - ref).abs().max().item() < tol
-    xn2 = F.layer_norm(xn, (K,), lw2, lb2, 1e-5)
-    ref2 = xn2.to(dtype).float() @ w.float() + bias
-    yf = torch.empty(M, N, dtype=torch.float32, device=DEV)
-    nat.gemm_skinny(dtype, M, N, K, wp, bias, pro=nat.PRO_LN2, h=h, ln=(lw, lb), ln2=(lw2, lb2), epi=nat.EPI_STORE_F32,
-                    yf=yf)
-    assert (yf - ref2).abs().max().item() < (5e-4 if dtype == torch.float32 else 4e-2)
+    slab = torch.full((KSP, M, N), 123.0, device=DEV)
+    nat.gemm_skinny(dtype, M, N, K, wp, None, x=x, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KSP)
+    ref_mm = x.float() @ w.float()
+    assert (slab.sum(0) - ref_mm).abs().max().item() < (3e-4 if dtype == torch.float32 else 5e-3) * max(1.0, ref_mm.abs().max().item())
+    # each slab is exactly the partial product over its K slice
+    ks = K // KSP
+    for i in range(KSP):
+        part = x.float()[:, i * ks:(i + 1) * ks] @ w.float()[i * ks:(i + 1) * ks]
+        assert (slab[i] - part).abs().max().item() < (3e-4 if dtype == torch.float32 else 5e-3) * max(1.0, part.abs().max().item())
+    h0 = rnd(M, N, seed=27, scale=2.0) + 0.3
+    lw, lb = 1 + 0.1 * rnd(N, seed=21), 0.1 * rnd(N, seed=22)
+    lw2, lb2 = 1 + 0.1 * rnd(N, seed=23), 0.1 * rnd(N, seed=24)
+    h = h0.clone()
+    out = torch.empty(M, N, dtype=dtype, device=DEV)
+    nat.ln_reduce(h, lw, lb, out, slab=slab, nslab=KSP, bias=bias)
+    h_ref = h0 + bias + slab[0] + slab[1] + slab[2] + slab[3]
+    assert torch.equal(h, h_ref)                                  # fixed summation order -> bit-exact
+    ref = F.layer_norm(h_ref, (N,), lw, lb, 1e-5)
+    tol = 3e-5 if dtype == torch.float32 else 3e-2
+    assert (out.float() - ref).abs().max().item() < tol
+    h2 = h_ref.clone()
+    nat.ln_reduce(h2, lw, lb, out, w2=lw2, b2=lb2)                # no pending update: h untouched
+    assert torch.equal(h2, h_ref)
+    ref2 = F.layer_norm(ref, (N,), lw2, lb2, 1e-5)
+    assert (out.float() - ref2).abs().max().item() < (6e-5 if dtype == torch.float32 else 4e-2)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_skinny_qkv_cache(nat, dtype):
     M, D, H, smax = 5, 1280, 20, 40
-    h = rnd(M, D, seed=30)
-    lw, lb = 1 + 0.1 * rnd(D, seed=31), 0.1 * rnd(D, seed=32)
+    x = rnd(M, D, seed=30).to(dtype)
     w = (rnd(D, 3 * D, seed=33) * 0.03).to(dtype)
     bias = rnd(3 * D, seed=34)
     wp = nat.pack_weight(w)
-    ref = F.layer_norm(h, (D,), lw, lb, 1e-5).to(dtype).float() @ w.float() + bias
+    ref = x.float() @ w.float() + bias
     q = torch.zeros(M, D, dtype=dtype, device=DEV)
     kc = torch.zeros(M, H, smax, 64, dtype=dtype, device=DEV)
     vc = torch.zeros(M, H, smax, 64, dtype=dtype, device=DEV)
     pos = torch.tensor([17], dtype=torch.int32, device=DEV)
-    nat.gemm_skinny(dtype, M, 3 * D, D, wp, bias, pro=nat.PRO_LN, h=h, ln=(lw, lb), epi=nat.EPI_QKV_CACHE, y=q,
-                    kcache=kc, vcache=vc, pos=pos, heads=H, smax=smax)
+    nat.gemm_skinny(dtype, M, 3 * D, D, wp, bias, x=x, epi=nat.EPI_QKV_CACHE, y=q, kcache=kc, vcache=vc, pos=pos, heads=H,
+                    smax=smax)
     tol = 3e-4 if dtype == torch.float32 else 3e-2
     assert (q.float() - ref[:, :D]).abs().max().item() < tol
     assert (kc[:, :, 17, :].reshape(M, D).float() - ref[:, D:2 * D]).abs().max().item() < tol
@@ -254,13 +264,13 @@ def test_gemm_conv_plain_gemm_residual(nat, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_attn_decode(nat, dtype):
-    B, H, smax = 5, 20, 200
-    pos = 150
+@pytest.mark.parametrize("smax,pos", [(200, 150), (900, 777), (64, 0)])
+def test_attn_decode(nat, dtype, smax, pos):
+    B, H = 5, 20
     q = rnd(B, H * 64, seed=70).to(dtype)
     kc = rnd(B, H, smax, 64, seed=71).to(dtype)
     vc = rnd(B, H, smax, 64, seed=72).to(dtype)
-    pad = torch.tensor([0, 3, 17, 149, 150], dtype=torch.int32, device=DEV)
+    pad = torch.tensor([0, 3, 17, 149, 150], dtype=torch.int32, device=DEV).clamp(max=pos)
     out = torch.empty(B, H * 64, dtype=dtype, device=DEV)
     nat.attn_decode(q, kc, vc, out, pad, torch.tensor([pos], dtype=torch.int32, device=DEV), B, H, smax)
     qf = q.float().view(B, H, 1, 64)
