@@ -274,61 +274,55 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // Residual update (sum of split-K slabs + bias, fixed order) fused with LayerNorm (optionally two in sequence);
-// one wave per row, every load issued up front.
-template <typename T>
-__global__ __launch_bounds__(64) void ln_reduce_kernel(float* __restrict__ h, const float* __restrict__ slab, int nslab,
+// one wave per row.  NV (float4 per lane) and NSLAB are compile-time so that EVERY load -- h, bias, all slabs and both
+// LayerNorm parameter sets -- is issued before the first use: one memory round trip per launch.
+template <typename T, int NV, int NSLAB, bool LN2>
+__global__ __launch_bounds__(64) void ln_reduce_kernel(float* __restrict__ h, const float* __restrict__ slab,
                                                         const float* __restrict__ bias, const float* __restrict__ w,
                                                         const float* __restrict__ b, const float* __restrict__ w2,
                                                         const float* __restrict__ b2, T* __restrict__ y, int M, int D) {
   const int row = blockIdx.x, lane = threadIdx.x;
   float* hr = h + (int64_t)row * D;
   const int nv = D / 4;
-  f32x4 v[LN_MAXV];
+  f32x4 v[NV], bs[NV], sl[NSLAB > 0 ? NSLAB : 1][NV], lw[NV], lb[NV], lw2[LN2 ? NV : 1], lb2[LN2 ? NV : 1];
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     int idx = lane + i * 64;
-    v[i] = idx < nv ? ld16<f32x4>(hr + idx * 4) : f32x4{0, 0, 0, 0};
+    bool ok = idx < nv;
+    v[i] = ok ? ld16<f32x4>(hr + idx * 4) : zero;
+    lw[i] = ok ? ld16<f32x4>(w + idx * 4) : zero;
+    lb[i] = ok ? ld16<f32x4>(b + idx * 4) : zero;
+    if constexpr (LN2) {
+      lw2[i] = ok ? ld16<f32x4>(w2 + idx * 4) : zero;
+      lb2[i] = ok ? ld16<f32x4>(b2 + idx * 4) : zero;
+    }
+    if constexpr (NSLAB > 0) {
+      bs[i] = (ok && bias != nullptr) ? ld16<f32x4>(bias + idx * 4) : zero;
+#pragma unroll
+      for (int sidx = 0; sidx < NSLAB; ++sidx)
+        sl[sidx][i] = ok ? ld16<f32x4>(slab + ((int64_t)sidx * M + row) * D + idx * 4) : zero;
+    }
   }
-  if (nslab > 0) {
-    if (bias != nullptr) {
+  if constexpr (NSLAB > 0) {
 #pragma unroll
-      for (int i = 0; i < LN_MAXV; ++i) {
-        int idx = lane + i * 64;
-        if (idx < nv) {
-          f32x4 t = ld16<f32x4>(bias + idx * 4);
-          v[i] += t;
-        }
-      }
-    }
-    for (int sidx = 0; sidx < nslab; ++sidx) {
-      const float* sr = slab + ((int64_t)sidx * M + row) * D;
+    for (int i = 0; i < NV; ++i) {
+      v[i] += bs[i];
 #pragma unroll
-      for (int i = 0; i < LN_MAXV; ++i) {
-        int idx = lane + i * 64;
-        if (idx < nv) {
-          f32x4 t = ld16<f32x4>(sr + idx * 4);
-          v[i] += t;
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+      for (int sidx = 0; sidx < NSLAB; ++sidx) v[i] += sl[sidx][i];
       int idx = lane + i * 64;
       if (idx < nv) st16(hr + idx * 4, v[i]);
     }
   }
-  for (int pass = 0; pass < 2; ++pass) {
-    const float* lw = pass == 0 ? w : w2;
-    const float* lb = pass == 0 ? b : b2;
-    if (lw == nullptr) break;
+#pragma unroll
+  for (int pass = 0; pass < (LN2 ? 2 : 1); ++pass) {
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i)
-      if (lane + i * 64 < nv) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    for (int i = 0; i < NV; ++i) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];  // padding lanes hold zeros
     float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i)
+    for (int i = 0; i < NV; ++i)
       if (lane + i * 64 < nv) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -338,18 +332,20 @@ __global__ __launch_bounds__(64) void ln_reduce_kernel(float* __restrict__ h, co
       }
     float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-5f);
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      int idx = lane + i * 64;
-      if (idx < nv) {
-        f32x4 ww = ld16<f32x4>(lw + idx * 4), bb = ld16<f32x4>(lb + idx * 4);
+    for (int i = 0; i < NV; ++i) {
+      if (lane + i * 64 < nv) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mean) * rstd * ww[e] + bb[e];
+        for (int e = 0; e < 4; ++e) {
+          float ww = pass == 0 ? lw[i][e] : lw2[LN2 ? i : 0][e];
+          float bb = pass == 0 ? lb[i][e] : lb2[LN2 ? i : 0][e];
+          v[i][e] = (v[i][e] - mean) * rstd * ww + bb;
+        }
       }
     }
   }
   T* yr = y + (int64_t)row * D;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     int idx = lane + i * 64;
     if (idx < nv) {
       if constexpr (sizeof(T) == 4) {
@@ -363,6 +359,28 @@ __global__ __launch_bounds__(64) void ln_reduce_kernel(float* __restrict__ h, co
       }
     }
   }
+}
+
+template <typename T, int NV>
+static int launch_ln_reduce(float* h, const float* slab, int nslab, const float* bias, const float* w, const float* b,
+                            const float* w2, const float* b2, T* y, int M, int D, hipStream_t s) {
+  dim3 grid(M), block(64);
+  const bool two = w2 != nullptr;
+#define ITTS_LNR(NS, L2) hipLaunchKernelGGL((ln_reduce_kernel<T, NV, NS, L2>), grid, block, 0, s, h, slab, bias, w, b, w2, b2, y, M, D)
+  if (nslab == 0) {
+    if (two) ITTS_LNR(0, true); else ITTS_LNR(0, false);
+  } else if (nslab == 4) {
+    if (two) ITTS_LNR(4, true); else ITTS_LNR(4, false);
+  } else if (nslab == 2) {
+    if (two) ITTS_LNR(2, true); else ITTS_LNR(2, false);
+  } else if (nslab == 1) {
+    if (two) ITTS_LNR(1, true); else ITTS_LNR(1, false);
+  } else {
+    set_error("itts_ln_reduce: nslab must be 0, 1, 2 or 4 (got %d)", nslab);
+    return ITTS_ERR_INVALID;
+  }
+#undef ITTS_LNR
+  return check_launch("itts_ln_reduce");
 }
 
 __global__ __launch_bounds__(256) void embed_step_kernel(const int32_t* __restrict__ tokens, const float* __restrict__ table,
@@ -486,24 +504,24 @@ extern "C" int itts_ln_reduce(float* h, const float* slab, int nslab, const floa
                               const float* w2, const float* b2, void* y, int M, int D, int dtype, void* stream) {
   ITTS_REQUIRE(h && w && b && y, "itts_ln_reduce: null pointer");
   ITTS_REQUIRE(nslab >= 0 && (nslab == 0 || slab != nullptr), "itts_ln_reduce: slab missing");
-  ITTS_REQUIRE(D % 4 == 0 && D <= 4 * 64 * LN_MAXV && D > 0, "itts_ln_reduce: unsupported D=%d", D);
+  ITTS_REQUIRE((w2 == nullptr) == (b2 == nullptr), "itts_ln_reduce: pass both or neither of w2/b2");
+  ITTS_REQUIRE(D % 4 == 0 && D <= 4 * 64 * 8 && D > 0, "itts_ln_reduce: unsupported D=%d (max 2048)", D);
   if (M == 0) return ITTS_OK;
-  dim3 grid(M), block(64);
   hipStream_t s = (hipStream_t)stream;
+  const int nvl = (D / 4 + 63) / 64;  // float4 per lane
+#define ITTS_LNR_T(TT_)                                                                                         \
+  (nvl <= 5 ? launch_ln_reduce<TT_, 5>(h, slab, nslab, bias, w, b, w2, b2, (TT_*)y, M, D, s)                     \
+            : launch_ln_reduce<TT_, 8>(h, slab, nslab, bias, w, b, w2, b2, (TT_*)y, M, D, s))
   switch (dtype) {
     case ITTS_F32:
-      hipLaunchKernelGGL(ln_reduce_kernel<float>, grid, block, 0, s, h, slab, nslab, bias, w, b, w2, b2, (float*)y, M, D);
-      break;
+      return ITTS_LNR_T(float);
     case ITTS_BF16:
-      hipLaunchKernelGGL(ln_reduce_kernel<bf16_t>, grid, block, 0, s, h, slab, nslab, bias, w, b, w2, b2, (bf16_t*)y, M, D);
-      break;
+      return ITTS_LNR_T(bf16_t);
     case ITTS_F16:
-      hipLaunchKernelGGL(ln_reduce_kernel<f16_t>, grid, block, 0, s, h, slab, nslab, bias, w, b, w2, b2, (f16_t*)y, M, D);
-      break;
-    default:
-      ITTS_REQUIRE(false, "itts_ln_reduce: unknown dtype %d", dtype);
+      return ITTS_LNR_T(f16_t);
   }
-  return check_launch("itts_ln_reduce");
+#undef ITTS_LNR_T
+  ITTS_REQUIRE(false, "itts_ln_reduce: unknown dtype %d", dtype);
 }
 
 extern "C" int itts_embed_step(const int32_t* tokens, const float* table, const float* pos_table, const int32_t* step,

@@ -47,6 +47,15 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
   const char* bp = (const char*)p.wp + ((int64_t)nt * KT * 64 + lane) * 16;
   const T* X = (const T*)p.x;
 
+  // epilogue operands are requested now, so that their latency overlaps the weight stream
+  float bias_pre = 0.f;
+  int pos_pre = 0;
+  if (tid < MT * 256) {
+    int col = nt * 16 + (tid & 15);
+    if (p.bias != nullptr && ks == 0 && col < p.N) bias_pre = p.bias[col];
+    if (p.epi == ITTS_EPI_QKV_CACHE) pos_pre = p.pos[0];
+  }
+
   f32x4 acc[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -83,7 +92,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
     int mt = e >> 8, rr = (e >> 4) & 15, c = e & 15;
     int row = mt * 16 + rr, col = nt * 16 + c;
     if (row >= p.M || col >= p.N) continue;
-    float bs = (p.bias != nullptr && ks == 0) ? p.bias[col] : 0.f;  // issued before the LDS sum
+    float bs = (e == tid) ? bias_pre : ((p.bias != nullptr && ks == 0) ? p.bias[col] : 0.f);
     int src = ((rr >> 2) << 4) | c, j = rr & 3;
     float v = 0.f;
     for (int w = 0; w < NW; ++w) v += red[((w * MT + mt) * 64 + src) * 4 + j];
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
           T* cache = (T*)(cc < D ? p.kcache : p.vcache);
           if (cc >= D) cc -= D;
           int hh = cc >> 6, dd = cc & 63;
-          int pos = p.pos[0];
+          int pos = (e == tid) ? pos_pre : p.pos[0];
           cache[(((int64_t)row * p.heads + hh) * p.smax + pos) * 64 + dd] = EL::from_f(v);
         }
       } break;
