@@ -14,6 +14,8 @@ Data layout in HBM
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import _native as nat
@@ -58,6 +60,9 @@ class GPTEngine:
         self._cap_b = self._cap_s = 0
         self._graphs = {}
         self.KSPLIT = 4  # split-K of the two N=1280 GEMMs of a block (80 column tiles -> 320 workgroups)
+        self.prefetch_blocks = int(os.environ.get("ITTS_PREFETCH_BLOCKS", "64"))  # side-stream weight prefetch; 0 = off
+        self._side = None
+        self._sink = torch.zeros(4, dtype=torch.int32, device=dev)
         self.weight_bytes = sum(t.numel() * t.element_size() for l in self.layers for t in
                                 (l["w_qkv"], l["w_o"], l["w_fc"], l["w_pr"])) + self.w_head.numel()
 
@@ -165,9 +170,29 @@ class GPTEngine:
         step, pos = self.state[0:1], self.state[1:2]
         h, xn = self.h[:B], self.xn[:B]
         slab = self.slab.view(-1)[: KS * B * D].view(KS, B, D)  # [ks][B][D] on a contiguous prefix of the buffer
+        # Side stream: while block i runs (latency-bound launches), block i+1's weights are pulled into the Infinity Cache.
+        main = torch.cuda.current_stream()
+        side = None
+        if self.prefetch_blocks > 0:
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            side = self._side
+
+        def prefetch(tensors):
+            if side is None:
+                return
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                nat.prefetch(tensors, self.prefetch_blocks, self._sink)
+
         nat.embed_step(self.tokens, self.mel_emb, self.mel_pos, step, 1, h)
         pending = None
         for i, l in enumerate(self.layers):
+            if i + 1 < self.L:
+                n = self.layers[i + 1]
+                prefetch([n["w_qkv"], n["w_o"], n["w_fc"], n["w_pr"]])
+            else:
+                prefetch([self.w_head])
             if pending is None:
                 nat.ln_reduce(h, l["ln1"][0], l["ln1"][1], xn)
             else:
@@ -180,7 +205,11 @@ class GPTEngine:
             nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f)
             nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], None, x=self.f, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS)
             pending = l["b_pr"]
+        n0 = self.layers[0]
+        prefetch([n0["w_qkv"], n0["w_o"], n0["w_fc"], n0["w_pr"]])  # for the next token, under the head + sampling
         self._head(h, B, pending=(slab, KS, pending))
+        if side is not None:
+            main.wait_stream(side)
 
     def _step_kernels(self, B, sp):
         self._step_transformer(B)
