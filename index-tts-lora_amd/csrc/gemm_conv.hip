@@ -13,8 +13,6 @@
 
 namespace itts {
 
-constexpr int CV_CK = 2;                        // k-steps per staged chunk
-constexpr int CV_ROWB = CV_CK * 64 + 16;        // LDS bytes per staged row (128 B payload + 16 B pad)
 constexpr int CV_MAX_HALO = 64;                 // (taps-1)*dil must not exceed this
 
 struct ConvParams {
@@ -35,13 +33,17 @@ struct ConvParams {
   int NT, KT;
 };
 
-template <typename T, int WM, int WN, int TM, int TN>
+// CK = k-steps of channels staged per chunk (2 for convolutions, whose taps multiply the MFMA work per chunk; 4 for
+// plain GEMMs).  HALO = compile-time bound on (taps-1)*dil (0 for plain GEMMs) that sizes the staging registers.
+template <typename T, int WM, int WN, int TM, int TN, int CK, int HALO>
 __global__ __launch_bounds__(256) void gemm_conv_kernel(ConvParams p) {
   typedef Elem<T> EL;
   typedef typename EL::frag frag;
   constexpr int E = EL::E, KS = EL::KS;
   constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
-  constexpr int MAXST = ((BM + CV_MAX_HALO) * 8 + 255) / 256;
+  constexpr int SEGS = CK * 4;                 // 16-byte segments per staged row
+  constexpr int ROWB = CK * 64 + 16;           // LDS bytes per staged row (payload + 16 B pad: conflict-free b128 reads)
+  constexpr int MAXST = ((BM + HALO) * SEGS + 255) / 256;
   static_assert(WM * WN == 4, "4 waves per workgroup");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -51,8 +53,8 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(ConvParams p) {
   const int t0 = blockIdx.x * BM;
   const int nt0 = blockIdx.y * (BN / 16) + wn * TN;
   const int b = blockIdx.z;
-  const int HR = BM + (p.taps - 1) * p.dil;  // staged rows
-  const int NC = (p.KT + CV_CK - 1) / CV_CK;  // channel chunks
+  const int HR = BM + (p.taps - 1) * p.dil;   // staged rows
+  const int NC = (p.KT + CK - 1) / CK;        // channel chunks
   const T* xb = (const T*)p.x + (int64_t)b * p.x_bstride;
   const char* wp = (const char*)p.wp;
 
@@ -63,58 +65,76 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(ConvParams p) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   frag stg[MAXST];
-  auto prefetch = [&](int c) {
+  auto prefetch_a = [&](int c) {
 #pragma unroll
     for (int q = 0; q < MAXST; ++q) {
       int idx = tid + q * 256;
-      int i = idx >> 3, seg = idx & 7;
+      int i = idx / SEGS, seg = idx - i * SEGS;
       int tin = t0 + p.off0 + i;
-      int col = c * (CV_CK * KS) + seg * E;
+      int col = c * (CK * KS) + seg * E;
       bool ok = (i < HR) && (tin >= 0) && (tin < p.Tin) && (col < p.Cin);
       stg[q] = ok ? ld16<frag>(xb + (int64_t)tin * p.Cin + col) : zero_frag<frag>();
     }
   };
-  auto commit = [&]() {
+  auto commit_a = [&]() {
 #pragma unroll
     for (int q = 0; q < MAXST; ++q) {
       int idx = tid + q * 256;
-      int i = idx >> 3, seg = idx & 7;
-      if (i < HR) st16(lds + i * CV_ROWB + seg * 16, stg[q]);
+      int i = idx / SEGS, seg = idx - i * SEGS;
+      if (i < HR) st16(lds + i * ROWB + seg * 16, stg[q]);
     }
   };
-  prefetch(0);
+  // Flat step space: step s = (chunk c, tap j, k-step kk within the chunk); weight block = ((j*NT + nt)*KT + c*CK + kk).
+  // The last chunk may hold fewer than CK k-steps.
+  auto fetch_b = [&](frag (&bf)[TN], int c, int j, int kk) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      int nt = nt0 + tn;
+      bool ok = (nt < p.NT) && (c < NC);
+      bf[tn] = ok ? ld16<frag>(wp + ((((int64_t)j * p.NT + nt) * p.KT + c * CK + kk) * 64 + lane) * 16) : zero_frag<frag>();
+    }
+  };
+  auto advance = [&](int& c, int& j, int& kk) {
+    int nkk = min(CK, p.KT - c * CK);
+    if (++kk == nkk) {
+      kk = 0;
+      if (++j == p.taps) {
+        j = 0;
+        ++c;
+      }
+    }
+  };
+
+  frag b0[TN], b1[TN], b2[TN];
+  int fc = 0, fj = 0, fk = 0;  // cursor of the next weight fetch
+  fetch_b(b0, fc, fj, fk);
+  advance(fc, fj, fk);
+  fetch_b(b1, fc, fj, fk);
+  advance(fc, fj, fk);
+  prefetch_a(0);
   for (int c = 0; c < NC; ++c) {
     __syncthreads();  // everyone finished reading the previous chunk
-    commit();
+    commit_a();
     __syncthreads();
-    if (c + 1 < NC) prefetch(c + 1);
-    const int ks0 = c * CV_CK;
-    const int nkk = min(CV_CK, p.KT - ks0);
-    const int nit = p.taps * nkk;
-    frag bcur[TN], bnxt[TN];
-    // B block for (tap j, k-step ks, n-tile nt): ((j*NT + nt)*KT + ks) * 1024 bytes
-    auto fetch_b = [&](frag (&bf)[TN], int it) {
-      int j = it / nkk, kk = it - j * nkk;
+    if (c + 1 < NC) prefetch_a(c + 1);
+    const int nkk = min(CK, p.KT - c * CK);
+    for (int j = 0; j < p.taps; ++j) {
+      for (int kk = 0; kk < nkk; ++kk) {
+        fetch_b(b2, fc, fj, fk);  // two steps ahead; crosses chunk boundaries, so no bubble after the barriers
+        advance(fc, fj, fk);
+        const unsigned char* abase = lds + (wm * TM * 16 + r + j * p.dil) * ROWB + kk * 64 + g * 16;
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        int nt = nt0 + tn;
-        bf[tn] = (nt < p.NT) ? ld16<frag>(wp + ((((int64_t)j * p.NT + nt) * p.KT + ks0 + kk) * 64 + lane) * 16)
-                             : zero_frag<frag>();
+        for (int tm = 0; tm < TM; ++tm) {
+          frag af = ld16<frag>(abase + tm * 16 * ROWB);
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = EL::mma(af, b0[tn], acc[tm][tn]);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          b0[tn] = b1[tn];
+          b1[tn] = b2[tn];
+        }
       }
-    };
-    fetch_b(bcur, 0);
-    for (int it = 0; it < nit; ++it) {
-      if (it + 1 < nit) fetch_b(bnxt, it + 1);
-      int j = it / nkk, kk = it - j * nkk;
-      const unsigned char* abase = lds + (wm * TM * 16 + r + j * p.dil) * CV_ROWB + kk * 64 + g * 16;
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        frag af = ld16<frag>(abase + tm * 16 * CV_ROWB);
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = EL::mma(af, bcur[tn], acc[tm][tn]);
-      }
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) bcur[tn] = bnxt[tn];
     }
   }
 
@@ -154,27 +174,34 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(ConvParams p) {
   }
 }
 
-template <typename T, int WM, int WN, int TM, int TN>
+template <typename T, int WM, int WN, int TM, int TN, int CK, int HALO>
 static int launch_conv(const ConvParams& p, hipStream_t s) {
   constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
   int HR = BM + (p.taps - 1) * p.dil;
-  size_t ldsb = (size_t)HR * CV_ROWB;
+  size_t ldsb = (size_t)HR * (CK * 64 + 16);
   dim3 grid((p.Tout + BM - 1) / BM, (p.N + BN - 1) / BN, p.B);
   if (grid.y > 65535 || grid.z > 65535) {
     set_error("itts_gemm_conv: grid too large (%u,%u,%u)", grid.x, grid.y, grid.z);
     return ITTS_ERR_INVALID;
   }
-  hipLaunchKernelGGL((gemm_conv_kernel<T, WM, WN, TM, TN>), grid, dim3(256), ldsb, s, p);
+  static bool attr = false;
+  if (!attr && ldsb > 64 * 1024) {
+    hipFuncSetAttribute((const void*)gemm_conv_kernel<T, WM, WN, TM, TN, CK, HALO>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemm_conv_kernel<T, WM, WN, TM, TN, CK, HALO>), grid, dim3(256), ldsb, s, p);
   return check_launch("itts_gemm_conv");
 }
 
 template <typename T>
 static int dispatch_conv(const ConvParams& p, hipStream_t s) {
-  if (p.N % 128 == 0) return launch_conv<T, 1, 4, 16, 2>(p, s);
-  if (p.N % 64 == 0) return launch_conv<T, 2, 2, 8, 2>(p, s);
-  if (p.N % 96 == 0) return launch_conv<T, 4, 1, 4, 6>(p, s);
-  if (p.N % 48 == 0) return launch_conv<T, 4, 1, 4, 3>(p, s);
-  return launch_conv<T, 4, 1, 4, 2>(p, s);
+  const bool plain = (p.taps == 1);  // GEMM: no halo, 4 k-steps per chunk
+  if (p.N % 128 == 0) return plain ? launch_conv<T, 1, 4, 16, 2, 4, 0>(p, s) : launch_conv<T, 1, 4, 16, 2, 2, CV_MAX_HALO>(p, s);
+  if (p.N % 64 == 0) return plain ? launch_conv<T, 2, 2, 8, 2, 4, 0>(p, s) : launch_conv<T, 2, 2, 8, 2, 2, CV_MAX_HALO>(p, s);
+  if (p.N % 96 == 0) return launch_conv<T, 2, 2, 8, 3, 2, CV_MAX_HALO>(p, s);
+  if (p.N % 48 == 0) return launch_conv<T, 4, 1, 8, 3, 2, CV_MAX_HALO>(p, s);
+  return launch_conv<T, 4, 1, 8, 2, 2, CV_MAX_HALO>(p, s);
 }
 
 }  // namespace itts

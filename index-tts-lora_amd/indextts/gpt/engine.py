@@ -60,7 +60,7 @@ class GPTEngine:
         self._cap_b = self._cap_s = 0
         self._graphs = {}
         self.KSPLIT = 4  # split-K of the two N=1280 GEMMs of a block (80 column tiles -> 320 workgroups)
-        self.prefetch_blocks = int(os.environ.get("ITTS_PREFETCH_BLOCKS", "64"))  # side-stream weight prefetch; 0 = off
+        self.prefetch_blocks = int(os.environ.get("ITTS_PREFETCH_BLOCKS", "0"))  # side-stream weight prefetch: measured 1.5x SLOWER in-graph, off
         self._side = None
         self._sink = torch.zeros(4, dtype=torch.int32, device=dev)
         self.weight_bytes = sum(t.numel() * t.element_size() for l in self.layers for t in
