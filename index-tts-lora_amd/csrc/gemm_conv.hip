@@ -55,8 +55,13 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(ConvParams p) {
   const int b = blockIdx.z;
   const int HR = BM + (p.taps - 1) * p.dil;   // staged rows
   const int NC = (p.KT + CK - 1) / CK;        // channel chunks
-  const T* xb = (const T*)p.x + (int64_t)b * p.x_bstride;
-  const char* wp = (const char*)p.wp;
+  // Range-checked buffer descriptors: out-of-range rows (conv zero padding, M tail) and disabled lanes read zeros with
+  // no branch around the load, so the compiler keeps counted waits instead of draining the queue at every join.
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>((const T*)p.x + (int64_t)b * p.x_bstride), 0, (int)((int64_t)p.Tin * p.Cin * (int)sizeof(T)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.wp), 0, (int)((int64_t)p.taps * p.NT * p.KT * 1024), 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFFFu;
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -72,8 +77,9 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(ConvParams p) {
       int i = idx / SEGS, seg = idx - i * SEGS;
       int tin = t0 + p.off0 + i;
       int col = c * (CK * KS) + seg * E;
-      bool ok = (i < HR) && (tin >= 0) && (tin < p.Tin) && (col < p.Cin);
-      stg[q] = ok ? ld16<frag>(xb + (int64_t)tin * p.Cin + col) : zero_frag<frag>();
+      bool ok = (i < HR) && (col < p.Cin);
+      unsigned off = ok ? (unsigned)((tin * p.Cin + col) * (int)sizeof(T)) : OOB;  // tin < 0 wraps to a huge offset
+      stg[q] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
     }
   };
   auto commit_a = [&]() {
@@ -84,19 +90,19 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(ConvParams p) {
       if (i < HR) st16(lds + i * ROWB + seg * 16, stg[q]);
     }
   };
-  // Flat step space: step s = (chunk c, tap j, k-step kk within the chunk); weight block = ((j*NT + nt)*KT + c*CK + kk).
-  // The last chunk may hold fewer than CK k-steps.
+  // Flat step space: step = (chunk c, tap j, k-step kk within the chunk); weight block = ((j*NT + nt)*KT + c*CK + kk).
   auto fetch_b = [&](frag (&bf)[TN], int c, int j, int kk) {
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       int nt = nt0 + tn;
       bool ok = (nt < p.NT) && (c < NC);
-      bf[tn] = ok ? ld16<frag>(wp + ((((int64_t)j * p.NT + nt) * p.KT + c * CK + kk) * 64 + lane) * 16) : zero_frag<frag>();
+      unsigned off = ok ? (unsigned)((((j * p.NT + nt) * p.KT + c * CK + kk) * 64 + lane) * 16) : OOB;
+      bf[tn] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0));
     }
   };
   auto advance = [&](int& c, int& j, int& kk) {
     int nkk = min(CK, p.KT - c * CK);
-    if (++kk == nkk) {
+    if (++kk >= nkk) {
       kk = 0;
       if (++j == p.taps) {
         j = 0;
@@ -104,9 +110,21 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(ConvParams p) {
       }
     }
   };
+  auto load_a = [&](frag (&af)[TM], int j, int kk) {
+    const unsigned char* abase = lds + (wm * TM * 16 + r + j * p.dil) * ROWB + kk * 64 + g * 16;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) af[tm] = ld16<frag>(abase + tm * 16 * ROWB);
+  };
+  auto mma_all = [&](frag (&af)[TM], frag (&bf)[TN]) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = EL::mma(af[tm], bf[tn], acc[tm][tn]);
+  };
 
   frag b0[TN], b1[TN], b2[TN];
-  int fc = 0, fj = 0, fk = 0;  // cursor of the next weight fetch
+  frag a0[TM], a1[TM];
+  int fc = 0, fj = 0, fk = 0;  // cursor of the next weight fetch (runs two steps ahead, across chunk boundaries)
   fetch_b(b0, fc, fj, fk);
   advance(fc, fj, fk);
   fetch_b(b1, fc, fj, fk);
@@ -118,60 +136,87 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(ConvParams p) {
     __syncthreads();
     if (c + 1 < NC) prefetch_a(c + 1);
     const int nkk = min(CK, p.KT - c * CK);
-    for (int j = 0; j < p.taps; ++j) {
-      for (int kk = 0; kk < nkk; ++kk) {
-        fetch_b(b2, fc, fj, fk);  // two steps ahead; crosses chunk boundaries, so no bubble after the barriers
+    const int nit = p.taps * nkk;
+    // A fragments ping-pong between two register sets: the LDS reads of step it+1 are in flight under the MFMAs of step it
+    int j = 0, kk = 0;
+    load_a(a0, 0, 0);
+    for (int it = 0; it < nit; it += 2) {
+      int j1 = j, k1 = kk + 1;
+      if (k1 == nkk) { k1 = 0; ++j1; }
+      fetch_b(b2, fc, fj, fk);
+      advance(fc, fj, fk);
+      if (it + 1 < nit) load_a(a1, j1, k1);
+      mma_all(a0, b0);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) { b0[tn] = b1[tn]; b1[tn] = b2[tn]; }
+      if (it + 1 < nit) {
+        int j2 = j1, k2 = k1 + 1;
+        if (k2 == nkk) { k2 = 0; ++j2; }
+        fetch_b(b2, fc, fj, fk);
         advance(fc, fj, fk);
-        const unsigned char* abase = lds + (wm * TM * 16 + r + j * p.dil) * ROWB + kk * 64 + g * 16;
+        if (it + 2 < nit) load_a(a0, j2, k2);
+        mma_all(a1, b0);
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-          frag af = ld16<frag>(abase + tm * 16 * ROWB);
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = EL::mma(af, b0[tn], acc[tm][tn]);
-        }
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          b0[tn] = b1[tn];
-          b1[tn] = b2[tn];
-        }
+        for (int tn = 0; tn < TN; ++tn) { b0[tn] = b1[tn]; b1[tn] = b2[tn]; }
+        j = j2;
+        kk = k2;
       }
     }
   }
 
-  // ---- epilogue
-  char* yb = (char*)p.y;
-  const char* rb = (const char*)p.resid;
+  // ---- epilogue: range-checked buffer loads/stores (invalid elements get offset OOB: loads return 0, stores are
+  // dropped), all residual / accumulate operands of a column tile requested before the first use.
+  auto epilogue = [&](auto tag) {
+    typedef decltype(tag) YT;  // storage type of y / resid: float or T
+    constexpr int ES = (int)sizeof(YT);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        (YT*)p.y + (int64_t)b * p.y_bstride, 0, (int)(p.y_limit * ES), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<YT*>((const YT*)(p.resid ? p.resid : p.y)) + (int64_t)b * p.y_bstride, 0, (int)(p.y_limit * ES), 0x00020000);
+    auto ld = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off) -> float {
+      if constexpr (ES == 4) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+      else return Elem<YT>::to_f(__builtin_bit_cast(YT, __builtin_amdgcn_raw_buffer_load_b16(rs, off, 0, 0)));
+    };
+    auto stv = [&](unsigned off, float v) {
+      if constexpr (ES == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, off, 0, 0);
+      else __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, Elem<YT>::from_f(v)), ry, off, 0, 0);
+    };
+    const bool has_r = p.resid != nullptr, has_a = p.accumulate != 0;
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    int col = (nt0 + tn) * 16 + r;
-    if (col >= p.N) continue;
-    float bs = p.bias ? p.bias[col] : 0.f;
-    if (p.bias2) bs += p.bias2[(int64_t)b * p.N + col];
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = (nt0 + tn) * 16 + r;
+      const bool cok = col < p.N;
+      float bs = (cok && p.bias) ? p.bias[col] : 0.f;
+      if (cok && p.bias2) bs += p.bias2[(int64_t)b * p.N + col];
+      constexpr int TC = TM < 4 ? TM : 4;  // m-tiles per batch of in-flight epilogue loads
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
+      for (int tm0 = 0; tm0 < TM; tm0 += TC) {
+        unsigned offs[TC][4];
+        float rv[TC][4], av[TC][4];
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        int t = t0 + wm * TM * 16 + tm * 16 + g * 4 + jj;
-        if (t >= p.Tout) continue;
-        int64_t flat = (int64_t)t * p.N + col + p.y_shift;
-        if (flat < 0 || flat >= p.y_limit) continue;
-        int64_t off = (int64_t)b * p.y_bstride + flat;
-        float v = acc[tm][tn][jj] + bs;
-        if (p.act == 1) v = gelu_new(v);
-        if (p.y_f32) {
-          if (rb) v += ((const float*)rb)[off];
-          v *= p.scale;
-          if (p.accumulate) v += ((float*)yb)[off];
-          ((float*)yb)[off] = v;
-        } else {
-          if (rb) v += EL::to_f(((const T*)rb)[off]);
-          v *= p.scale;
-          if (p.accumulate) v += EL::to_f(((T*)yb)[off]);
-          ((T*)yb)[off] = EL::from_f(v);
-        }
+        for (int u = 0; u < TC; ++u)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            int t = t0 + wm * TM * 16 + (tm0 + u) * 16 + g * 4 + jj;
+            int64_t flat = (int64_t)t * p.N + col + p.y_shift;
+            bool ok = cok && (t < p.Tout) && (flat >= 0) && (flat < p.y_limit);
+            offs[u][jj] = ok ? (unsigned)(flat * ES) : OOB;
+            rv[u][jj] = has_r ? ld(rr, offs[u][jj]) : 0.f;
+            av[u][jj] = has_a ? ld(ry, offs[u][jj]) : 0.f;
+          }
+#pragma unroll
+        for (int u = 0; u < TC; ++u)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            float v = acc[tm0 + u][tn][jj] + bs;
+            if (p.act == 1) v = gelu_new(v);
+            v = (v + rv[u][jj]) * p.scale + av[u][jj];
+            stv(offs[u][jj], v);
+          }
       }
     }
-  }
+  };
+  if (p.y_f32) epilogue(float{}); else epilogue(T{});
 }
 
 template <typename T, int WM, int WN, int TM, int TN, int CK, int HALO>
