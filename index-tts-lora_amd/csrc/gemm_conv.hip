@@ -31,6 +31,7 @@ struct ConvParams {
   int accumulate;
   float scale;
   int NT, KT;
+  int MB, NB, GM;  // m-blocks per batch element, n-blocks, m-blocks per L2 group (XCD-aware tile order)
 };
 
 // CK = k-steps of channels staged per chunk (2 for convolutions, whose taps multiply the MFMA work per chunk; 4 for
@@ -50,9 +51,26 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(ConvParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r = lane & 15;
   const int wm = wave / WN, wn = wave % WN;
-  const int t0 = blockIdx.x * BM;
-  const int nt0 = blockIdx.y * (BN / 16) + wn * TN;
-  const int b = blockIdx.z;
+  // XCD-aware tile order (speed only): workgroups are dealt round-robin to the 8 XCDs, so give each XCD a CONTIGUOUS
+  // run of the tile sequence, and order the sequence so that 32 consecutive tiles form a compact GM x (32/GM) patch of
+  // the output -- its activation rows and weight columns then stay in that XCD's 4-MiB L2 instead of being re-fetched
+  // from the Infinity Cache by every tile.
+  int mblk, nblk, b;
+  {
+    const int bid = blockIdx.x, nwg = gridDim.x;
+    const int xcd = bid & 7, q = bid >> 3, base = nwg >> 3, rem = nwg & 7;
+    const int L = xcd * base + min(xcd, rem) + q;
+    const int MBt = p.MB * p.B;
+    const int per_group = p.GM * p.NB;
+    const int mgi = L / per_group, r1 = L - mgi * per_group;
+    const int gm_eff = min(p.GM, MBt - mgi * p.GM);
+    nblk = r1 / gm_eff;
+    const int m = mgi * p.GM + (r1 - nblk * gm_eff);
+    b = m / p.MB;
+    mblk = m - b * p.MB;
+  }
+  const int t0 = mblk * BM;
+  const int nt0 = nblk * (BN / 16) + wn * TN;
   const int HR = BM + (p.taps - 1) * p.dil;   // staged rows
   const int NC = (p.KT + CK - 1) / CK;        // channel chunks
   // Range-checked buffer descriptors: out-of-range rows (conv zero padding, M tail) and disabled lanes read zeros with
@@ -224,18 +242,29 @@ static int launch_conv(const ConvParams& p, hipStream_t s) {
   constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
   int HR = BM + (p.taps - 1) * p.dil;
   size_t ldsb = (size_t)HR * (CK * 64 + 16);
-  dim3 grid((p.Tout + BM - 1) / BM, (p.N + BN - 1) / BN, p.B);
-  if (grid.y > 65535 || grid.z > 65535) {
-    set_error("itts_gemm_conv: grid too large (%u,%u,%u)", grid.x, grid.y, grid.z);
+  ConvParams q = p;
+  q.MB = (p.Tout + BM - 1) / BM;
+  q.NB = (p.N + BN - 1) / BN;
+  // weight bytes one n-block touches; keep the n-extent of a 32-tile patch within ~2 MiB of weights
+  const int64_t wbytes = (int64_t)BN * p.KT * 64 * p.taps;  // BN/16 n-tiles x KT k-steps x 1 KiB x taps
+  int gn = (int)((2 << 20) / (wbytes > 0 ? wbytes : 1));
+  gn = gn < 1 ? 1 : (gn > 8 ? 8 : gn);
+  int gm = 32 / gn;  // 4..32 m-blocks per patch
+  gm = gm >= 32 ? 32 : (gm >= 16 ? 16 : (gm >= 8 ? 8 : 4));
+  q.GM = gm;
+  const int64_t total = (int64_t)q.MB * q.NB * p.B;
+  if (total > 0x7fffffff) {
+    set_error("itts_gemm_conv: too many tiles (%lld)", (long long)total);
     return ITTS_ERR_INVALID;
   }
+  dim3 grid((unsigned)total);
   static bool attr = false;
   if (!attr && ldsb > 64 * 1024) {
-    hipFuncSetAttribute((const void*)gemm_conv_kernel<T, WM, WN, TM, TN, CK, HALO>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)gemm_conv_kernel<T, WM, WN, TM, TN, CK, HALO>, hipFuncAttributeMaxDynamicSharedMemorySize,
                         160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_conv_kernel<T, WM, WN, TM, TN, CK, HALO>), grid, dim3(256), ldsb, s, p);
+  hipLaunchKernelGGL((gemm_conv_kernel<T, WM, WN, TM, TN, CK, HALO>), grid, dim3(256), ldsb, s, q);
   return check_launch("itts_gemm_conv");
 }
 
@@ -245,8 +274,8 @@ static int dispatch_conv(const ConvParams& p, hipStream_t s) {
   if (p.N % 128 == 0) return plain ? launch_conv<T, 1, 4, 16, 2, 4, 0>(p, s) : launch_conv<T, 1, 4, 16, 2, 2, CV_MAX_HALO>(p, s);
   if (p.N % 64 == 0) return plain ? launch_conv<T, 2, 2, 8, 2, 4, 0>(p, s) : launch_conv<T, 2, 2, 8, 2, 2, CV_MAX_HALO>(p, s);
   if (p.N % 96 == 0) return launch_conv<T, 2, 2, 8, 3, 2, CV_MAX_HALO>(p, s);
-  if (p.N % 48 == 0) return launch_conv<T, 4, 1, 8, 3, 2, CV_MAX_HALO>(p, s);
-  return launch_conv<T, 4, 1, 8, 2, 2, CV_MAX_HALO>(p, s);
+  if (p.N % 48 == 0) return launch_conv<T, 4, 1, 4, 3, 2, CV_MAX_HALO>(p, s);
+  return launch_conv<T, 4, 1, 4, 2, 2, CV_MAX_HALO>(p, s);
 }
 
 }  // namespace itts
