@@ -35,8 +35,13 @@ def conformer_encode(W: dict, mel_btf: torch.Tensor, lengths: torch.Tensor, head
     dev = mel_btf.device
     mask = (torch.arange(T, device=dev)[None, :] < lengths.to(dev)[:, None])[:, None, :]
     # Conv2dSubsampling2
-    x = F.relu(F.conv2d(mel_btf[:, None], W[prefix + "embed.conv.0.weight"], W[prefix + "embed.conv.0.bias"], stride=2))
-    b, c, t, f = x.shape
+    # Conv2d(1, C, 3, stride 2) as unfold + matmul (a [T'*F', 9] x [9, C] product)
+    w0 = W[prefix + "embed.conv.0.weight"]
+    patches = F.unfold(mel_btf[:, None], kernel_size=3, stride=2)                  # [B, 9, T'*F']
+    t, f = (T - 3) // 2 + 1, (mel_btf.shape[2] - 3) // 2 + 1
+    x = F.relu(torch.matmul(w0.view(w0.shape[0], 9), patches) + W[prefix + "embed.conv.0.bias"][None, :, None])
+    b, c = x.shape[0], x.shape[1]
+    x = x.view(b, c, t, f)
     x = _lin(x.transpose(1, 2).reshape(b, t, c * f), W, prefix + "embed.out.0")
     mask = mask[:, :, 2::2]
     d = x.shape[-1]
@@ -65,11 +70,15 @@ def conformer_encode(W: dict, mel_btf: torch.Tensor, lengths: torch.Tensor, head
         # --- convolution module
         y = _ln(x, W, p + "norm_conv").transpose(1, 2)
         y = y.masked_fill(~mask, 0.0)
-        y = F.glu(F.conv1d(y, W[p + "conv_module.pointwise_conv1.weight"], W[p + "conv_module.pointwise_conv1.bias"]), dim=1)
-        wd = W[p + "conv_module.depthwise_conv.weight"]
-        y = F.conv1d(y, wd, W[p + "conv_module.depthwise_conv.bias"], padding=(wd.shape[-1] - 1) // 2, groups=wd.shape[0])
+        y = F.glu(torch.matmul(W[p + "conv_module.pointwise_conv1.weight"][:, :, 0], y)
+                  + W[p + "conv_module.pointwise_conv1.bias"][None, :, None], dim=1)
+        wd = W[p + "conv_module.depthwise_conv.weight"]                                # [C, 1, k] depthwise
+        kd = wd.shape[-1]
+        yp = F.pad(y, ((kd - 1) // 2, (kd - 1) // 2))
+        y = (yp.unfold(2, kd, 1) * wd[None, :, 0, None, :]).sum(-1) + W[p + "conv_module.depthwise_conv.bias"][None, :, None]
         y = F.silu(_ln(y.transpose(1, 2), W, p + "conv_module.norm")).transpose(1, 2)
-        y = F.conv1d(y, W[p + "conv_module.pointwise_conv2.weight"], W[p + "conv_module.pointwise_conv2.bias"])
+        y = torch.matmul(W[p + "conv_module.pointwise_conv2.weight"][:, :, 0], y) \
+            + W[p + "conv_module.pointwise_conv2.bias"][None, :, None]
         y = y.masked_fill(~mask, 0.0)
         x = x + y.transpose(1, 2)
         # --- feed forward

@@ -128,25 +128,32 @@ class UnifiedVoice:
         """model.py:606-667 -> (fake_inputs [B,P+1], prefix_emb [B,P,D] fp32, attention_mask [B,P+1])."""
         eng = self.engine
         dev = self.device
-        text_inputs = text_inputs.to(dev).long()
-        B, L = text_inputs.shape
+        t = text_inputs.to(dev).long()
+        B, L = t.shape
         D = conditional_latents.shape[-1]
-        P = conditional_latents.shape[1] + L + 2
-        emb = torch.zeros(B, P, D, dtype=torch.float32, device=dev)
-        mask = torch.ones(B, P + 1, dtype=torch.long, device=dev)
-        single = conditional_latents.shape[0] == 1
-        for b in range(B):
-            t = text_inputs[b]
-            t = t[(t != self.stop_text_token) & (t != self.start_text_token)]
-            t = F.pad(F.pad(t, (1, 0), value=self.start_text_token), (0, 1), value=self.stop_text_token)
-            te = eng.text_emb[t] + eng.text_pos[: t.numel()]
-            row = torch.cat([conditional_latents[0 if single else b].to(dev, torch.float32), te], dim=0)
-            pad = P - row.shape[0]
-            emb[b, pad:] = row
-            mask[b, :pad] = 0
+        C = conditional_latents.shape[1]
+        P = C + L + 2
+        # strip start/stop ids, then start | tokens | stop, vectorised over the batch (model.py:630-636)
+        valid = (t != self.stop_text_token) & (t != self.start_text_token)
+        n = valid.sum(dim=1)                                               # tokens kept per row
+        rank = torch.cumsum(valid, dim=1) - 1
+        tok = torch.full((B, L + 2), self.stop_text_token, dtype=torch.long, device=dev)
+        tok[:, 0] = self.start_text_token
+        rows = torch.arange(B, device=dev)[:, None].expand(B, L)
+        tok[rows[valid], (rank + 1)[valid]] = t[valid]
+        te = eng.text_emb[tok] + eng.text_pos[: L + 2][None]               # positions > n+1 are dropped by the shift below
+        c = conditional_latents.to(dev, torch.float32)
+        if c.shape[0] == 1 and B > 1:
+            c = c.expand(B, -1, -1)
+        row = torch.cat([c, te], dim=1)                                    # [B, P, D], valid length C + n + 2
+        pad = (L - n)                                                      # left padding per row (model.py:643-649)
+        idx = torch.arange(P, device=dev)[None, :] - pad[:, None]
+        keep = idx >= 0
+        emb = row.gather(1, idx.clamp(min=0)[:, :, None].expand(-1, -1, D)) * keep[:, :, None]
+        mask = torch.cat([keep.long(), torch.ones(B, 1, dtype=torch.long, device=dev)], dim=1)
         fake = torch.ones(B, P + 1, dtype=torch.long, device=dev)
         fake[:, -1] = self.start_mel_token
-        return fake, emb, mask
+        return fake, emb.contiguous(), mask
 
     # ---- generation -------------------------------------------------------------------------------------------
     def inference_speech(self, speech_conditioning_mel, text_inputs, cond_mel_lengths=None, input_tokens=None,
