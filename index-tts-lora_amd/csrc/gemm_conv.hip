@@ -36,16 +36,25 @@ struct ConvParams {
 
 // CK = k-steps of channels staged per chunk (2 for convolutions, whose taps multiply the MFMA work per chunk; 4 for
 // plain GEMMs).  HALO = compile-time bound on (taps-1)*dil (0 for plain GEMMs) that sizes the staging registers.
+// Waves per SIMD the register budget is sized for: 8-wave workgroups put 2 waves on each SIMD (one wave's MFMAs run under
+// the other's LDS reads / address arithmetic); 4-wave workgroups with a small accumulator tile ask for 2 workgroups per CU.
+template <int WM, int WN, int TM, int TN>
+struct ConvOcc {
+  static constexpr int NW = WM * WN;
+  static constexpr int WPS = (NW == 8) ? 2 : ((TM * TN <= 16) ? 2 : 1);
+};
+
 template <typename T, int WM, int WN, int TM, int TN, int CK, int HALO>
-__global__ __launch_bounds__(256) void gemm_conv_kernel(ConvParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void gemm_conv_kernel(ConvParams p) {
   typedef Elem<T> EL;
   typedef typename EL::frag frag;
   constexpr int E = EL::E, KS = EL::KS;
   constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
   constexpr int SEGS = CK * 4;                 // 16-byte segments per staged row
   constexpr int ROWB = CK * 64 + 16;           // LDS bytes per staged row (payload + 16 B pad: conflict-free b128 reads)
-  constexpr int MAXST = ((BM + HALO) * SEGS + 255) / 256;
-  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int NTH = WM * WN * 64;            // threads per workgroup (4 or 8 waves)
+  constexpr int MAXST = ((BM + HALO) * SEGS + NTH - 1) / NTH;
+  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(ConvParams p) {
   auto prefetch_a = [&](int c) {
 #pragma unroll
     for (int q = 0; q < MAXST; ++q) {
-      int idx = tid + q * 256;
+      int idx = tid + q * NTH;
       int i = idx / SEGS, seg = idx - i * SEGS;
       int tin = t0 + p.off0 + i;
       int col = c * (CK * KS) + seg * E;
@@ -103,7 +112,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(ConvParams p) {
   auto commit_a = [&]() {
 #pragma unroll
     for (int q = 0; q < MAXST; ++q) {
-      int idx = tid + q * 256;
+      int idx = tid + q * NTH;
       int i = idx / SEGS, seg = idx - i * SEGS;
       if (i < HR) st16(lds + i * ROWB + seg * 16, stg[q]);
     }
@@ -264,16 +273,16 @@ static int launch_conv(const ConvParams& p, hipStream_t s) {
                         160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_conv_kernel<T, WM, WN, TM, TN, CK, HALO>), grid, dim3(256), ldsb, s, q);
+  hipLaunchKernelGGL((gemm_conv_kernel<T, WM, WN, TM, TN, CK, HALO>), grid, dim3(WM * WN * 64), ldsb, s, q);
   return check_launch("itts_gemm_conv");
 }
 
 template <typename T>
 static int dispatch_conv(const ConvParams& p, hipStream_t s) {
   const bool plain = (p.taps == 1);  // GEMM: no halo, 4 k-steps per chunk
-  if (p.N % 128 == 0) return plain ? launch_conv<T, 1, 4, 16, 2, 4, 0>(p, s) : launch_conv<T, 1, 4, 16, 2, 2, CV_MAX_HALO>(p, s);
-  if (p.N % 64 == 0) return plain ? launch_conv<T, 2, 2, 8, 2, 4, 0>(p, s) : launch_conv<T, 2, 2, 8, 2, 2, CV_MAX_HALO>(p, s);
-  if (p.N % 96 == 0) return launch_conv<T, 2, 2, 8, 3, 2, CV_MAX_HALO>(p, s);
+  if (p.N % 128 == 0) return plain ? launch_conv<T, 2, 4, 8, 2, 4, 0>(p, s) : launch_conv<T, 2, 4, 8, 2, 2, CV_MAX_HALO>(p, s);
+  if (p.N % 64 == 0) return plain ? launch_conv<T, 4, 2, 4, 2, 4, 0>(p, s) : launch_conv<T, 4, 2, 4, 2, 2, CV_MAX_HALO>(p, s);
+  if (p.N % 96 == 0) return launch_conv<T, 4, 2, 4, 3, 2, CV_MAX_HALO>(p, s);
   if (p.N % 48 == 0) return launch_conv<T, 4, 1, 4, 3, 2, CV_MAX_HALO>(p, s);
   return launch_conv<T, 4, 1, 4, 2, 2, CV_MAX_HALO>(p, s);
 }
