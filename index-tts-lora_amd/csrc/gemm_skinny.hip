@@ -28,14 +28,17 @@ struct SkinnyParams {
   int slab_rows;  // total rows of a slab (the caller's M), the stride between split-K slabs
 };
 
-template <typename T, int MT, int SPW>
+// NTB = column tiles per workgroup.  More than one workgroup per CU does not overlap for this kernel (measured: 257
+// column tiles cost a full second round), so shapes with more than 256 tiles give each workgroup several tiles instead.
+template <typename T, int MT, int SPW, int NTB>
 __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
   typedef Elem<T> EL;
   typedef typename EL::frag frag;
   constexpr int E = EL::E, KS = EL::KS;
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][MT][64][4]
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][NTB][MT][64][4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
-  const int nt = blockIdx.x, ks = blockIdx.y;
+  const int nt0 = blockIdx.x * NTB, ks = blockIdx.y;
+  const int NTtot = (p.N + 15) / 16;
   const int g = lane >> 4, r = lane & 15;
   const int KT = p.K / KS;
   const int SB = (KT + p.ksplit - 1) / p.ksplit;  // k-steps per split slice
@@ -44,30 +47,34 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
   const int s_begin = b_begin + wave * spw;
   const int s_end = min(b_end, s_begin + spw);
 
-  const char* bp = (const char*)p.wp + ((int64_t)nt * KT * 64 + lane) * 16;
+  const char* bp = (const char*)p.wp + ((int64_t)nt0 * KT * 64 + lane) * 16;  // tile t of this workgroup: + t*KT*1024
   const T* X = (const T*)p.x;
 
   // epilogue operands are requested now, so that their latency overlaps the weight stream
   float bias_pre = 0.f;
   int pos_pre = 0;
   if (tid < MT * 256) {
-    int col = nt * 16 + (tid & 15);
+    int col = nt0 * 16 + (tid & 15);
     if (p.bias != nullptr && ks == 0 && col < p.N) bias_pre = p.bias[col];
     if (p.epi == ITTS_EPI_QKV_CACHE) pos_pre = p.pos[0];
   }
 
-  f32x4 acc[MT];
+  f32x4 acc[NTB][MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NTB; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int base = s_begin; base < s_end; base += SPW) {
-    frag bf[SPW];
+    frag bf[NTB][SPW];
     frag af[SPW][MT];
 #pragma unroll
-    for (int i = 0; i < SPW; ++i) {
-      int s = base + i;
-      bf[i] = (s < s_end) ? ld16<frag>(bp + (int64_t)s * 1024) : zero_frag<frag>();
-    }
+    for (int t = 0; t < NTB; ++t)
+#pragma unroll
+      for (int i = 0; i < SPW; ++i) {
+        int s = base + i;
+        bf[t][i] = (s < s_end && nt0 + t < NTtot) ? ld16<frag>(bp + ((int64_t)t * KT + s) * 1024) : zero_frag<frag>();
+      }
 #pragma unroll
     for (int i = 0; i < SPW; ++i) {
       int s = base + i;
@@ -80,22 +87,27 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
 #pragma unroll
     for (int i = 0; i < SPW; ++i) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt] = EL::mma(af[i][mt], bf[i], acc[mt]);
+      for (int t = 0; t < NTB; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[t][mt] = EL::mma(af[i][mt], bf[t][i], acc[t][mt]);
     }
   }
 
   // ---- cross-wave reduction, fixed order
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) st16(red + ((wave * MT + mt) * 64 + lane) * 4, acc[mt]);
+  for (int t = 0; t < NTB; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) st16(red + (((wave * NTB + t) * MT + mt) * 64 + lane) * 4, acc[t][mt]);
   __syncthreads();
-  for (int e = tid; e < MT * 256; e += blockDim.x) {
-    int mt = e >> 8, rr = (e >> 4) & 15, c = e & 15;
-    int row = mt * 16 + rr, col = nt * 16 + c;
+  for (int e = tid; e < NTB * MT * 256; e += blockDim.x) {
+    int t = e / (MT * 256), e1 = e - t * (MT * 256);
+    int mt = e1 >> 8, rr = (e1 >> 4) & 15, c = e1 & 15;
+    int row = mt * 16 + rr, col = (nt0 + t) * 16 + c;
     if (row >= p.M || col >= p.N) continue;
     float bs = (e == tid) ? bias_pre : ((p.bias != nullptr && ks == 0) ? p.bias[col] : 0.f);
     int src = ((rr >> 2) << 4) | c, j = rr & 3;
     float v = 0.f;
-    for (int w = 0; w < NW; ++w) v += red[((w * MT + mt) * 64 + src) * 4 + j];
+    for (int w = 0; w < NW; ++w) v += red[(((w * NTB + t) * MT + mt) * 64 + src) * 4 + j];
     v += bs;
     switch (p.epi) {
       case ITTS_EPI_STORE:
@@ -141,12 +153,19 @@ static int launch_skinny(const SkinnyParams& p, hipStream_t s) {
   if (NW < 1) NW = 1;
   const int spw = (SB + NW - 1) / NW;
   const int NT = (p.N + 15) / 16;
-  size_t lds = (size_t)NW * MT * 256 * 4;
-  dim3 grid(NT, p.ksplit), block(NW * 64);
-  if (spw <= 5)
-    hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 5>), grid, block, lds, s, p);
-  else
-    hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 10>), grid, block, lds, s, p);
+  // keep the grid within one round of the 256 CUs
+  int ntb = (NT * p.ksplit + 255) / 256;
+  if (ntb > 3) ntb = 3;
+  if (spw > 5 && ntb > 2) ntb = 2;  // register budget of the 10-step variant
+  size_t lds = (size_t)NW * ntb * MT * 256 * 4;
+  dim3 grid((NT + ntb - 1) / ntb, p.ksplit), block(NW * 64);
+#define ITTS_SK(SPW_, NTB_) hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, SPW_, NTB_>), grid, block, lds, s, p)
+  if (spw <= 5) {
+    if (ntb == 1) ITTS_SK(5, 1); else if (ntb == 2) ITTS_SK(5, 2); else ITTS_SK(5, 3);
+  } else {
+    if (ntb == 1) ITTS_SK(10, 1); else ITTS_SK(10, 2);
+  }
+#undef ITTS_SK
   return check_launch("itts_gemm_skinny");
 }
 

@@ -59,7 +59,7 @@ class GPTEngine:
         self.extra_ids = torch.tensor([1, start_mel_token], dtype=torch.int32, device=dev)  # fake prefix ids (model.py:658-667)
         self._cap_b = self._cap_s = 0
         self._graphs = {}
-        self.KSPLIT = 4  # split-K of the two N=1280 GEMMs of a block (80 column tiles -> 320 workgroups)
+        self.KSPLIT = 3  # split-K of the two N=1280 GEMMs of a block: 80 column tiles x 3 = 240 workgroups (one round of 256 CUs)
         self.prefetch_blocks = int(os.environ.get("ITTS_PREFETCH_BLOCKS", "0"))  # side-stream weight prefetch: measured 1.5x SLOWER in-graph, off
         self._side = None
         self._sink = torch.zeros(4, dtype=torch.int32, device=dev)

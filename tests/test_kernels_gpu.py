@@ -114,10 +114,10 @@ def test_gemm_skinny_plain(nat, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M", [1, 13, 32])
-def test_ln_reduce_and_splitk_slabs(nat, dtype, M):
+@pytest.mark.parametrize("M,KSP", [(1, 4), (13, 3), (32, 3), (32, 4)])
+def test_ln_reduce_and_splitk_slabs(nat, dtype, M, KSP):
     """out-proj with split-K slabs, then residual-reduce + LayerNorm (+ second LayerNorm), as in one decode block."""
-    K, N, KSP = 5120, 1280, 4
+    K, N = 5120, 1280
     x = rnd(M, K, seed=20).to(dtype)
     w = (rnd(K, N, seed=25) * 0.03).to(dtype)
     bias = rnd(N, seed=26)
@@ -127,7 +127,8 @@ def test_ln_reduce_and_splitk_slabs(nat, dtype, M):
     ref_mm = x.float() @ w.float()
     assert (slab.sum(0) - ref_mm).abs().max().item() < (3e-4 if dtype == torch.float32 else 5e-3) * max(1.0, ref_mm.abs().max().item())
     # each slab is exactly the partial product over its K slice
-    ks = K // KSP
+    kstep = 16 if dtype == torch.float32 else 32
+    ks = -(-(K // kstep) // KSP) * kstep          # k-steps are split evenly, the last slice takes the remainder
     for i in range(KSP):
         part = x.float()[:, i * ks:(i + 1) * ks] @ w.float()[i * ks:(i + 1) * ks]
         assert (slab[i] - part).abs().max().item() < (3e-4 if dtype == torch.float32 else 5e-3) * max(1.0, part.abs().max().item())
@@ -137,7 +138,9 @@ def test_ln_reduce_and_splitk_slabs(nat, dtype, M):
     h = h0.clone()
     out = torch.empty(M, N, dtype=dtype, device=DEV)
     nat.ln_reduce(h, lw, lb, out, slab=slab, nslab=KSP, bias=bias)
-    h_ref = h0 + bias + slab[0] + slab[1] + slab[2] + slab[3]
+    h_ref = h0 + bias
+    for i in range(KSP):
+        h_ref = h_ref + slab[i]
     assert torch.equal(h, h_ref)                                  # fixed summation order -> bit-exact
     ref = F.layer_norm(h_ref, (N,), lw, lb, 1e-5)
     tol = 3e-5 if dtype == torch.float32 else 3e-2

@@ -143,3 +143,17 @@ for name, fn, bytes_ in [
     us = timed_graph(fn, R * L)
     extra = f"  {bytes_ * MB:6.1f} MB -> {bytes_ / us / 1e6:6.2f} TB/s" if bytes_ else ""
     log(f"{name:32s} {us:7.2f} us/launch{extra}")
+
+# ---- balance experiment: column tiles vs the 256 CUs
+for N in (3840, 4096, 4112, 5120, 6144, 8192):
+    ws = [rand_w(D, N) for _ in range(L)]
+    yb = torch.zeros(B, N, device=dev, dtype=T)
+    bb = torch.zeros(N, device=dev)
+
+    def fn():
+        for _ in range(R):
+            for i in range(L):
+                nat.gemm_skinny(T, B, N, D, ws[i], bb, x=xn, epi=nat.EPI_GELU_STORE, y=yb)
+    us = timed_graph(fn, R * L)
+    log(f"skinny K=1280 N={N:5d} ({N // 16:3d} tiles) {us:7.2f} us  {D * N * 2 / us / 1e6:5.2f} TB/s")
+    del ws
