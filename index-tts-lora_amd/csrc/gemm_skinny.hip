@@ -53,8 +53,8 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
   // epilogue operands are requested now, so that their latency overlaps the weight stream
   float bias_pre = 0.f;
   int pos_pre = 0;
-  if (tid < MT * 256) {
-    int col = nt0 * 16 + (tid & 15);
+  if (tid < NTB * MT * 256) {  // the element this thread handles first in the epilogue (e == tid)
+    int col = (nt0 + tid / (MT * 256)) * 16 + (tid & 15);
     if (p.bias != nullptr && ks == 0 && col < p.N) bias_pre = p.bias[col];
     if (p.epi == ITTS_EPI_QKV_CACHE) pos_pre = p.pos[0];
   }
