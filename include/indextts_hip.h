@@ -95,7 +95,7 @@ typedef struct itts_skinny_args {
   int M, N, K;
   const void* wp;    /* packed W */
   const float* bias; /* [N] or NULL */
-  const void* x;     /* T [M][K] */
+  const void* x;     /* T [M][K]  (fp32 [M][K] when x_ln_f32 != 0) */
   int epi;
   void* y;
   float* yf;
@@ -104,6 +104,8 @@ typedef struct itts_skinny_args {
   const int32_t* pos; /* device scalar: cache row to write */
   int heads, smax;
   int ksplit; /* split-K over workgroups (grid.y); > 1 only with ITTS_EPI_SLAB_F32 */
+  int x_ln_f32; /* != 0: x is the fp32 residual stream and is normalised per row on the fly, (x - mean) * rstd with eps
+                   1e-5 (LayerNorm without its affine part, which the caller folds into W and bias); needs ksplit 1 */
 } itts_skinny_args;
 int itts_gemm_skinny(const itts_skinny_args* a, void* stream);
 

@@ -25,12 +25,18 @@ struct SkinnyParams {
   const int32_t* pos;
   int heads, smax;
   int ksplit;
-  int slab_rows;  // total rows of a slab (the caller's M), the stride between split-K slabs
+  int slab_rows;
+  int lnf;  // A operand is the fp32 residual stream, normalised per row (LayerNorm without affine) on the fly  // total rows of a slab (the caller's M), the stride between split-K slabs
 };
 
 // NTB = column tiles per workgroup.  More than one workgroup per CU does not overlap for this kernel (measured: 257
 // column tiles cost a full second round), so shapes with more than 256 tiles give each workgroup several tiles instead.
-template <typename T, int MT, int SPW, int NTB>
+// LNF: the A operand is fp32 [M][K] and is LayerNorm-normalised on the fly ((x - mean) * rstd, eps 1e-5; the affine part
+// is folded into the packed weights / bias by the caller).  Each wave computes exact two-pass statistics of its own K
+// slice, the slices are merged across the waves with Chan's parallel-variance formula through LDS (one barrier), and the
+// normalised values are rounded to T only then -- same numerics as LayerNorm in fp32 followed by a T-typed matmul.
+// Requires ksplit == 1 and the wave's whole K slice in one register chunk.
+template <typename T, int MT, int SPW, int NTB, bool LNF>
 __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
   typedef Elem<T> EL;
   typedef typename EL::frag frag;
@@ -65,6 +71,95 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  if constexpr (LNF) {
+    const float* H = (const float*)p.x;
+    float* stat = red + NW * NTB * MT * 256;  // [NW][MT*16][2] (mean, M2) of each wave's K slice
+    frag bf[NTB][SPW];
+    float xa[SPW][MT][E];
+#pragma unroll
+    for (int t = 0; t < NTB; ++t)
+#pragma unroll
+      for (int i = 0; i < SPW; ++i) {
+        int s = s_begin + i;
+        bf[t][i] = (s < s_end && nt0 + t < NTtot) ? ld16<frag>(bp + ((int64_t)t * KT + s) * 1024) : zero_frag<frag>();
+      }
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) {
+      int s = s_begin + i;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        int row = mt * 16 + r;
+        bool ok = (s < s_end) && (row < p.M);
+        const float* src = H + (int64_t)row * p.K + s * KS + g * E;
+#pragma unroll
+        for (int e4 = 0; e4 < E / 4; ++e4) {
+          f32x4 v = ok ? ld16<f32x4>(src + e4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xa[i][mt][e4 * 4 + e] = v[e];
+        }
+      }
+    }
+    const float n_w = (float)((s_end - s_begin) * KS);  // elements of a row in this wave's slice
+    float mean_w[MT], m2_w[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      float s1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < SPW; ++i)
+#pragma unroll
+        for (int e = 0; e < E; ++e) s1 += xa[i][mt][e];  // slots past s_end hold zeros
+      s1 += __shfl_xor(s1, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      mean_w[mt] = n_w > 0.f ? s1 / n_w : 0.f;
+      float s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < SPW; ++i)
+        if (s_begin + i < s_end) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            float d = xa[i][mt][e] - mean_w[mt];
+            s2 = fmaf(d, d, s2);
+          }
+        }
+      s2 += __shfl_xor(s2, 16, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      m2_w[mt] = s2;
+      if (g == 0) {
+        stat[(wave * (MT * 16) + mt * 16 + r) * 2 + 0] = mean_w[mt];
+        stat[(wave * (MT * 16) + mt * 16 + r) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    // merge the NW slices (all slices but possibly the last have spw*KS elements)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      float tot = 0.f, msum = 0.f;
+      for (int w = 0; w < NW; ++w) {
+        int sb = b_begin + w * spw, se = min(b_end, sb + spw);
+        float nw = (float)(max(se - sb, 0) * KS);
+        msum += nw * stat[(w * (MT * 16) + mt * 16 + r) * 2];
+        tot += nw;
+      }
+      float mean = msum / tot, m2 = 0.f;
+      for (int w = 0; w < NW; ++w) {
+        int sb = b_begin + w * spw, se = min(b_end, sb + spw);
+        float nw = (float)(max(se - sb, 0) * KS);
+        float d = stat[(w * (MT * 16) + mt * 16 + r) * 2] - mean;
+        m2 += stat[(w * (MT * 16) + mt * 16 + r) * 2 + 1] + nw * d * d;
+      }
+      float rstd = rsqrtf(m2 / tot + 1e-5f);
+#pragma unroll
+      for (int i = 0; i < SPW; ++i) {
+        frag af;
+#pragma unroll
+        for (int e = 0; e < E; ++e) af[e] = EL::from_f((xa[i][mt][e] - mean) * rstd);
+        if (s_begin + i < s_end) {
+#pragma unroll
+          for (int t = 0; t < NTB; ++t) acc[t][mt] = EL::mma(af, bf[t][i], acc[t][mt]);
+        }
+      }
+    }
+  } else {
   for (int base = s_begin; base < s_end; base += SPW) {
     frag bf[NTB][SPW];
     frag af[SPW][MT];
@@ -91,6 +186,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[t][mt] = EL::mma(af[i][mt], bf[t][i], acc[t][mt]);
     }
+  }
   }
 
   // ---- cross-wave reduction, fixed order
@@ -157,13 +253,19 @@ static int launch_skinny(const SkinnyParams& p, hipStream_t s) {
   int ntb = (NT * p.ksplit + 255) / 256;
   if (ntb > 3) ntb = 3;
   if (spw > 5 && ntb > 2) ntb = 2;  // register budget of the 10-step variant
-  size_t lds = (size_t)NW * ntb * MT * 256 * 4;
+  size_t lds = (size_t)NW * ntb * MT * 256 * 4 + (p.lnf ? (size_t)NW * MT * 16 * 2 * 4 : 0);
   dim3 grid((NT + ntb - 1) / ntb, p.ksplit), block(NW * 64);
-#define ITTS_SK(SPW_, NTB_) hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, SPW_, NTB_>), grid, block, lds, s, p)
-  if (spw <= 5) {
-    if (ntb == 1) ITTS_SK(5, 1); else if (ntb == 2) ITTS_SK(5, 2); else ITTS_SK(5, 3);
+#define ITTS_SK(SPW_, NTB_, LNF_) hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, SPW_, NTB_, LNF_>), grid, block, lds, s, p)
+  if (p.lnf) {
+    if (spw > 5 || p.ksplit != 1) {
+      set_error("itts_gemm_skinny: the LayerNorm-fused A operand needs K <= %d and ksplit == 1", 8 * 5 * KS);
+      return ITTS_ERR_INVALID;
+    }
+    if (ntb == 1) ITTS_SK(5, 1, true); else if (ntb == 2) ITTS_SK(5, 2, true); else ITTS_SK(5, 3, true);
+  } else if (spw <= 5) {
+    if (ntb == 1) ITTS_SK(5, 1, false); else if (ntb == 2) ITTS_SK(5, 2, false); else ITTS_SK(5, 3, false);
   } else {
-    if (ntb == 1) ITTS_SK(10, 1); else ITTS_SK(10, 2);
+    if (ntb == 1) ITTS_SK(10, 1, false); else ITTS_SK(10, 2, false);
   }
 #undef ITTS_SK
   return check_launch("itts_gemm_skinny");
@@ -199,7 +301,8 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
     p.K = a->K;
     p.wp = a->wp;
     p.bias = a->bias;
-    p.x = (const char*)a->x + (size_t)r0 * a->K * esz;
+    p.x = (const char*)a->x + (size_t)r0 * a->K * (a->x_ln_f32 ? 4 : esz);
+    p.lnf = a->x_ln_f32 ? 1 : 0;
     p.epi = a->epi;
     const size_t ycols = a->epi == ITTS_EPI_QKV_CACHE ? (size_t)a->N / 3 : (size_t)a->N;
     p.y = a->y ? (char*)a->y + (size_t)r0 * ycols * esz : nullptr;

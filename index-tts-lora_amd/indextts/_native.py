@@ -25,7 +25,7 @@ class SkinnyArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("wp", C.c_void_p),
                 ("bias", C.c_void_p), ("x", C.c_void_p), ("epi", C.c_int), ("y", C.c_void_p), ("yf", C.c_void_p),
                 ("kcache", C.c_void_p), ("vcache", C.c_void_p), ("pos", C.c_void_p), ("heads", C.c_int),
-                ("smax", C.c_int), ("ksplit", C.c_int)]
+                ("smax", C.c_int), ("ksplit", C.c_int), ("x_ln_f32", C.c_int)]
 
 
 class ConvArgs(C.Structure):
@@ -148,12 +148,13 @@ def aa_snake(x, alpha_log, beta_log, up_f, down_f, layout=0, out=None):
 
 
 def gemm_skinny(dtype, M, N, K, wp, bias=None, x=None, epi=EPI_STORE, y=None, yf=None, kcache=None, vcache=None, pos=None,
-                heads=0, smax=0, ksplit=1):
+                heads=0, smax=0, ksplit=1, x_ln_f32=False):
     a = SkinnyArgs()
     a.dtype, a.M, a.N, a.K = dt(dtype), M, N, K
     a.wp, a.bias, a.x = _p(wp), _p(bias), _p(x)
     a.epi, a.y, a.yf = epi, _p(y), _p(yf)
     a.kcache, a.vcache, a.pos, a.heads, a.smax, a.ksplit = _p(kcache), _p(vcache), _p(pos), heads, smax, ksplit
+    a.x_ln_f32 = int(bool(x_ln_f32))
     _check(lib().itts_gemm_skinny(C.byref(a), _stream()), "itts_gemm_skinny")
 
 

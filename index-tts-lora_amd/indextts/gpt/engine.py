@@ -36,17 +36,36 @@ class GPTEngine:
         def packed(w_kn):
             return nat.pack_weight(w_kn.detach().to(dev, dtype).contiguous())
 
+        # Decode-step structure (bf16/f16 only; the fp32 parity mode keeps separate LayerNorm launches):
+        #   mode 2: LayerNorm-2 is computed inside the FC GEMM (its affine part folded into the weights), the attention
+        #           out-projection updates the residual stream directly (no split-K)             -> 6 launches per block
+        #   mode 3: additionally LayerNorm-1 inside the QKV GEMM and an unsplit FC2               -> 5 launches per block
+        #   mode 1: every LayerNorm is its own [residual-reduce + LN] launch                      -> 7 launches per block
+        self.decode_mode = int(os.environ.get("ITTS_DECODE_MODE", "2")) if dtype != torch.float32 else 1
+
+        def fold(ln_w, ln_b, w_kn, b_n):
+            """LN(x; g, b) @ W + c  ==  norm(x) @ (diag(g) W) + (b @ W + c)."""
+            wf = W[w_kn].detach().to(dev, torch.float32)
+            g, bb = W[ln_w].detach().to(dev, torch.float32), W[ln_b].detach().to(dev, torch.float32)
+            return packed(g[:, None] * wf), (bb @ wf + W[b_n].detach().to(dev, torch.float32)).contiguous()
+
         self.layers = []
         for i in range(layers):
             p = f"gpt.h.{i}."
-            self.layers.append(dict(
+            d = dict(
                 ln1=(f32(p + "ln_1.weight"), f32(p + "ln_1.bias")),
                 ln2=(f32(p + "ln_2.weight"), f32(p + "ln_2.bias")),
                 w_qkv=packed(W[p + "attn.c_attn.weight"]), b_qkv=f32(p + "attn.c_attn.bias"),
                 w_o=packed(W[p + "attn.c_proj.weight"]), b_o=f32(p + "attn.c_proj.bias"),
                 w_fc=packed(W[p + "mlp.c_fc.weight"]), b_fc=f32(p + "mlp.c_fc.bias"),
                 w_pr=packed(W[p + "mlp.c_proj.weight"]), b_pr=f32(p + "mlp.c_proj.bias"),
-            ))
+            )
+            if self.decode_mode >= 2:
+                d["w_fc_ln"], d["b_fc_ln"] = fold(p + "ln_2.weight", p + "ln_2.bias", p + "mlp.c_fc.weight", p + "mlp.c_fc.bias")
+            if self.decode_mode >= 3:
+                d["w_qkv_ln"], d["b_qkv_ln"] = fold(p + "ln_1.weight", p + "ln_1.bias", p + "attn.c_attn.weight",
+                                                    p + "attn.c_attn.bias")
+            self.layers.append(d)
         self.ln_f = (f32("gpt.ln_f.weight"), f32("gpt.ln_f.bias"))
         self.final_norm = (f32("final_norm.weight"), f32("final_norm.bias"))
         self.V = W["mel_head.weight"].shape[0]
@@ -186,34 +205,70 @@ class GPTEngine:
                 nat.prefetch(tensors, self.prefetch_blocks, self._sink)
 
         nat.embed_step(self.tokens, self.mel_emb, self.mel_pos, step, 1, h)
-        pending = None
+        pending = None  # bias of an FC2 whose split-K slabs have not been folded into h yet
+        mode = self.decode_mode
         for i, l in enumerate(self.layers):
             if i + 1 < self.L:
                 n = self.layers[i + 1]
                 prefetch([n["w_qkv"], n["w_o"], n["w_fc"], n["w_pr"]])
             else:
                 prefetch([self.w_head])
-            if pending is None:
-                nat.ln_reduce(h, l["ln1"][0], l["ln1"][1], xn)
+            # --- attention half
+            if mode >= 3:
+                nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv_ln"], l["b_qkv_ln"], x=h, x_ln_f32=True, epi=nat.EPI_QKV_CACHE, y=self.q,
+                                kcache=self.kc[i], vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s)
             else:
-                nat.ln_reduce(h, l["ln1"][0], l["ln1"][1], xn, slab=slab, nslab=KS, bias=pending)
-            nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv"], l["b_qkv"], x=xn, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
-                            vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s)
+                if pending is None:
+                    nat.ln_reduce(h, l["ln1"][0], l["ln1"][1], xn)
+                else:
+                    nat.ln_reduce(h, l["ln1"][0], l["ln1"][1], xn, slab=slab, nslab=KS, bias=pending)
+                nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv"], l["b_qkv"], x=xn, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
+                                vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s)
             nat.attn_decode(self.q, self.kc[i], self.vc[i], self.a, self.pad, pos, B, H, self._cap_s)
-            nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS)
-            nat.ln_reduce(h, l["ln2"][0], l["ln2"][1], xn, slab=slab, nslab=KS, bias=l["b_o"])
-            nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f)
-            nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], None, x=self.f, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS)
-            pending = l["b_pr"]
+            # --- MLP half
+            if mode >= 2:
+                nat.gemm_skinny(T, B, D, D, l["w_o"], l["b_o"], x=self.a, epi=nat.EPI_RESID_F32, yf=h)
+                nat.gemm_skinny(T, B, 4 * D, D, l["w_fc_ln"], l["b_fc_ln"], x=h, x_ln_f32=True, epi=nat.EPI_GELU_STORE, y=self.f)
+            else:
+                nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS)
+                nat.ln_reduce(h, l["ln2"][0], l["ln2"][1], xn, slab=slab, nslab=KS, bias=l["b_o"])
+                nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f)
+            if mode >= 3:
+                nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], l["b_pr"], x=self.f, epi=nat.EPI_RESID_F32, yf=h)
+                pending = None
+            else:
+                nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], None, x=self.f, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS)
+                pending = l["b_pr"]
         n0 = self.layers[0]
         prefetch([n0["w_qkv"], n0["w_o"], n0["w_fc"], n0["w_pr"]])  # for the next token, under the head + sampling
-        self._head(h, B, pending=(slab, KS, pending))
+        self._head(h, B, pending=None if pending is None else (slab, KS, pending))
         if side is not None:
             main.wait_stream(side)
 
     def _step_kernels(self, B, sp):
         self._step_transformer(B)
         self._sample(B, sp)
+
+    def gemm_launches_of_step(self, B):
+        """Measurement aid (bench.py): ONLY the skinny-GEMM launches of one decode step, with the step's real arguments
+        (97 launches: 4 per block + the head).  Returns (launch count, algorithmic bytes: weights once + activations)."""
+        T, D, H, KS = self.dtype, self.D, self.H, self.KSPLIT
+        pos = self.state[1:2]
+        xn = self.xn[:B]
+        slab = self.slab.view(-1)[: KS * B * D].view(KS, B, D)
+        es = 4 if T == torch.float32 else 2
+        nbytes, n = 0, 0
+        for i, l in enumerate(self.layers):
+            nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv"], l["b_qkv"], x=xn, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
+                            vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s)
+            nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS)
+            nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f)
+            nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], None, x=self.f, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS)
+            nbytes += 12 * D * D * es + B * D * es * (1 + 1 + 1 + 4) + B * es * (3 * D + 4 * D) + 2 * KS * B * D * 4
+            n += 4
+        nat.gemm_skinny(T, B, self.V, D, self.w_head, self.b_head, x=self.xn, epi=nat.EPI_STORE_F32, yf=self.logits)
+        nbytes += self.V * D * es + B * D * es + B * self.V * 4
+        return n + 1, nbytes
 
     def decode(self, max_new: int, sp: dict, force_stop=None, use_graph=True, check_every=16, return_logits=False):
         """Run the sampling loop after prefill().  Returns codes int64 [B, n] padded with the stop token

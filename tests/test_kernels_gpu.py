@@ -377,3 +377,24 @@ def test_tanh_pcm(nat):
     assert (wav - ref).abs().max().item() < 2e-6
     exp = torch.clamp(32767 * wav, -32767.0, 32767.0).cpu().numpy().astype(np.int16)
     assert np.array_equal(pcm.cpu().numpy(), exp)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N", [(1, 3840), (13, 5120), (32, 5120), (32, 8194)])
+def test_gemm_skinny_layernorm_fused(nat, dtype, M, N):
+    """A operand = fp32 rows normalised on the fly; LayerNorm affine folded into W / bias by the caller."""
+    K = 1280
+    h = rnd(M, K, seed=120, scale=3.0) + 1.5          # non-zero mean on purpose
+    g, bb = 1 + 0.1 * rnd(K, seed=121), 0.1 * rnd(K, seed=122)
+    w = rnd(K, N, seed=123) * 0.03
+    c = rnd(N, seed=124)
+    wf = (g[:, None] * w).to(dtype)
+    bf = (bb @ w + c).contiguous()
+    wp = nat.pack_weight(wf)
+    xhat = F.layer_norm(h, (K,), None, None, 1e-5)
+    ref = xhat.to(dtype).float() @ wf.float() + bf      # what the kernel computes, in fp32
+    y = torch.empty(M, N, dtype=dtype, device=DEV)
+    nat.gemm_skinny(dtype, M, N, K, wp, bf, x=h, x_ln_f32=True, epi=nat.EPI_STORE, y=y)
+    assert (y.float() - ref).abs().max().item() < 3e-2
+    full = F.layer_norm(h, (K,), g, bb, 1e-5) @ w + c   # the un-folded fp32 computation
+    assert (y.float() - full).abs().max().item() < 6e-2
