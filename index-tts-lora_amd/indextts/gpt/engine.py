@@ -41,7 +41,9 @@ class GPTEngine:
         #           out-projection updates the residual stream directly (no split-K)             -> 6 launches per block
         #   mode 3: additionally LayerNorm-1 inside the QKV GEMM and an unsplit FC2               -> 5 launches per block
         #   mode 1: every LayerNorm is its own [residual-reduce + LN] launch                      -> 7 launches per block
-        self.decode_mode = int(os.environ.get("ITTS_DECODE_MODE", "2")) if dtype != torch.float32 else 1
+        # Measured on MI355X (B=32, bf16): mode 1 1.29 ms/token, mode 2 1.32, mode 3 1.49 -- the unsplit N=1280 GEMMs
+        # (80 workgroups) and the heavier fused prologue cost more than the launches they save, so mode 1 is the default.
+        self.decode_mode = int(os.environ.get("ITTS_DECODE_MODE", "1")) if dtype != torch.float32 else 1
 
         def fold(ln_w, ln_b, w_kn, b_n):
             """LN(x; g, b) @ W + c  ==  norm(x) @ (diag(g) W) + (b @ W + c)."""
