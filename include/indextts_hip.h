@@ -52,6 +52,9 @@ extern "C" {
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
+/* tuning/debug knob, not part of the product path: key 1 = column tiles per skinny-GEMM workgroup, key 2 = waves per
+ * workgroup (0 restores the built-in heuristic) */
+int itts_debug_set(int key, int value);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Packed weight layout (shared by itts_gemm_skinny and itts_gemm_conv).  A logical matrix W[K][N] (K = reduction

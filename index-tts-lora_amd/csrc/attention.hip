@@ -130,103 +130,144 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Prefill: workgroup = one wave = 64 consecutive queries of one (b, h); each lane owns one query row (q and the output
-// accumulator live in registers, fp32).  Key/value tiles of 32 rows are staged in LDS as fp32 and broadcast-read.
-// Online softmax per tile.  The workgroup whose query tile covers a key tile also writes those k/v rows to the cache.
+// Prefill / latent pass: flash-style causal attention on the matrix cores.  Workgroup = 4 waves = 64 consecutive queries
+// of one (b, h); wave w owns 16 query rows.  Per 64-key tile: K rows and a TRANSPOSED V tile are staged in LDS, S = Q K^T
+// (A = Q fragments kept in registers, B = K rows: both are 16-byte row-major reads), online softmax in the accumulator
+// layout (row max / sum over the 16 lanes that hold a row's columns), P goes through a per-wave LDS scratch to become an
+// A operand, O += P V with B = rows of V^T.  fp32 statistics; exact-fp32 MFMA in fp32 mode.  The workgroup whose query
+// tile covers a key tile also writes those k/v rows to the cache.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int AP_KT = 32;
-
 template <typename T>
-__global__ __launch_bounds__(64) void attn_prefill_kernel(const T* __restrict__ qkv, T* __restrict__ out,
-                                                           T* __restrict__ kc, T* __restrict__ vc,
-                                                           const int32_t* __restrict__ pad, int S, int H, int smax) {
+__global__ __launch_bounds__(256) void attn_prefill_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                            T* __restrict__ kc, T* __restrict__ vc,
+                                                            const int32_t* __restrict__ pad, int S, int H, int smax) {
   typedef Elem<T> EL;
-  __shared__ __attribute__((aligned(16))) float ks[AP_KT][HD];
-  __shared__ __attribute__((aligned(16))) float vs[AP_KT][HD];
+  typedef typename EL::frag frag;
+  constexpr int E = EL::E, KS = EL::KS, NKS = HD / KS;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int RS = HD * ES + 16;   // LDS row stride in bytes (64 elements + 16 B pad)
+  constexpr int CPR = HD / E;        // 16-byte chunks per row
+  __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * RS];
+  __shared__ __attribute__((aligned(16))) unsigned char Vt[64 * RS];
+  __shared__ __attribute__((aligned(16))) unsigned char Ps[4][16 * RS];
   const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
   const int D = H * HD;
-  const int qi = q0 + lane;
-  const bool qok = qi < S;
   const int j0 = pad ? pad[b] : 0;
   const T* base = qkv + (int64_t)b * S * 3 * D;
 
-  float qf[HD], o[HD];
+  frag qf[NKS];
+  {
+    const int row = q0 + wave * 16 + c;
 #pragma unroll
-  for (int d = 0; d < HD; ++d) {
-    qf[d] = qok ? EL::to_f(base[(int64_t)qi * 3 * D + h * HD + d]) * 0.125f : 0.f;
-    o[d] = 0.f;
+    for (int ks = 0; ks < NKS; ++ks)
+      qf[ks] = (row < S) ? ld16<frag>(base + (int64_t)row * 3 * D + h * HD + ks * KS + g * E) : zero_frag<frag>();
   }
-  float m = -INFINITY, l = 0.f;
-  const int jend = min(S, q0 + 64);  // keys needed by this query tile: [0, jend)
-  const int jstart = (j0 / AP_KT) * AP_KT;
-  for (int jt = (kc ? 0 : jstart); jt < jend; jt += AP_KT) {
+  f32x4 O[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) O[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { m[j] = -INFINITY; l[j] = 0.f; }
+
+  const int jend = min(S, q0 + 64);
+  for (int jt = (j0 / 64) * 64; jt < jend; jt += 64) {
     __syncthreads();
-    // stage 32 k rows and 32 v rows (64 dims each): 2048 + 2048 elements over 64 lanes
-    for (int idx = lane; idx < AP_KT * HD; idx += 64) {
-      int jj = idx >> 6, d = idx & 63;
-      int j = jt + jj;
-      float kvv = 0.f, vvv = 0.f;
-      if (j < S) {
-        T kraw = base[(int64_t)j * 3 * D + D + h * HD + d];
-        T vraw = base[(int64_t)j * 3 * D + 2 * D + h * HD + d];
-        kvv = EL::to_f(kraw);
-        vvv = EL::to_f(vraw);
-        if (kc && jt >= q0 && jt < q0 + 64) {
-          kc[(((int64_t)b * H + h) * smax + j) * HD + d] = kraw;
-          vc[(((int64_t)b * H + h) * smax + j) * HD + d] = vraw;
+    // ---- stage K rows and V^T (and append to the cache when this workgroup owns the tile)
+    for (int ch = tid; ch < 64 * CPR; ch += 256) {
+      const int kk = ch / CPR, dc = ch - kk * CPR;
+      const int key = jt + kk;
+      frag kv = zero_frag<frag>(), vv = zero_frag<frag>();
+      if (key < S) {
+        const T* src = base + (int64_t)key * 3 * D + D + h * HD + dc * E;
+        kv = ld16<frag>(src);
+        vv = ld16<frag>(src + D);
+        if (kc != nullptr && jt == q0) {
+          const int64_t o = (((int64_t)b * H + h) * smax + key) * HD + dc * E;
+          st16(kc + o, kv);
+          st16(vc + o, vv);
         }
       }
-      ks[jj][d] = kvv;
-      vs[jj][d] = vvv;
+      st16(Ks + kk * RS + dc * E * ES, kv);
+#pragma unroll
+      for (int e = 0; e < E; ++e) *reinterpret_cast<T*>(Vt + (dc * E + e) * RS + kk * ES) = vv[e];
     }
     __syncthreads();
-    if (jt + AP_KT <= j0) continue;  // tile entirely inside the left padding (only staged for the cache write)
-    float s[AP_KT];
-    float tmax = -INFINITY;
+    if (jt + 64 <= j0) continue;  // tile entirely inside the left padding (block-uniform)
+    // ---- S = Q K^T  (per wave: 16 queries x 64 keys)
+    f32x4 sacc[4];
 #pragma unroll
-    for (int jj = 0; jj < AP_KT; ++jj) {
-      float d0 = 0.f;
+    for (int n = 0; n < 4; ++n) {
+      sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int d = 0; d < HD; d += 4) {
-        f32x4 kv = *reinterpret_cast<const f32x4*>(&ks[jj][d]);
-        d0 = fmaf(qf[d], kv[0], d0);
-        d0 = fmaf(qf[d + 1], kv[1], d0);
-        d0 = fmaf(qf[d + 2], kv[2], d0);
-        d0 = fmaf(qf[d + 3], kv[3], d0);
+      for (int ks = 0; ks < NKS; ++ks) {
+        frag bf = ld16<frag>(Ks + (16 * n + c) * RS + (ks * KS + g * E) * ES);
+        sacc[n] = EL::mma(qf[ks], bf, sacc[n]);
       }
-      int j = jt + jj;
-      bool vis = qok && (j <= qi) && (j >= j0);
-      s[jj] = vis ? d0 : -INFINITY;
-      tmax = fmaxf(tmax, s[jj]);
     }
-    float mn = fmaxf(m, tmax);
-    if (mn > -INFINITY) {               // something is visible for this lane
-      float corr = __expf(m - mn);      // m = -inf -> 0
-      l *= corr;
+    // ---- online softmax; this lane holds rows 4g+j (j<4), columns 16n+c (n<4)
+    float rmax[4];
 #pragma unroll
-      for (int d = 0; d < HD; ++d) o[d] *= corr;
+    for (int j = 0; j < 4; ++j) {
+      const int q = q0 + wave * 16 + 4 * g + j;
+      float mx = -INFINITY;
 #pragma unroll
-      for (int jj = 0; jj < AP_KT; ++jj) {
-        float pv = __expf(s[jj] - mn);  // -inf -> 0
-        l += pv;
-#pragma unroll
-        for (int d = 0; d < HD; d += 4) {
-          f32x4 vv = *reinterpret_cast<const f32x4*>(&vs[jj][d]);
-          o[d] = fmaf(pv, vv[0], o[d]);
-          o[d + 1] = fmaf(pv, vv[1], o[d + 1]);
-          o[d + 2] = fmaf(pv, vv[2], o[d + 2]);
-          o[d + 3] = fmaf(pv, vv[3], o[d + 3]);
-        }
+      for (int n = 0; n < 4; ++n) {
+        const int key = jt + 16 * n + c;
+        const bool vis = (key <= q) && (key >= j0) && (key < S);
+        const float v = vis ? sacc[n][j] * 0.125f : -INFINITY;
+        sacc[n][j] = v;
+        mx = fmaxf(mx, v);
       }
-      m = mn;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      rmax[j] = mx;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float mn = fmaxf(m[j], rmax[j]);
+      const float corr = (m[j] == -INFINITY) ? 0.f : __expf(m[j] - mn);
+      float rs = 0.f;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const float pv = (sacc[n][j] == -INFINITY) ? 0.f : __expf(sacc[n][j] - mn);
+        sacc[n][j] = pv;
+        rs += pv;
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) rs += __shfl_xor(rs, o, 64);
+      l[j] = l[j] * corr + rs;
+      m[j] = mn;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) O[n][j] *= corr;
+    }
+    // ---- P: accumulator layout -> A-operand layout through the wave's LDS scratch
+    unsigned char* ps = Ps[wave];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<T*>(ps + (4 * g + j) * RS + (16 * n + c) * ES) = EL::from_f(sacc[n][j]);
+    // same wave wrote and reads: LDS operations of a wave complete in order, no barrier needed
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      frag af = ld16<frag>(ps + c * RS + (ks * KS + g * E) * ES);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        frag bf = ld16<frag>(Vt + (16 * n + c) * RS + (ks * KS + g * E) * ES);
+        O[n] = EL::mma(af, bf, O[n]);
+      }
     }
   }
-  if (qok) {
-    float inv = l > 0.f ? 1.0f / l : 0.f;
-    T* orow = out + ((int64_t)b * S + qi) * D + h * HD;
+  // ---- normalise and store: rows 4g+j, dims 16n+c
 #pragma unroll
-    for (int d = 0; d < HD; ++d) orow[d] = EL::from_f(o[d] * inv);
+  for (int j = 0; j < 4; ++j) {
+    const int q = q0 + wave * 16 + 4 * g + j;
+    if (q >= S) continue;
+    const float inv = l[j] > 0.f ? 1.0f / l[j] : 0.f;
+    T* orow = out + ((int64_t)b * S + q) * D + h * HD;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) orow[16 * n + c] = EL::from_f(O[n][j] * inv);
   }
 }
 
@@ -263,7 +304,7 @@ extern "C" int itts_attn_prefill(const void* qkv, void* out, void* kcache, void*
   ITTS_REQUIRE((kcache == nullptr) == (vcache == nullptr), "itts_attn_prefill: pass both caches or neither");
   ITTS_REQUIRE(B > 0 && S > 0 && H > 0 && (!kcache || S <= smax), "itts_attn_prefill: bad shape B=%d S=%d H=%d smax=%d", B, S, H, smax);
   ITTS_REQUIRE(B <= 65535 && H <= 65535, "itts_attn_prefill: grid too large");
-  dim3 grid((S + 63) / 64, H, B), block(64);
+  dim3 grid((S + 63) / 64, H, B), block(256);
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
     case ITTS_F32:

@@ -373,12 +373,16 @@ static int launch_ln_reduce(float* h, const float* slab, int nslab, const float*
     if (two) ITTS_LNR(4, true); else ITTS_LNR(4, false);
   } else if (nslab == 3) {
     if (two) ITTS_LNR(3, true); else ITTS_LNR(3, false);
+  } else if (nslab == 6) {
+    if (two) ITTS_LNR(6, true); else ITTS_LNR(6, false);
+  } else if (nslab == 8) {
+    if (two) ITTS_LNR(8, true); else ITTS_LNR(8, false);
   } else if (nslab == 2) {
     if (two) ITTS_LNR(2, true); else ITTS_LNR(2, false);
   } else if (nslab == 1) {
     if (two) ITTS_LNR(1, true); else ITTS_LNR(1, false);
   } else {
-    set_error("itts_ln_reduce: nslab must be 0..4 (got %d)", nslab);
+    set_error("itts_ln_reduce: nslab must be 0..4, 6 or 8 (got %d)", nslab);
     return ITTS_ERR_INVALID;
   }
 #undef ITTS_LNR

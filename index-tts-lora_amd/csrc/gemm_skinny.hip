@@ -238,6 +238,8 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
   }
 }
 
+int g_tune_ntb = 0, g_tune_nw = 0;  // itts_debug_set(1|2, v): tuning overrides (0 = heuristic)
+
 template <typename T, int MT>
 static int launch_skinny(const SkinnyParams& p, hipStream_t s) {
   constexpr int KS = Elem<T>::KS;
@@ -247,10 +249,12 @@ static int launch_skinny(const SkinnyParams& p, hipStream_t s) {
   int NW = (SB + 4) / 5;
   if (NW > 8) NW = 8;
   if (NW < 1) NW = 1;
+  if (g_tune_nw > 0 && !p.lnf) NW = g_tune_nw > 8 ? 8 : g_tune_nw;
   const int spw = (SB + NW - 1) / NW;
   const int NT = (p.N + 15) / 16;
   // keep the grid within one round of the 256 CUs
   int ntb = (NT * p.ksplit + 255) / 256;
+  if (g_tune_ntb > 0) ntb = g_tune_ntb;
   if (ntb > 3) ntb = 3;
   if (spw > 5 && ntb > 2) ntb = 2;  // register budget of the 10-step variant
   size_t lds = (size_t)NW * ntb * MT * 256 * 4 + (p.lnf ? (size_t)NW * MT * 16 * 2 * 4 : 0);
@@ -327,5 +331,12 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
     }
     if (rc != ITTS_OK) return rc;
   }
+  return ITTS_OK;
+}
+
+extern "C" int itts_debug_set(int key, int value) {
+  if (key == 1) itts::g_tune_ntb = value;
+  else if (key == 2) itts::g_tune_nw = value;
+  else return ITTS_ERR_INVALID;
   return ITTS_OK;
 }

@@ -48,6 +48,7 @@ class SampleArgs(C.Structure):
 _SIGNATURES = {
     "itts_abi_version": (C.c_int, []),
     "itts_last_error": (C.c_char_p, []),
+    "itts_debug_set": (C.c_int, [C.c_int, C.c_int]),
     "itts_packed_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "itts_pack_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_aa_snake_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

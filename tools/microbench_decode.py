@@ -157,3 +157,30 @@ for N in (3840, 4096, 4112, 5120, 6144, 8192):
     us = timed_graph(fn, R * L)
     log(f"skinny K=1280 N={N:5d} ({N // 16:3d} tiles) {us:7.2f} us  {D * N * 2 / us / 1e6:5.2f} TB/s")
     del ws
+
+# ---- sweep (ksplit, tiles per workgroup, waves) for the two N=1280 GEMMs and FC
+slab8 = torch.randn(8, B, D, device=dev)
+for name, K, ws, xin in (("proj", D, w_o, a), ("FC2", 4 * D, w_pr, f)):
+    for ks in (2, 3, 4, 6, 8):
+        for ntb in (1, 2):
+            def fn(ks=ks, ws=ws, xin=xin, K=K):
+                for _ in range(R):
+                    for i in range(L):
+                        nat.gemm_skinny(T, B, D, K, ws[i], None, x=xin, epi=nat.EPI_SLAB_F32, yf=slab8, ksplit=ks)
+            nat.lib().itts_debug_set(1, ntb)
+            us = timed_graph(fn, R * L)
+            log(f"{name} ksplit={ks} ntb={ntb}: {us:6.2f} us  (blocks {((80 + ntb - 1) // ntb) * ks})")
+nat.lib().itts_debug_set(1, 0)
+for ntb in (1, 2, 3):
+    for nw in (4, 8):
+        nat.lib().itts_debug_set(1, ntb)
+        nat.lib().itts_debug_set(2, nw)
+        us = timed_graph(exp_fc, R * L)
+        log(f"FC ntb={ntb} nw={nw}: {us:6.2f} us")
+nat.lib().itts_debug_set(1, 0)
+nat.lib().itts_debug_set(2, 0)
+for ns in (3, 6, 8):
+    def fn(ns=ns):
+        for _ in range(R * L):
+            nat.ln_reduce(h, lw, lb, xn, slab=slab8, nslab=ns, bias=bias_d)
+    log(f"ln_reduce nslab={ns}: {timed_graph(fn, R * L):6.2f} us")
