@@ -131,6 +131,7 @@ class IndexTTS:
 
         self.cache_audio_prompt = None
         self.cache_cond_mel = None
+        self._feat_graphs = {}
         self._cache_conds = None
         self._cache_spk = None
         self.gr_progress = None
@@ -258,6 +259,37 @@ class IndexTTS:
             self.cache_audio_prompt = audio_prompt
             self._cache_conds = self._cache_spk = None
         return self.cache_cond_mel
+
+    def _prompt_features(self, cond_mel):
+        """(conditioning latents [1,32,D], speaker embedding [1,1,512]) of a prompt mel.  The two host-side PyTorch
+        networks are a few hundred small launches; for a given prompt length they are captured once into a CUDA graph
+        and replayed (first call runs eagerly as warm-up; any capture failure falls back to eager execution)."""
+        key = tuple(cond_mel.shape)
+        ent = self._feat_graphs.get(key)
+        if ent is None:
+            self._feat_graphs[key] = "warm"
+            lens = torch.full((cond_mel.shape[0],), cond_mel.shape[-1], device=self.device)
+            return self.gpt.get_conditioning(cond_mel, lens), self.bigvgan.speaker_embedding(cond_mel.transpose(1, 2))
+        if ent == "warm":
+            try:
+                static_mel = cond_mel.clone()
+                lens = torch.full((cond_mel.shape[0],), cond_mel.shape[-1], device=self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    conds = self.gpt.get_conditioning(static_mel, lens)
+                    spk = self.bigvgan.speaker_embedding(static_mel.transpose(1, 2))
+                ent = (g, static_mel, conds, spk)
+            except Exception as e:  # noqa: BLE001
+                print(f">> [warning] prompt-feature graph capture failed ({e}); running eagerly")
+                ent = "eager"
+            self._feat_graphs[key] = ent
+        if ent == "eager":
+            lens = torch.full((cond_mel.shape[0],), cond_mel.shape[-1], device=self.device)
+            return self.gpt.get_conditioning(cond_mel, lens), self.bigvgan.speaker_embedding(cond_mel.transpose(1, 2))
+        g, static_mel, conds, spk = ent
+        static_mel.copy_(cond_mel)
+        g.replay()
+        return conds.clone(), spk.clone()
 
     def _conds(self, cond_mel, speaker_id=None):
         if speaker_id:
@@ -451,8 +483,7 @@ class IndexTTS:
                 phase_events[name] = e
         gen, _ = self._gen_kwargs(generation_kwargs)
         mark("start")
-        conds = self.gpt.get_conditioning(cond_mel, torch.tensor([cond_mel.shape[-1]], device=self.device))
-        spk = self.bigvgan.speaker_embedding(cond_mel.transpose(1, 2))
+        conds, spk = self._prompt_features(cond_mel)
         L = max(int(t.numel()) for t in text_token_rows)
         stop = self.cfg.gpt.stop_text_token
         batch = torch.full((len(text_token_rows), L), stop, dtype=torch.int32, device=self.device)
