@@ -287,14 +287,12 @@ def main():
     if rank == 0 and not args.no_roofline:
         # one more identical step with per-launch HIP events (eager launches instead of graph replay)
         eng = tts.gpt.engine
-        real_get_graph = eng._get_graph
-        eng._get_graph = lambda B, sp_: None
-        t_phase = {}
+        eng.force_eager = True
         with KernelTimer(nat) as kt:
             torch.cuda.synchronize()
             step(4242)
             agg = kt.summary()
-        eng._get_graph = real_get_graph
+        eng.force_eager = False
         tot = sum(v[1] for v in agg.values())
         breakdown = {n: {"launches": v[0], "ms": round(v[1], 3), "share": round(v[1] / tot, 3)} for n, v in
                      sorted(agg.items(), key=lambda kv: -kv[1][1])}

@@ -134,11 +134,10 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
     uint32_t thr = 0u;
     for (int bit = 31; bit >= 0; --bit) {
       const uint32_t cand = thr | (1u << bit);
+      // wave-wide count without cross-lane shuffles: one ballot + scalar popcount per key slot
       int cnt = 0;
 #pragma unroll
-      for (int i = 0; i < SM_MAXV / 256; ++i) cnt += keys[i] >= cand ? 1 : 0;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+      for (int i = 0; i < SM_MAXV / 256; ++i) cnt += __popcll(__ballot(keys[i] >= cand));
       int* slot = &hist[(bit & 1) * 4];
       if (lane == 0) slot[wave] = cnt;
       __syncthreads();

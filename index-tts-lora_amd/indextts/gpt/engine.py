@@ -83,6 +83,8 @@ class GPTEngine:
         self.KSPLIT = 3  # split-K of the two N=1280 GEMMs of a block: 80 column tiles x 3 = 240 workgroups (one round of 256 CUs)
         self.prefetch_blocks = int(os.environ.get("ITTS_PREFETCH_BLOCKS", "0"))  # side-stream weight prefetch: measured 1.5x SLOWER in-graph, off
         self._side = None
+        self.force_eager = False  # measurement aid: launch every kernel eagerly
+        self.steps_per_graph = 4  # decode tokens per CUDA-graph replay (the loop state lives on the device)
         self._sink = torch.zeros(4, dtype=torch.int32, device=dev)
         self.weight_bytes = sum(t.numel() * t.element_size() for l in self.layers for t in
                                 (l["w_qkv"], l["w_o"], l["w_fc"], l["w_pr"])) + self.w_head.numel()
@@ -285,29 +287,31 @@ class GPTEngine:
         logits_trace = [self.logits[:B].clone()] if return_logits else None
         self._sample(B, sp)  # token 1 from the prefill logits
         n = 1
-        graph = None
+        G = 1 if return_logits else self.steps_per_graph
         while n < max_new:
-            if use_graph and graph is None and n >= 2:
-                graph = self._get_graph(B, sp)
-            if graph is not None:
-                graph.replay()
+            if use_graph and not self.force_eager and n >= 2:
+                k = G if n + G <= max_new else 1          # several tokens per replay while they fit
+                self._get_graph(B, sp, k).replay()
             else:
-                self._step_kernels(B, sp)
-            n += 1
+                k = 1
+                self._step_kernels(B, sp)                 # eager: first step doubles as the warm-up before capture
+            prev = n
+            n += k
             if return_logits:
                 logits_trace.append(self.logits[:B].clone())
-            if n % check_every == 0 and int(self.state[2].item()) >= B:
+            if n // check_every != prev // check_every and int(self.state[2].item()) >= B:
                 break
         codes = self.history[:B, :n].to(torch.int64)
         return (codes, torch.stack(logits_trace, 0)) if return_logits else codes
 
-    def _get_graph(self, B, sp):
-        key = (B, tuple(sorted(sp.items())))
+    def _get_graph(self, B, sp, nsteps=1):
+        key = (B, nsteps, tuple(sorted(sp.items())))
         g = self._graphs.get(key)
         if g is None:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._step_kernels(B, sp)
+                for _ in range(nsteps):
+                    self._step_kernels(B, sp)
             self._graphs[key] = g
         return g
 
