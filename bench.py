@@ -175,6 +175,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--schedule", choices=["pipelined", "serial"], default="pipelined",
+                    help="pipelined: latent pass + vocoder of batch i on a second HIP stream beside the token loop of batch "
+                         "i+1 (BatchPipeline); serial: one batch at a time on one stream")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -191,7 +194,7 @@ def main():
 
     import weights
     from indextts import _native as nat
-    from indextts.infer import IndexTTS
+    from indextts.infer import BatchPipeline, IndexTTS
 
     gsd = bsd = None
     if rank == 0:
@@ -218,12 +221,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for w in range(args.warmup):
-        outs = step(1234 + w)
+    pipe = BatchPipeline(tts) if args.schedule == "pipelined" else None
+
+    def run_steps(n, seed0):
+        """n steps of the hot path; every step's waveforms are complete when this returns."""
+        if n <= 0:
+            return None
+        if pipe is None:
+            o = None
+            for k in range(n):
+                o = step(seed0 + k)
+            return o
+        tickets, marks = [], [time.perf_counter()]
+        for k in range(n):
+            tickets.append(pipe.submit(cond_mel, texts, max_mel_tokens=MEL_TOKENS + 1, force_stop=force, seed=seed0 + k, **gen))
+            marks.append(time.perf_counter())
+        o = [t.result() for t in tickets][-1]
+        marks.append(time.perf_counter())
+        log("[bench] pipeline host marks (ms): " + " ".join(f"{1e3 * (b - a):.1f}" for a, b in zip(marks[:-1], marks[1:])))
+        return o
+
+    outs = run_steps(args.warmup, 1234)
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        outs = step(2000 + k)
+    outs = run_steps(args.steps, 2000)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -236,10 +257,14 @@ def main():
     assert samples == BATCH * MEL_TOKENS * 1024, f"unexpected audio length {samples}"
     value = audio_s_step * world * args.steps / elapsed
 
-    # phase split of one more (un-instrumented, graph-replayed) step
+    # phase split of one more (un-instrumented, graph-replayed) step, run serially on one stream
     pe = {}
     step(3000, pe)
     torch.cuda.synchronize()
+    ts = time.perf_counter()
+    step(3001)
+    torch.cuda.synchronize()
+    serial_ms = 1e3 * (time.perf_counter() - ts)
     names = ["start", "conditioned", "prefilled", "decoded", "latents", "vocoded"]
     phases = {f"{a}->{b}": round(pe[a].elapsed_time(pe[b]), 3) for a, b in zip(names[:-1], names[1:])}
     eng = tts.gpt.engine
@@ -276,7 +301,11 @@ def main():
         "config": {"workload": "BASELINE config 3: batch=32 utterances/GPU, top-k sampling (k=30,p=0.8), 140 acoustic tokens "
                                "(5.97 s) each, shared 3.2 s prompt, text U{20..60} tokens, random-init weights at real shapes",
                    "gpt_dtype": "bf16", "vocoder_dtype": "fp16", "parallelism": f"dp{world} (utterance sharding, no collectives)",
-                   "audio_seconds_per_step_per_gpu": round(audio_s_step, 3)},
+                   "audio_seconds_per_step_per_gpu": round(audio_s_step, 3),
+                   "schedule": ("2-stage batch pipeline: latent pass + vocoder of batch i on a second HIP stream beside "
+                                "the token loop of batch i+1; all steps complete inside the timed region")
+                   if pipe is not None else "serial: one batch at a time on one stream"},
+        "serial_ms_per_step": round(serial_ms, 3),
         "first_token_ms_p50": round(first_token_ms, 2),
         "phases_ms": phases,
         "decode_step": {"us": round(step_us, 2), "algorithmic_MB": round(dec_bytes / 1e6, 1), "ctx": ctx_mid,

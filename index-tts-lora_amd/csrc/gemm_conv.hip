@@ -10,6 +10,7 @@
 // L2 into B-fragment registers (they are shared only by workgroups, which L2 serves), double-buffered one step ahead;
 // the next chunk's activation rows are fetched into registers while the current chunk is being multiplied.
 #include "common.h"
+#include <type_traits>
 
 namespace itts {
 
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = EL::mma(af[tm], bf[tn], acc[tm][tn]);
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = EL::mma(bf[tn], af[tm], acc[tm][tn]);  // weights as A: transposed tile
   };
 
   frag b0[TN], b1[TN], b2[TN];
@@ -191,59 +192,127 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
     }
   }
 
-  // ---- epilogue: range-checked buffer loads/stores (invalid elements get offset OOB: loads return 0, stores are
-  // dropped), all residual / accumulate operands of a column tile requested before the first use.
-  auto epilogue = [&](auto tag) {
+  // ---- epilogue.  The MFMAs ran with the weight fragment as the A operand, so each lane holds the transposed tile:
+  // acc[tm][tn][jj] = out(row = tile row (lane & 15), channel = 16*n-tile + 4*(lane >> 4) + jj), i.e. FOUR CONSECUTIVE
+  // CHANNELS of one output row -> one 8/16-byte access per tile for residual, accumulate and store instead of four
+  // 2/4-byte ones.  Range-checked buffer accesses throughout (invalid elements get offset OOB: loads return 0, stores
+  // are dropped; a null bias is a zero-length buffer), all residual / accumulate operands of a batch of m-tiles
+  // requested before the first use.  VEC needs N, y_shift, y_limit to be multiples of 4 (validity is then per quad).
+  auto epilogue = [&](auto tag, auto vec_tag) {
     typedef decltype(tag) YT;  // storage type of y / resid: float or T
     constexpr int ES = (int)sizeof(YT);
+    constexpr bool VEC = decltype(vec_tag)::value;
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
         (YT*)p.y + (int64_t)b * p.y_bstride, 0, (int)(p.y_limit * ES), 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<YT*>((const YT*)(p.resid ? p.resid : p.y)) + (int64_t)b * p.y_bstride, 0, (int)(p.y_limit * ES), 0x00020000);
-    auto ld = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off) -> float {
+    const __amdgpu_buffer_rsrc_t rb1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.bias ? p.bias : (const float*)p.wp), 0, p.bias ? p.N * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.bias2 ? p.bias2 + (int64_t)b * p.N : (const float*)p.wp), 0, p.bias2 ? p.N * 4 : 0, 0x00020000);
+    auto ld1 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off) -> float {
       if constexpr (ES == 4) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
       else return Elem<YT>::to_f(__builtin_bit_cast(YT, __builtin_amdgcn_raw_buffer_load_b16(rs, off, 0, 0)));
     };
-    auto stv = [&](unsigned off, float v) {
+    auto st1 = [&](unsigned off, float v) {
       if constexpr (ES == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, off, 0, 0);
       else __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, Elem<YT>::from_f(v)), ry, off, 0, 0);
+    };
+    auto ld4 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off, float (&o)[4]) {
+      if constexpr (ES == 4) {
+        f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = v[i];
+      } else {
+        typedef YT yt4 __attribute__((ext_vector_type(4)));
+        yt4 v = __builtin_bit_cast(yt4, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (float)v[i];
+      }
+    };
+    auto st4 = [&](unsigned off, const float (&o)[4]) {
+      if constexpr (ES == 4) {
+        f32x4 v = {o[0], o[1], o[2], o[3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, off, 0, 0);
+      } else {
+        typedef YT yt4 __attribute__((ext_vector_type(4)));
+        yt4 v = {(YT)o[0], (YT)o[1], (YT)o[2], (YT)o[3]};
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), ry, off, 0, 0);
+      }
     };
     const bool has_r = p.resid != nullptr, has_a = p.accumulate != 0;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-      const int col = (nt0 + tn) * 16 + r;
-      const bool cok = col < p.N;
-      float bs = (cok && p.bias) ? p.bias[col] : 0.f;
-      if (cok && p.bias2) bs += p.bias2[(int64_t)b * p.N + col];
+      const int col0 = (nt0 + tn) * 16 + g * 4;
+      const bool cok = (nt0 + tn) < p.NT;
+      float bs[4];
+      {
+        // zero-length / short descriptors make out-of-range channels (and a null bias) read as 0
+        unsigned boff = cok ? (unsigned)(col0 * 4) : OOB;
+        if constexpr (VEC) {
+          f32x4 v1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb1, boff, 0, 0));
+          f32x4 v2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb2, boff, 0, 0));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) bs[i] = v1[i] + v2[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            unsigned o = cok ? (unsigned)((col0 + i) * 4) : OOB;
+            bs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb1, o, 0, 0)) +
+                    __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb2, o, 0, 0));
+          }
+        }
+      }
       constexpr int TC = TM < 4 ? TM : 4;  // m-tiles per batch of in-flight epilogue loads
 #pragma unroll
       for (int tm0 = 0; tm0 < TM; tm0 += TC) {
-        unsigned offs[TC][4];
+        unsigned offs[TC][VEC ? 1 : 4];
         float rv[TC][4], av[TC][4];
 #pragma unroll
-        for (int u = 0; u < TC; ++u)
+        for (int u = 0; u < TC; ++u) {
+          const int t = t0 + wm * TM * 16 + (tm0 + u) * 16 + r;
+          const int64_t flat = (int64_t)t * p.N + col0 + p.y_shift;
+          const bool rok = cok && (t < p.Tout);
+          if constexpr (VEC) {
+            bool ok = rok && (col0 < p.N) && (flat >= 0) && (flat < p.y_limit);
+            offs[u][0] = ok ? (unsigned)(flat * ES) : OOB;
+            if (has_r) ld4(rr, offs[u][0], rv[u]);
+            if (has_a) ld4(ry, offs[u][0], av[u]);
+          } else {
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            int t = t0 + wm * TM * 16 + (tm0 + u) * 16 + g * 4 + jj;
-            int64_t flat = (int64_t)t * p.N + col + p.y_shift;
-            bool ok = cok && (t < p.Tout) && (flat >= 0) && (flat < p.y_limit);
-            offs[u][jj] = ok ? (unsigned)(flat * ES) : OOB;
-            rv[u][jj] = has_r ? ld(rr, offs[u][jj]) : 0.f;
-            av[u][jj] = has_a ? ld(ry, offs[u][jj]) : 0.f;
+            for (int jj = 0; jj < 4; ++jj) {
+              bool ok = rok && (col0 + jj < p.N) && (flat + jj >= 0) && (flat + jj < p.y_limit);
+              offs[u][jj] = ok ? (unsigned)((flat + jj) * ES) : OOB;
+              if (has_r) rv[u][jj] = ld1(rr, offs[u][jj]);
+              if (has_a) av[u][jj] = ld1(ry, offs[u][jj]);
+            }
           }
+        }
 #pragma unroll
-        for (int u = 0; u < TC; ++u)
+        for (int u = 0; u < TC; ++u) {
+          float o[4];
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) {
-            float v = acc[tm0 + u][tn][jj] + bs;
+            float v = acc[tm0 + u][tn][jj] + bs[jj];
             if (p.act == 1) v = gelu_new(v);
-            v = (v + rv[u][jj]) * p.scale + av[u][jj];
-            stv(offs[u][jj], v);
+            v = (v + (has_r ? rv[u][jj] : 0.f)) * p.scale + (has_a ? av[u][jj] : 0.f);
+            o[jj] = v;
           }
+          if constexpr (VEC) st4(offs[u][0], o);
+          else {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) st1(offs[u][jj], o[jj]);
+          }
+        }
       }
     }
   };
-  if (p.y_f32) epilogue(float{}); else epilogue(T{});
+  const bool vec = ((p.N | p.y_shift | p.y_limit) & 3) == 0;
+  if (p.y_f32) {
+    if (vec) epilogue(float{}, std::true_type{}); else epilogue(float{}, std::false_type{});
+  } else {
+    if (vec) epilogue(T{}, std::true_type{}); else epilogue(T{}, std::false_type{});
+  }
 }
 
 template <typename T, int WM, int WN, int TM, int TN, int CK, int HALO>

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -103,6 +104,11 @@ def dt(t: torch.dtype) -> int:
 
 def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+# Held around every CUDA-graph capture and by helper threads while they enqueue work (infer.BatchPipeline): a capture in
+# the default (global) error mode is invalidated by allocations / synchronisation on any other thread.
+CAPTURE_LOCK = threading.RLock()
 
 
 def _stream():

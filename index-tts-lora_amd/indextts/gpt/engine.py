@@ -309,7 +309,7 @@ class GPTEngine:
         g = self._graphs.get(key)
         if g is None:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with nat.CAPTURE_LOCK, torch.cuda.graph(g):  # no other thread may allocate / synchronise during a capture
                 for _ in range(nsteps):
                     self._step_kernels(B, sp)
             self._graphs[key] = g

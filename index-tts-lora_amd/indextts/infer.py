@@ -11,7 +11,9 @@ from __future__ import annotations
 
 import json
 import os
+import queue
 import random
+import threading
 import time
 import warnings
 from typing import Dict, List
@@ -19,6 +21,7 @@ from typing import Dict, List
 import numpy as np
 import torch
 
+from indextts import _native as nat
 from indextts.BigVGAN.models import BigVGAN as Generator
 from indextts.gpt.model import UnifiedVoice
 from indextts.utils.audio import read_audio, write_pcm16
@@ -275,18 +278,18 @@ class IndexTTS:
                 static_mel = cond_mel.clone()
                 lens = torch.full((cond_mel.shape[0],), cond_mel.shape[-1], device=self.device)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with nat.CAPTURE_LOCK, torch.cuda.graph(g):
                     conds = self.gpt.get_conditioning(static_mel, lens)
                     spk = self.bigvgan.speaker_embedding(static_mel.transpose(1, 2))
-                ent = (g, static_mel, conds, spk)
+                ent = (g, static_mel, conds, spk, lens)  # lens is read by the captured kernels: keep it alive
             except Exception as e:  # noqa: BLE001
-                print(f">> [warning] prompt-feature graph capture failed ({e}); running eagerly")
+                warnings.warn(f"prompt-feature graph capture failed ({e}); running eagerly", RuntimeWarning)
                 ent = "eager"
             self._feat_graphs[key] = ent
         if ent == "eager":
             lens = torch.full((cond_mel.shape[0],), cond_mel.shape[-1], device=self.device)
             return self.gpt.get_conditioning(cond_mel, lens), self.bigvgan.speaker_embedding(cond_mel.transpose(1, 2))
-        g, static_mel, conds, spk = ent
+        g, static_mel, conds, spk, _ = ent
         static_mel.copy_(cond_mel)
         g.replay()
         return conds.clone(), spk.clone()
@@ -476,13 +479,23 @@ class IndexTTS:
         group of equal-length utterances (batching unequal lengths would change the tail of the shorter waveforms).
         Returns a list of fp32 waveforms already scaled to the int16 range, like infer.py:892.
         phase_events, if given, receives torch.cuda.Event marks at the phase boundaries."""
-        def mark(name):
-            if phase_events is not None:
-                e = torch.cuda.Event(enable_timing=True)
-                e.record()
-                phase_events[name] = e
+        st = self._batch_tokens(cond_mel, text_token_rows, max_mel_tokens, force_stop, seed, phase_events, **generation_kwargs)
+        outs = self._batch_waveforms(st, phase_events)
+        return (outs, st["rows"]) if return_codes else outs
+
+    @staticmethod
+    def _mark(phase_events, name):
+        if phase_events is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            phase_events[name] = e
+
+    def _batch_tokens(self, cond_mel, text_token_rows, max_mel_tokens=600, force_stop=None, seed=1234, phase_events=None,
+                      **generation_kwargs):
+        """Stage A of infer_batch: prompt conditioning -> prefill -> sampling loop -> silence squeeze (host).  Everything
+        here is latency-bound small launches; it ends with the codes on the host, as infer.py:848-861 does."""
         gen, _ = self._gen_kwargs(generation_kwargs)
-        mark("start")
+        self._mark(phase_events, "start")
         conds, spk = self._prompt_features(cond_mel)
         L = max(int(t.numel()) for t in text_token_rows)
         stop = self.cfg.gpt.stop_text_token
@@ -496,15 +509,21 @@ class IndexTTS:
                   temperature=float(gen["temperature"]), repetition_penalty=float(gen["repetition_penalty"]), seed=int(seed))
         if not sp["do_sample"]:
             sp["top_p"], sp["top_k"], sp["temperature"] = 1.0, 0, 1.0
-        mark("conditioned")
+        self._mark(phase_events, "conditioned")
         g.engine.prefill(emb, pad, max_mel_tokens)
-        mark("prefilled")
+        self._mark(phase_events, "prefilled")
         codes = g.engine.decode(max_mel_tokens, sp, force_stop=force_stop)
-        mark("decoded")
+        self._mark(phase_events, "decoded")
         codes_c, lens = self.remove_long_silence(codes)
         rows = [codes_c[i, : int(lens[i])] for i in range(codes_c.shape[0])]
-        lat = self._latents(conds, [t.reshape(-1) for t in text_token_rows], rows)
-        mark("latents")
+        return dict(conds=conds, spk=spk, rows=rows, texts=[t.reshape(-1) for t in text_token_rows])
+
+    def _batch_waveforms(self, st, phase_events=None):
+        """Stage B of infer_batch: batched teacher-forced latent pass + vocoder (large MFMA-bound launches, no host sync).
+        Touches no decode-loop state, so it may run on another stream beside the next batch's stage A (BatchPipeline)."""
+        conds, spk = st["conds"], st["spk"]
+        lat = self._latents(conds, st["texts"], st["rows"])
+        self._mark(phase_events, "latents")
         outs = [None] * len(lat)
         groups: Dict[int, List[int]] = {}
         for i, x in enumerate(lat):
@@ -517,5 +536,89 @@ class IndexTTS:
             wav = self._vocode(torch.stack([lat[i] for i in idx], 0), spk)
             for j, i in enumerate(idx):
                 outs[i] = wav[j]
-        mark("vocoded")
-        return (outs, rows) if return_codes else outs
+        self._mark(phase_events, "vocoded")
+        return outs
+
+
+class BatchTicket:
+    """Handle of one batch in flight in a BatchPipeline: result() waits for its vocoder stage and returns the waveforms."""
+
+    def __init__(self, rows, keep):
+        self.rows, self._keep = rows, keep
+        self._ready = threading.Event()
+        self._outs = self._done = self._err = None
+
+    def _set(self, outs, done, err=None):
+        self._outs, self._done, self._err = outs, done, err
+        self._ready.set()
+
+    def result(self):
+        self._ready.wait()
+        if self._err is not None:
+            raise self._err
+        self._done.synchronize()
+        self._keep = None
+        return self._outs
+
+
+class BatchPipeline:
+    """Two-stage software pipeline over utterance batches (serving schedule; not in the reference API).
+
+    Stage A of a batch (conditioning, prefill, the token loop: ~7 small launches per block per token, latency-bound, the
+    matrix cores idle) runs on the caller's thread; its stage B (latent pass + vocoder: large MFMA-bound launches) is
+    enqueued by a worker thread on a second HIP stream and overlaps stage A of the NEXT batch.  Results are identical
+    to infer_batch(): the two stages share only read-only weights (the latent pass and the vocoder allocate their
+    activations per call from the stream-aware allocator, the decode loop owns the KV cache and its state)."""
+
+    def __init__(self, tts: "IndexTTS"):
+        self.tts = tts
+        lo, hi = 0, -1
+        self.stream_a = torch.cuda.Stream(device=tts.device, priority=hi)   # latency-critical token loop
+        self.stream_b = torch.cuda.Stream(device=tts.device, priority=lo)   # throughput work
+        self._jobs: "queue.Queue" = queue.Queue()
+        self._inflight: List[BatchTicket] = []
+        self._thread = threading.Thread(target=self._worker, name="itts-stage-b", daemon=True)
+        self._thread.start()
+
+    def _worker(self):
+        torch.cuda.set_device(self.tts.device)
+        while True:
+            job = self._jobs.get()
+            if job is None:
+                return
+            st, ticket, a_done = job
+            try:
+                # graph captures (global error mode) must not see another thread allocating or synchronising
+                with nat.CAPTURE_LOCK, torch.no_grad(), torch.cuda.stream(self.stream_b):
+                    self.stream_b.wait_event(a_done)
+                    outs = self.tts._batch_waveforms(st)
+                    done = torch.cuda.Event()
+                    done.record()
+                ticket._set(outs, done)
+            except BaseException as e:  # noqa: BLE001  (surfaced by result())
+                ticket._set(None, None, e)
+
+    def submit(self, cond_mel, text_token_rows, **kw) -> BatchTicket:
+        """Runs stage A (returns once the codes are on the host) and hands stage B to the worker."""
+        self.stream_a.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream_a):
+            st = self.tts._batch_tokens(cond_mel, text_token_rows, **kw)
+            for t in (st["conds"], st["spk"]):
+                t.record_stream(self.stream_b)
+            a_done = torch.cuda.Event()
+            a_done.record()
+        ticket = BatchTicket(st["rows"], st)
+        self._inflight = [t for t in self._inflight if not t._ready.is_set()] + [ticket]
+        self._jobs.put((st, ticket, a_done))
+        return ticket
+
+    def drain(self):
+        for t in self._inflight:
+            t._ready.wait()
+        self._inflight.clear()
+        self.stream_a.synchronize()
+        self.stream_b.synchronize()
+
+    def close(self):
+        self._jobs.put(None)
+        self._thread.join()

@@ -167,3 +167,31 @@ def test_bigvgan_half_tracks_fp32(dtype, tol):
     w, _ = v(torch.from_numpy(g["latent8"]).to(DEV), torch.from_numpy(g["melref"]).to(DEV))
     rms = (w.cpu() - torch.from_numpy(g["wav8"])).pow(2).mean().sqrt().item()
     assert rms < tol, rms
+
+
+def test_batch_pipeline_equals_serial_infer_batch():
+    """BatchPipeline (stage B on a second stream beside the next batch's token loop) returns exactly what
+    infer_batch returns batch by batch: same kernels, same inputs, no shared mutable state between the stages."""
+    from indextts.infer import BatchPipeline, IndexTTS
+    cfg = weights.reference_config()
+    cfg["gpt"]["layers"] = 2
+    tts = IndexTTS.from_weights(cfg, weights.gpt_state_dict(2), weights.bigvgan_state_dict(), device="cuda:0",
+                                precision_config={"gpt": "bf16", "vocoder": "fp16"})
+    cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
+    rng = np.random.default_rng(5)
+    batches = [[torch.from_numpy(rng.integers(2, 12000, size=int(n))).to(torch.int32) for n in rng.integers(5, 20, size=4)]
+               for _ in range(3)]
+    gen = dict(do_sample=True, top_k=30, top_p=0.8, temperature=1.0, repetition_penalty=10.0, num_beams=1)
+    kw = dict(max_mel_tokens=13, force_stop=[12, 9, 12, 7])
+    serial = [tts.infer_batch(cond_mel, b, seed=100 + i, return_codes=True, **kw, **gen) for i, b in enumerate(batches)]
+    torch.cuda.synchronize()
+    pipe = BatchPipeline(tts)
+    tickets = [pipe.submit(cond_mel, b, seed=100 + i, **kw, **gen) for i, b in enumerate(batches)]
+    for (wavs, rows), t in zip(serial, tickets):
+        got = t.result()
+        assert [r.tolist() for r in rows] == [r.tolist() for r in t.rows]
+        assert len(got) == len(wavs)
+        for a, b in zip(wavs, got):
+            assert a.shape == b.shape and torch.equal(a, b)
+    pipe.drain()
+    pipe.close()
