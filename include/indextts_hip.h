@@ -53,7 +53,7 @@ extern "C" {
 int itts_abi_version(void);
 const char* itts_last_error(void);
 /* tuning/debug knob, not part of the product path: key 1 = column tiles per skinny-GEMM workgroup, key 2 = waves per
- * workgroup (0 restores the built-in heuristic) */
+ * skinny-GEMM workgroup, key 3 = plain-GEMM kernel override (0 restores the built-in heuristic) */
 int itts_debug_set(int key, int value);
 
 /* ------------------------------------------------------------------------------------------------------------------

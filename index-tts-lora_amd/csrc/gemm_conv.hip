@@ -35,6 +35,153 @@ struct ConvParams {
   int MB, NB, GM;  // m-blocks per batch element, n-blocks, m-blocks per L2 group (XCD-aware tile order)
 };
 
+// XCD-aware tile order (speed only): workgroups are dealt round-robin to the 8 XCDs, so give each XCD a CONTIGUOUS
+// run of the tile sequence, and order the sequence so that 32 consecutive tiles form a compact GM x (32/GM) patch of
+// the output -- its activation rows and weight columns then stay in that XCD's 4-MiB L2 instead of being re-fetched
+// from the Infinity Cache by every tile.
+__device__ __forceinline__ void tile_of_workgroup(const ConvParams& p, int& mblk, int& nblk, int& b) {
+  const int bid = blockIdx.x, nwg = gridDim.x;
+  const int xcd = bid & 7, q = bid >> 3, base = nwg >> 3, rem = nwg & 7;
+  const int L = xcd * base + min(xcd, rem) + q;
+  const int MBt = p.MB * p.B;
+  const int per_group = p.GM * p.NB;
+  const int mgi = L / per_group, r1 = L - mgi * per_group;
+  const int gm_eff = min(p.GM, MBt - mgi * p.GM);
+  nblk = r1 / gm_eff;
+  const int m = mgi * p.GM + (r1 - nblk * gm_eff);
+  b = m / p.MB;
+  mblk = m - b * p.MB;
+}
+
+// Epilogue.  The MFMAs ran with the weight fragment as the A operand, so each lane holds the transposed tile:
+// acc[tm][tn][jj] = out(row = tile row (lane & 15), channel = 16*n-tile + 4*(lane >> 4) + jj), i.e. FOUR CONSECUTIVE
+// CHANNELS of one output row -> one 8/16-byte access per tile for residual, accumulate and store instead of four
+// 2/4-byte ones.  Range-checked buffer accesses throughout (invalid elements get offset OOB: loads return 0, stores
+// are dropped; a null bias is a zero-length buffer), all residual / accumulate operands of a batch of m-tiles
+// requested before the first use.  VEC needs N, y_shift, y_limit to be multiples of 4 (validity is then per quad).
+template <typename T, typename YT, bool VEC, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f32x4 (&acc)[TM][TN], int b, int row0, int nt0, int g, int r) {
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  constexpr int ES = (int)sizeof(YT);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+      (YT*)p.y + (int64_t)b * p.y_bstride, 0, (int)(p.y_limit * ES), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<YT*>((const YT*)(p.resid ? p.resid : p.y)) + (int64_t)b * p.y_bstride, 0, (int)(p.y_limit * ES), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.bias ? p.bias : (const float*)p.wp), 0, p.bias ? p.N * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.bias2 ? p.bias2 + (int64_t)b * p.N : (const float*)p.wp), 0, p.bias2 ? p.N * 4 : 0, 0x00020000);
+  auto ld1 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off) -> float {
+    if constexpr (ES == 4) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+    else return Elem<YT>::to_f(__builtin_bit_cast(YT, __builtin_amdgcn_raw_buffer_load_b16(rs, off, 0, 0)));
+  };
+  auto st1 = [&](unsigned off, float v) {
+    if constexpr (ES == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, off, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, Elem<YT>::from_f(v)), ry, off, 0, 0);
+  };
+  auto ld4 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off, float (&o)[4]) {
+    if constexpr (ES == 4) {
+      f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = v[i];
+    } else {
+      typedef YT yt4 __attribute__((ext_vector_type(4)));
+      yt4 v = __builtin_bit_cast(yt4, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (float)v[i];
+    }
+  };
+  auto st4 = [&](unsigned off, const float (&o)[4]) {
+    if constexpr (ES == 4) {
+      f32x4 v = {o[0], o[1], o[2], o[3]};
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, off, 0, 0);
+    } else {
+      typedef YT yt4 __attribute__((ext_vector_type(4)));
+      yt4 v = {(YT)o[0], (YT)o[1], (YT)o[2], (YT)o[3]};
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), ry, off, 0, 0);
+    }
+  };
+  const bool has_r = p.resid != nullptr, has_a = p.accumulate != 0;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col0 = (nt0 + tn) * 16 + g * 4;
+    const bool cok = (nt0 + tn) < p.NT;
+    float bs[4];
+    {
+      // zero-length / short descriptors make out-of-range channels (and a null bias) read as 0
+      unsigned boff = cok ? (unsigned)(col0 * 4) : OOB;
+      if constexpr (VEC) {
+        f32x4 v1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb1, boff, 0, 0));
+        f32x4 v2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb2, boff, 0, 0));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bs[i] = v1[i] + v2[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          unsigned o = cok ? (unsigned)((col0 + i) * 4) : OOB;
+          bs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb1, o, 0, 0)) +
+                  __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb2, o, 0, 0));
+        }
+      }
+    }
+    constexpr int TC = TM < 4 ? TM : 4;  // m-tiles per batch of in-flight epilogue loads
+#pragma unroll
+    for (int tm0 = 0; tm0 < TM; tm0 += TC) {
+      unsigned offs[TC][VEC ? 1 : 4];
+      float rv[TC][4], av[TC][4];
+#pragma unroll
+      for (int u = 0; u < TC; ++u) {
+        const int t = row0 + (tm0 + u) * 16 + r;
+        const int64_t flat = (int64_t)t * p.N + col0 + p.y_shift;
+        const bool rok = cok && (t < p.Tout);
+        if constexpr (VEC) {
+          bool ok = rok && (col0 < p.N) && (flat >= 0) && (flat < p.y_limit);
+          offs[u][0] = ok ? (unsigned)(flat * ES) : OOB;
+          if (has_r) ld4(rr, offs[u][0], rv[u]);
+          if (has_a) ld4(ry, offs[u][0], av[u]);
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            bool ok = rok && (col0 + jj < p.N) && (flat + jj >= 0) && (flat + jj < p.y_limit);
+            offs[u][jj] = ok ? (unsigned)((flat + jj) * ES) : OOB;
+            if (has_r) rv[u][jj] = ld1(rr, offs[u][jj]);
+            if (has_a) av[u][jj] = ld1(ry, offs[u][jj]);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < TC; ++u) {
+        float o[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          float v = acc[tm0 + u][tn][jj] + bs[jj];
+          if (p.act == 1) v = gelu_new(v);
+          v = (v + (has_r ? rv[u][jj] : 0.f)) * p.scale + (has_a ? av[u][jj] : 0.f);
+          o[jj] = v;
+        }
+        if constexpr (VEC) st4(offs[u][0], o);
+        else {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) st1(offs[u][jj], o[jj]);
+        }
+      }
+    }
+  }
+}
+
+// row0 = first output row of this wave's tile column; YT = storage type of y / resid (float or T)
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[TM][TN], int b, int row0, int nt0, int g, int r) {
+  const bool vec = ((p.N | p.y_shift | p.y_limit) & 3) == 0;
+  if (p.y_f32) {
+    if (vec) conv_epilogue_impl<T, float, true>(p, acc, b, row0, nt0, g, r);
+    else conv_epilogue_impl<T, float, false>(p, acc, b, row0, nt0, g, r);
+  } else {
+    if (vec) conv_epilogue_impl<T, T, true>(p, acc, b, row0, nt0, g, r);
+    else conv_epilogue_impl<T, T, false>(p, acc, b, row0, nt0, g, r);
+  }
+}
+
 // CK = k-steps of channels staged per chunk (2 for convolutions, whose taps multiply the MFMA work per chunk; 4 for
 // plain GEMMs).  HALO = compile-time bound on (taps-1)*dil (0 for plain GEMMs) that sizes the staging registers.
 // Waves per SIMD the register budget is sized for: 8-wave workgroups put 2 waves on each SIMD (one wave's MFMAs run under
@@ -61,24 +208,8 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r = lane & 15;
   const int wm = wave / WN, wn = wave % WN;
-  // XCD-aware tile order (speed only): workgroups are dealt round-robin to the 8 XCDs, so give each XCD a CONTIGUOUS
-  // run of the tile sequence, and order the sequence so that 32 consecutive tiles form a compact GM x (32/GM) patch of
-  // the output -- its activation rows and weight columns then stay in that XCD's 4-MiB L2 instead of being re-fetched
-  // from the Infinity Cache by every tile.
   int mblk, nblk, b;
-  {
-    const int bid = blockIdx.x, nwg = gridDim.x;
-    const int xcd = bid & 7, q = bid >> 3, base = nwg >> 3, rem = nwg & 7;
-    const int L = xcd * base + min(xcd, rem) + q;
-    const int MBt = p.MB * p.B;
-    const int per_group = p.GM * p.NB;
-    const int mgi = L / per_group, r1 = L - mgi * per_group;
-    const int gm_eff = min(p.GM, MBt - mgi * p.GM);
-    nblk = r1 / gm_eff;
-    const int m = mgi * p.GM + (r1 - nblk * gm_eff);
-    b = m / p.MB;
-    mblk = m - b * p.MB;
-  }
+  tile_of_workgroup(p, mblk, nblk, b);
   const int t0 = mblk * BM;
   const int nt0 = nblk * (BN / 16) + wn * TN;
   const int HR = BM + (p.taps - 1) * p.dil;   // staged rows
@@ -192,127 +323,7 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
     }
   }
 
-  // ---- epilogue.  The MFMAs ran with the weight fragment as the A operand, so each lane holds the transposed tile:
-  // acc[tm][tn][jj] = out(row = tile row (lane & 15), channel = 16*n-tile + 4*(lane >> 4) + jj), i.e. FOUR CONSECUTIVE
-  // CHANNELS of one output row -> one 8/16-byte access per tile for residual, accumulate and store instead of four
-  // 2/4-byte ones.  Range-checked buffer accesses throughout (invalid elements get offset OOB: loads return 0, stores
-  // are dropped; a null bias is a zero-length buffer), all residual / accumulate operands of a batch of m-tiles
-  // requested before the first use.  VEC needs N, y_shift, y_limit to be multiples of 4 (validity is then per quad).
-  auto epilogue = [&](auto tag, auto vec_tag) {
-    typedef decltype(tag) YT;  // storage type of y / resid: float or T
-    constexpr int ES = (int)sizeof(YT);
-    constexpr bool VEC = decltype(vec_tag)::value;
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-        (YT*)p.y + (int64_t)b * p.y_bstride, 0, (int)(p.y_limit * ES), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<YT*>((const YT*)(p.resid ? p.resid : p.y)) + (int64_t)b * p.y_bstride, 0, (int)(p.y_limit * ES), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb1 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.bias ? p.bias : (const float*)p.wp), 0, p.bias ? p.N * 4 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb2 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.bias2 ? p.bias2 + (int64_t)b * p.N : (const float*)p.wp), 0, p.bias2 ? p.N * 4 : 0, 0x00020000);
-    auto ld1 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off) -> float {
-      if constexpr (ES == 4) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
-      else return Elem<YT>::to_f(__builtin_bit_cast(YT, __builtin_amdgcn_raw_buffer_load_b16(rs, off, 0, 0)));
-    };
-    auto st1 = [&](unsigned off, float v) {
-      if constexpr (ES == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, off, 0, 0);
-      else __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, Elem<YT>::from_f(v)), ry, off, 0, 0);
-    };
-    auto ld4 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off, float (&o)[4]) {
-      if constexpr (ES == 4) {
-        f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = v[i];
-      } else {
-        typedef YT yt4 __attribute__((ext_vector_type(4)));
-        yt4 v = __builtin_bit_cast(yt4, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (float)v[i];
-      }
-    };
-    auto st4 = [&](unsigned off, const float (&o)[4]) {
-      if constexpr (ES == 4) {
-        f32x4 v = {o[0], o[1], o[2], o[3]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, off, 0, 0);
-      } else {
-        typedef YT yt4 __attribute__((ext_vector_type(4)));
-        yt4 v = {(YT)o[0], (YT)o[1], (YT)o[2], (YT)o[3]};
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), ry, off, 0, 0);
-      }
-    };
-    const bool has_r = p.resid != nullptr, has_a = p.accumulate != 0;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int col0 = (nt0 + tn) * 16 + g * 4;
-      const bool cok = (nt0 + tn) < p.NT;
-      float bs[4];
-      {
-        // zero-length / short descriptors make out-of-range channels (and a null bias) read as 0
-        unsigned boff = cok ? (unsigned)(col0 * 4) : OOB;
-        if constexpr (VEC) {
-          f32x4 v1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb1, boff, 0, 0));
-          f32x4 v2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb2, boff, 0, 0));
-#pragma unroll
-          for (int i = 0; i < 4; ++i) bs[i] = v1[i] + v2[i];
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            unsigned o = cok ? (unsigned)((col0 + i) * 4) : OOB;
-            bs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb1, o, 0, 0)) +
-                    __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb2, o, 0, 0));
-          }
-        }
-      }
-      constexpr int TC = TM < 4 ? TM : 4;  // m-tiles per batch of in-flight epilogue loads
-#pragma unroll
-      for (int tm0 = 0; tm0 < TM; tm0 += TC) {
-        unsigned offs[TC][VEC ? 1 : 4];
-        float rv[TC][4], av[TC][4];
-#pragma unroll
-        for (int u = 0; u < TC; ++u) {
-          const int t = t0 + wm * TM * 16 + (tm0 + u) * 16 + r;
-          const int64_t flat = (int64_t)t * p.N + col0 + p.y_shift;
-          const bool rok = cok && (t < p.Tout);
-          if constexpr (VEC) {
-            bool ok = rok && (col0 < p.N) && (flat >= 0) && (flat < p.y_limit);
-            offs[u][0] = ok ? (unsigned)(flat * ES) : OOB;
-            if (has_r) ld4(rr, offs[u][0], rv[u]);
-            if (has_a) ld4(ry, offs[u][0], av[u]);
-          } else {
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              bool ok = rok && (col0 + jj < p.N) && (flat + jj >= 0) && (flat + jj < p.y_limit);
-              offs[u][jj] = ok ? (unsigned)((flat + jj) * ES) : OOB;
-              if (has_r) rv[u][jj] = ld1(rr, offs[u][jj]);
-              if (has_a) av[u][jj] = ld1(ry, offs[u][jj]);
-            }
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < TC; ++u) {
-          float o[4];
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            float v = acc[tm0 + u][tn][jj] + bs[jj];
-            if (p.act == 1) v = gelu_new(v);
-            v = (v + (has_r ? rv[u][jj] : 0.f)) * p.scale + (has_a ? av[u][jj] : 0.f);
-            o[jj] = v;
-          }
-          if constexpr (VEC) st4(offs[u][0], o);
-          else {
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) st1(offs[u][jj], o[jj]);
-          }
-        }
-      }
-    }
-  };
-  const bool vec = ((p.N | p.y_shift | p.y_limit) & 3) == 0;
-  if (p.y_f32) {
-    if (vec) epilogue(float{}, std::true_type{}); else epilogue(float{}, std::false_type{});
-  } else {
-    if (vec) epilogue(T{}, std::true_type{}); else epilogue(T{}, std::false_type{});
-  }
+  conv_epilogue<T, TM, TN>(p, acc, b, t0 + wm * TM * 16, nt0, g, r);
 }
 
 template <typename T, int WM, int WN, int TM, int TN, int CK, int HALO>
@@ -346,11 +357,178 @@ static int launch_conv(const ConvParams& p, hipStream_t s) {
   return check_launch("itts_gemm_conv");
 }
 
+// -------------------------------------------------------------------------------------------------------------------
+// Plain GEMM (taps == 1): software-pipelined so that no wait in the k-loop ever drains the memory queue.
+//   * activations: chunk c+2 is in flight global -> registers, chunk c+1 is written to the OTHER LDS buffer while chunk c
+//     is multiplied out of this one: one barrier per chunk, two chunks (~2 x 1024 MFMA cycles per wave) of latency cover;
+//   * weights: ring of 4 fragment sets with STATIC indices (the chunk body is fully unrolled over its 4 k-steps), filled 3
+//     steps ahead; the ring slot of step s of the next chunk is refilled right after step s of this chunk has issued.
+//   vmcnt is an in-order counter, so the issue order is what makes every wait a counted one: B(c,3) -> A(c+2) ->
+//   B(c+1,0..2); the waits inside chunk c are all on loads older than A(c+2).
+// One 8-wave workgroup per CU (two 128-register accumulator/operand sets per SIMD would not fit twice).
+// -------------------------------------------------------------------------------------------------------------------
+template <typename T, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_plain_kernel(ConvParams p) {
+  typedef Elem<T> EL;
+  typedef typename EL::frag frag;
+  constexpr int E = EL::E, KS = EL::KS, CK = 4;
+  constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
+  constexpr int SEGS = CK * 4, ROWB = CK * 64 + 16, NTH = WM * WN * 64;
+  constexpr int MAXST = (BM * SEGS + NTH - 1) / NTH;
+  constexpr int BUFB = BM * ROWB;
+  static_assert(WM * WN == 8 || WM * WN == 4, "4 or 8 waves per workgroup");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, r = lane & 15;
+  const int wm = wave / WN, wn = wave % WN;
+  int mblk, nblk, b;
+  tile_of_workgroup(p, mblk, nblk, b);
+  const int t0 = mblk * BM;
+  const int nt0 = nblk * (BN / 16) + wn * TN;
+  const int NC = (p.KT + CK - 1) / CK;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>((const T*)p.x + (int64_t)b * p.x_bstride), 0, (int)((int64_t)p.Tin * p.Cin * (int)sizeof(T)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.wp), 0, (int)((int64_t)p.NT * p.KT * 1024), 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-thread staging slots: row / segment are chunk-independent
+  unsigned st_goff[MAXST];   // byte offset of (row, seg) within chunk 0, or OOB
+  int st_lds[MAXST];
+  int st_col[MAXST];
+#pragma unroll
+  for (int q = 0; q < MAXST; ++q) {
+    int idx = tid + q * NTH;
+    int i = idx / SEGS, seg = idx - i * SEGS;
+    int tin = t0 + p.off0 + i;
+    bool ok = (i < BM) && (tin >= 0) && (tin < p.Tin);
+    st_col[q] = seg * E;
+    st_goff[q] = ok ? (unsigned)((tin * p.Cin + seg * E) * (int)sizeof(T)) : OOB;
+    st_lds[q] = (i < BM) ? i * ROWB + seg * 16 : -1;
+  }
+  frag stg[MAXST];
+  auto prefetch_a = [&](int c) {
+#pragma unroll
+    for (int q = 0; q < MAXST; ++q) {
+      bool ok = (st_goff[q] != OOB) && (c * (CK * KS) + st_col[q] < p.Cin);
+      unsigned off = ok ? st_goff[q] + (unsigned)(c * (CK * KS) * (int)sizeof(T)) : OOB;
+      stg[q] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+    }
+  };
+  auto commit_a = [&](unsigned char* buf) {
+#pragma unroll
+    for (int q = 0; q < MAXST; ++q)
+      if (st_lds[q] >= 0) st16(buf + st_lds[q], stg[q]);
+  };
+  // weight block of (n-tile nt, flat k-step ks) = nt*KT + ks
+  unsigned wbase[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) wbase[tn] = (nt0 + tn) < p.NT ? (unsigned)((((nt0 + tn) * p.KT) * 64 + lane) * 16) : OOB;
+  auto fetch_b = [&](frag (&bf)[TN], int ks) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      unsigned off = (wbase[tn] != OOB && ks < p.KT) ? wbase[tn] + (unsigned)ks * 1024u : OOB;
+      bf[tn] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0));
+    }
+  };
+  const int a_off = (wm * TM * 16 + r) * ROWB + g * 16;
+  auto load_a = [&](frag (&af)[TM], const unsigned char* buf, int kk) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) af[tm] = ld16<frag>(buf + a_off + tm * 16 * ROWB + kk * 64);
+  };
+  auto mma_all = [&](frag (&af)[TM], frag (&bf)[TN]) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = EL::mma(bf[tn], af[tm], acc[tm][tn]);  // weights as A: transposed tile
+  };
+
+  frag bq0[TN], bq1[TN], bq2[TN], bq3[TN];
+  frag a0[TM], a1[TM];
+  // prologue: chunk 0 into LDS buffer 0, chunk 1 in flight, weight steps 0..2 in flight
+  prefetch_a(0);
+  fetch_b(bq0, 0);
+  fetch_b(bq1, 1);
+  fetch_b(bq2, 2);
+  commit_a(lds);
+  prefetch_a(1);
+  __syncthreads();
+  for (int c = 0; c < NC; ++c) {
+    unsigned char* cur = lds + (c & 1) * BUFB;
+    unsigned char* nxt = lds + ((c + 1) & 1) * BUFB;
+    const int ks0 = c * CK;
+    fetch_b(bq3, ks0 + 3);
+    load_a(a0, cur, 0);
+    commit_a(nxt);              // chunk c+1 (requested one chunk ago) -> the buffer everyone left at the last barrier
+    prefetch_a(c + 2);
+    __builtin_amdgcn_sched_barrier(0);  // keep the long-latency requests at the top of the chunk
+    load_a(a1, cur, 1);
+    mma_all(a0, bq0);
+    fetch_b(bq0, ks0 + 4);
+    load_a(a0, cur, 2);
+    mma_all(a1, bq1);
+    fetch_b(bq1, ks0 + 5);
+    load_a(a1, cur, 3);
+    mma_all(a0, bq2);
+    fetch_b(bq2, ks0 + 6);
+    mma_all(a1, bq3);
+    __syncthreads();            // nxt complete for everyone; everyone done reading cur
+  }
+  conv_epilogue<T, TM, TN>(p, acc, b, t0 + wm * TM * 16, nt0, g, r);
+}
+
+template <typename T, int WM, int WN, int TM, int TN>
+static int launch_plain(const ConvParams& p, hipStream_t s) {
+  constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
+  size_t ldsb = (size_t)2 * BM * (4 * 64 + 16);
+  ConvParams q = p;
+  q.MB = (p.Tout + BM - 1) / BM;
+  q.NB = (p.N + BN - 1) / BN;
+  const int64_t wbytes = (int64_t)BN * p.KT * 64;
+  int gn = (int)((2 << 20) / (wbytes > 0 ? wbytes : 1));
+  gn = gn < 1 ? 1 : (gn > 8 ? 8 : gn);
+  int gm = 32 / gn;
+  gm = gm >= 32 ? 32 : (gm >= 16 ? 16 : (gm >= 8 ? 8 : 4));
+  q.GM = gm;
+  const int64_t total = (int64_t)q.MB * q.NB * p.B;
+  if (total > 0x7fffffff) {
+    set_error("itts_gemm_conv: too many tiles (%lld)", (long long)total);
+    return ITTS_ERR_INVALID;
+  }
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_plain_kernel<T, WM, WN, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemm_plain_kernel<T, WM, WN, TM, TN>), dim3((unsigned)total), dim3(WM * WN * 64), ldsb, s, q);
+  return check_launch("itts_gemm_conv");
+}
+
+int g_conv_cfg = 0;  // itts_debug_set(3, id): plain-GEMM kernel override for A/B measurements (0 = default)
+
 template <typename T>
 static int dispatch_conv(const ConvParams& p, hipStream_t s) {
   const bool plain = (p.taps == 1);  // GEMM: no halo, 4 k-steps per chunk
-  if (p.N % 128 == 0) return plain ? launch_conv<T, 2, 4, 8, 2, 4, 0>(p, s) : launch_conv<T, 2, 4, 8, 2, 2, CV_MAX_HALO>(p, s);
-  if (p.N % 64 == 0) return plain ? launch_conv<T, 4, 2, 4, 2, 4, 0>(p, s) : launch_conv<T, 4, 2, 4, 2, 2, CV_MAX_HALO>(p, s);
+  if (plain && p.N % 128 == 0) {
+    // Measured on MI355X (bf16, M = 3008 / 7488, N = 1280..5120, K = 1280 / 5120): 128 x 128 pipelined 435-720 TFLOP/s,
+    // 256 x 128 pipelined 300-625, the unpipelined 256 x 128 tile of the convolution kernel 260-540.
+    if (g_conv_cfg == 5) return launch_plain<T, 2, 4, 8, 2>(p, s);   // 256 x 128
+    if (g_conv_cfg == 1) return launch_conv<T, 2, 4, 8, 2, 4, 0>(p, s);
+    return launch_plain<T, 2, 4, 4, 2>(p, s);                        // 128 x 128, two workgroups per CU
+  }
+  if (plain && p.N % 64 == 0) {
+    const int64_t rows = (int64_t)p.B * ((p.Tout + 255) / 256);
+    return (rows * (p.N / 64) >= 448) ? launch_conv<T, 4, 2, 4, 2, 4, 0>(p, s) : launch_conv<T, 4, 2, 2, 2, 4, 0>(p, s);
+  }
+  if (p.N % 128 == 0) return launch_conv<T, 2, 4, 8, 2, 2, CV_MAX_HALO>(p, s);
+  if (p.N % 64 == 0) return launch_conv<T, 4, 2, 4, 2, 2, CV_MAX_HALO>(p, s);
   if (p.N % 96 == 0) return launch_conv<T, 4, 2, 4, 3, 2, CV_MAX_HALO>(p, s);
   if (p.N % 48 == 0) return launch_conv<T, 4, 1, 4, 3, 2, CV_MAX_HALO>(p, s);
   return launch_conv<T, 4, 1, 4, 2, 2, CV_MAX_HALO>(p, s);

@@ -42,6 +42,13 @@ def bench(name, dtype, B, T, Cin, N, taps, dil, y_f32=False, resid=False, act=0)
 
 
 bf, fh = torch.bfloat16, torch.float16
+if os.environ.get("ITTS_CONV_CFG"):
+    nat.lib().itts_debug_set(3, int(os.environ["ITTS_CONV_CFG"]))
+    print("plain-GEMM tile cfg", os.environ["ITTS_CONV_CFG"])
+bench("prefill QKV  3008x3840x1280", bf, 1, 3008, 1280, 3840, 1, 1)
+bench("prefill proj 3008x1280x1280 +res", bf, 1, 3008, 1280, 1280, 1, 1, y_f32=True, resid=True)
+bench("prefill FC   3008x5120x1280 gelu", bf, 1, 3008, 1280, 5120, 1, 1, act=1)
+bench("prefill FC2  3008x1280x5120 +res", bf, 1, 3008, 5120, 1280, 1, 1, y_f32=True, resid=True)
 bench("latent QKV  7488x3840x1280", bf, 1, 7488, 1280, 3840, 1, 1)
 bench("latent proj 7488x1280x1280 +res", bf, 1, 7488, 1280, 1280, 1, 1, y_f32=True, resid=True)
 bench("latent FC   7488x5120x1280 gelu", bf, 1, 7488, 1280, 5120, 1, 1, act=1)
