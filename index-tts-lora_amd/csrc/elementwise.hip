@@ -20,7 +20,10 @@ struct Fir24 {
 // rows are staged in LDS as fp32, so every input element is read from HBM once (the CUDA original re-reads a 44-element
 // window per thread from global memory).
 // -------------------------------------------------------------------------------------------------------------------
-constexpr int AA_TT = 32;
+constexpr int AA_R = 4;     // consecutive rows per thread (register blocking along time)
+// Output rows per workgroup, by channel-slice width: the largest tile whose two compute phases (ceil((TT+6)/R) pair groups
+// and TT/R output groups, times CS/4 channel quads) each fit one pass of the 256 threads.
+template <int CS> struct AaTile { static constexpr int TT = CS == 64 ? 56 : CS == 48 ? 76 : CS == 32 ? 120 : 160; };
 
 // sin for the periodic term: exact library sinf in fp32 (parity) mode, hardware v_sin_f32 for 16-bit storage types
 template <typename T>
@@ -29,21 +32,26 @@ __device__ __forceinline__ float aa_sin(float x) {
   else return __sinf(x);
 }
 
-// Work is vectorised over 4 adjacent channels everywhere (16-byte LDS accesses, 8/16-byte global accesses):
-//   x tile  rows  t0-6 .. t0+TT+5        (XR = TT+12, replicate-clamped at load)
-//   s tile  rows  m = 2*t0-6 .. 2*t0+2*TT+5  (SR = 2*TT+12), row pair (2i, 2i+1) from x rows i .. i+6
+// Work is vectorised over 4 adjacent channels everywhere (8/16-byte LDS and global accesses) and register-blocked over
+// AA_R consecutive rows, so that a thread re-uses the FIR windows it has read (the un-blocked form was LDS-bandwidth
+// bound: 19 16-byte LDS reads per 4 outputs against 7 here):
+//   x tile  rows  t0-6 .. t0+TT+5            (XR = TT+12, replicate-clamped at load, kept in the storage type T)
+//   s tile  rows  m = 2*t0-6 .. 2*t0+2*TT+5  (SR = 2*TT+12, fp32), row pair (2i, 2i+1) from x rows i .. i+6
 //   y[t0+tt] = sum_j down[j] * s_tile[2*tt + 1 + j]
 template <typename T, int CS>
 __global__ __launch_bounds__(256) void aa_snake_btc_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                             const float* __restrict__ alpha_log,
                                                             const float* __restrict__ beta_log, Fir24 f, int T_len, int C) {
-  constexpr int XR = AA_TT + 12, SR = 2 * AA_TT + 12, NQ = AA_TT + 6, C4 = CS / 4;
-  __shared__ __attribute__((aligned(16))) float xs[XR * CS];
+  constexpr int TT = AaTile<CS>::TT, R = AA_R;
+  constexpr int SR = 2 * TT + 12, NQ = TT + 6, C4 = CS / 4;
+  constexpr int QG = (NQ + R - 1) / R;       // pair groups (the last one may be partial)
+  constexpr int XRP = QG * R + 6;            // x rows the pair groups may touch (>= XR; the excess is never used)
+  typedef T t4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) T xs[XRP * CS];
   __shared__ __attribute__((aligned(16))) float ss[SR * CS];
   __shared__ __attribute__((aligned(16))) float ca[CS];
   __shared__ __attribute__((aligned(16))) float cb[CS];
-  typedef T t4 __attribute__((ext_vector_type(4)));
-  const int t0 = blockIdx.x * AA_TT;
+  const int t0 = blockIdx.x * TT;
   const int c0 = blockIdx.y * CS;
   const int b = blockIdx.z;
   const int tid = threadIdx.x;
@@ -54,45 +62,65 @@ __global__ __launch_bounds__(256) void aa_snake_btc_kernel(const T* __restrict__
     ca[tid] = expf(alpha_log[c0 + tid]);
     cb[tid] = 1.0f / (expf(beta_log[c0 + tid]) + 1e-9f);
   }
-  // phase 1: x tile
-  for (int idx = tid; idx < XR * C4; idx += 256) {
-    int i = idx / C4, c4 = idx - i * C4;
-    int row = min(max(t0 - 6 + i, 0), T_len - 1);
-    t4 v = *reinterpret_cast<const t4*>(xb + (int64_t)row * C + c4 * 4);
-    f32x4 o = {Elem<T>::to_f(v[0]), Elem<T>::to_f(v[1]), Elem<T>::to_f(v[2]), Elem<T>::to_f(v[3])};
-    *reinterpret_cast<f32x4*>(&xs[i * CS + c4 * 4]) = o;
+  // phase 1: x tile (rows past TT+12 only pad the last pair group; they are clamped like the rest and never contribute).
+  // All of a thread's loads are issued before the first LDS write: one HBM round trip per workgroup, not one per pass.
+  {
+    constexpr int NLD = (XRP * C4 + 255) / 256;
+    t4 v[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+      int idx = min(tid + q * 256, XRP * C4 - 1);
+      int i = idx / C4, c4 = idx - i * C4;
+      int row = min(max(t0 - 6 + i, 0), T_len - 1);
+      v[q] = *reinterpret_cast<const t4*>(xb + (int64_t)row * C + c4 * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+      int idx = tid + q * 256;
+      int i = idx / C4, c4 = idx - i * C4;
+      if (idx < XRP * C4) *reinterpret_cast<t4*>(&xs[i * CS + c4 * 4]) = v[q];
+    }
   }
   __syncthreads();
-  // phase 2: upsample (polyphase, gain 2) + SnakeBeta -> s tile
-  for (int idx = tid; idx < NQ * C4; idx += 256) {
-    int i = idx / C4, c4 = idx - i * C4;
-    f32x4 xv[7];
+  // phase 2: upsample (polyphase, gain 2) + SnakeBeta -> s tile; R pairs per thread from R+6 x rows
+  for (int idx = tid; idx < QG * C4; idx += 256) {
+    int qg = idx / C4, c4 = idx - qg * C4;
+    const int i0 = qg * R;
+    f32x4 xv[R + 6];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) xv[k] = *reinterpret_cast<const f32x4*>(&xs[(i + k) * CS + c4 * 4]);
-    f32x4 ue = {0.f, 0.f, 0.f, 0.f}, uo = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < R + 6; ++k) {
+      t4 v = *reinterpret_cast<const t4*>(&xs[(i0 + k) * CS + c4 * 4]);
+      xv[k] = f32x4{Elem<T>::to_f(v[0]), Elem<T>::to_f(v[1]), Elem<T>::to_f(v[2]), Elem<T>::to_f(v[3])};
+    }
+    const f32x4 a = *reinterpret_cast<const f32x4*>(&ca[c4 * 4]);
+    const f32x4 ib = *reinterpret_cast<const f32x4*>(&cb[c4 * 4]);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      float we = f.up[11 - 2 * k], wo = f.up[10 - 2 * k];  // even: x[q-3+k]*up[11-2k]; odd: x[q-2+k]*up[10-2k]
+    for (int q = 0; q < R; ++q) {
+      if (i0 + q < NQ) {
+        f32x4 ue = {0.f, 0.f, 0.f, 0.f}, uo = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        ue[e] = fmaf(xv[k][e], we, ue[e]);
-        uo[e] = fmaf(xv[k + 1][e], wo, uo[e]);
+        for (int k = 0; k < 6; ++k) {
+          float we = f.up[11 - 2 * k], wo = f.up[10 - 2 * k];  // even: x[i-3+k]*up[11-2k]; odd: x[i-2+k]*up[10-2k]
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            ue[e] = fmaf(xv[q + k][e], we, ue[e]);
+            uo[e] = fmaf(xv[q + k + 1][e], wo, uo[e]);
+          }
+        }
+        f32x4 se, so;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float u = 2.0f * ue[e];
+          float sn = aa_sin<T>(u * a[e]);
+          se[e] = u + ib[e] * sn * sn;
+          u = 2.0f * uo[e];
+          sn = aa_sin<T>(u * a[e]);
+          so[e] = u + ib[e] * sn * sn;
+        }
+        *reinterpret_cast<f32x4*>(&ss[(2 * (i0 + q)) * CS + c4 * 4]) = se;
+        *reinterpret_cast<f32x4*>(&ss[(2 * (i0 + q) + 1) * CS + c4 * 4]) = so;
       }
     }
-    f32x4 a = *reinterpret_cast<const f32x4*>(&ca[c4 * 4]);
-    f32x4 ib = *reinterpret_cast<const f32x4*>(&cb[c4 * 4]);
-    f32x4 se, so;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float u = 2.0f * ue[e];
-      float sn = aa_sin<T>(u * a[e]);
-      se[e] = u + ib[e] * sn * sn;
-      u = 2.0f * uo[e];
-      sn = aa_sin<T>(u * a[e]);
-      so[e] = u + ib[e] * sn * sn;
-    }
-    *reinterpret_cast<f32x4*>(&ss[(2 * i) * CS + c4 * 4]) = se;
-    *reinterpret_cast<f32x4*>(&ss[(2 * i + 1) * CS + c4 * 4]) = so;
   }
   __syncthreads();
   // phase 2b: replicate padding of the UPSAMPLED signal at the sequence ends (block-uniform conditions)
@@ -112,20 +140,28 @@ __global__ __launch_bounds__(256) void aa_snake_btc_kernel(const T* __restrict__
     }
     __syncthreads();
   }
-  // phase 3: 12-tap low-pass, stride 2
-  for (int idx = tid; idx < AA_TT * C4; idx += 256) {
-    int tt = idx / C4, c4 = idx - tt * C4;
-    int t = t0 + tt;
-    if (t >= T_len) break;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // phase 3: 12-tap low-pass, stride 2; R outputs per thread from 2R+10 s rows
+  static_assert(TT % R == 0, "row groups tile the workgroup tile");
+  for (int idx = tid; idx < (TT / R) * C4; idx += 256) {
+    int tg = idx / C4, c4 = idx - tg * C4;
+    const int tt0 = tg * R;
+    if (t0 + tt0 >= T_len) continue;
+    f32x4 sv[2 * R + 10];
 #pragma unroll
-    for (int j = 0; j < 12; ++j) {
-      f32x4 sv = *reinterpret_cast<const f32x4*>(&ss[(2 * tt + 1 + j) * CS + c4 * 4]);
+    for (int j = 0; j < 2 * R + 10; ++j) sv[j] = *reinterpret_cast<const f32x4*>(&ss[(2 * tt0 + 1 + j) * CS + c4 * 4]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] = fmaf(f.down[j], sv[e], acc[e]);
+    for (int q = 0; q < R; ++q) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 12; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(f.down[j], sv[2 * q + j][e], acc[e]);
+      const int t = t0 + tt0 + q;
+      if (t < T_len) {
+        t4 o = {Elem<T>::from_f(acc[0]), Elem<T>::from_f(acc[1]), Elem<T>::from_f(acc[2]), Elem<T>::from_f(acc[3])};
+        *reinterpret_cast<t4*>(yb + (int64_t)t * C + c4 * 4) = o;
+      }
     }
-    t4 o = {Elem<T>::from_f(acc[0]), Elem<T>::from_f(acc[1]), Elem<T>::from_f(acc[2]), Elem<T>::from_f(acc[3])};
-    *reinterpret_cast<t4*>(yb + (int64_t)t * C + c4 * 4) = o;
   }
 }
 
@@ -361,12 +397,84 @@ __global__ __launch_bounds__(64) void ln_reduce_kernel(float* __restrict__ h, co
   }
 }
 
+// One float4 per thread, D/4 threads (D/256 waves) per row: a fifth of the per-lane load queue of the one-wave-per-row
+// form for D = 1280; the two row statistics cross the waves through LDS.
+template <typename T, int NSLAB, bool LN2>
+__global__ __launch_bounds__(1024) void ln_reduce_wide_kernel(float* __restrict__ h, const float* __restrict__ slab,
+                                                              const float* __restrict__ bias, const float* __restrict__ w,
+                                                              const float* __restrict__ b, const float* __restrict__ w2,
+                                                              const float* __restrict__ b2, T* __restrict__ y, int M, int D) {
+  __shared__ float red[2][2][16];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  float* hr = h + (int64_t)row * D;
+  f32x4 v = ld16<f32x4>(hr + tid * 4);
+  const f32x4 lw = ld16<f32x4>(w + tid * 4), lb = ld16<f32x4>(b + tid * 4);
+  f32x4 lw2 = {0.f, 0.f, 0.f, 0.f}, lb2 = lw2;
+  if constexpr (LN2) {
+    lw2 = ld16<f32x4>(w2 + tid * 4);
+    lb2 = ld16<f32x4>(b2 + tid * 4);
+  }
+  if constexpr (NSLAB > 0) {
+    f32x4 sl[NSLAB];
+    f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) bs = ld16<f32x4>(bias + tid * 4);
+#pragma unroll
+    for (int sidx = 0; sidx < NSLAB; ++sidx) sl[sidx] = ld16<f32x4>(slab + ((int64_t)sidx * M + row) * D + tid * 4);
+    v += bs;
+#pragma unroll
+    for (int sidx = 0; sidx < NSLAB; ++sidx) v += sl[sidx];  // same association order as the one-wave form
+    st16(hr + tid * 4, v);
+  }
+#pragma unroll
+  for (int pass = 0; pass < (LN2 ? 2 : 1); ++pass) {
+    float s = wave_sum(v[0] + v[1] + v[2] + v[3]);
+    if (lane == 0) red[pass][0][wave] = s;
+    __syncthreads();
+    float tot = 0.f;
+    for (int i = 0; i < nw; ++i) tot += red[pass][0][i];
+    const float mean = tot / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float d = v[e] - mean;
+      q = fmaf(d, d, q);
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[pass][1][wave] = q;
+    __syncthreads();
+    float qt = 0.f;
+    for (int i = 0; i < nw; ++i) qt += red[pass][1][i];
+    const float rstd = rsqrtf(qt / (float)D + 1e-5f);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float ww = pass == 0 ? lw[e] : lw2[e];
+      float bb = pass == 0 ? lb[e] : lb2[e];
+      v[e] = (v[e] - mean) * rstd * ww + bb;
+    }
+  }
+  T* yr = y + (int64_t)row * D;
+  if constexpr (sizeof(T) == 4) {
+    st16(yr + tid * 4, v);
+  } else {
+    typedef T t4 __attribute__((ext_vector_type(4)));
+    t4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f(v[e]);
+    *reinterpret_cast<t4*>(yr + tid * 4) = o;
+  }
+}
+
 template <typename T, int NV>
 static int launch_ln_reduce(float* h, const float* slab, int nslab, const float* bias, const float* w, const float* b,
                             const float* w2, const float* b2, T* y, int M, int D, hipStream_t s) {
-  dim3 grid(M), block(64);
+  const bool wide = (D % 256 == 0) && D <= 4096;
+  dim3 grid(M), block(wide ? D / 4 : 64);
   const bool two = w2 != nullptr;
-#define ITTS_LNR(NS, L2) hipLaunchKernelGGL((ln_reduce_kernel<T, NV, NS, L2>), grid, block, 0, s, h, slab, bias, w, b, w2, b2, y, M, D)
+#define ITTS_LNR(NS, L2)                                                                                                   \
+  do {                                                                                                                     \
+    if (wide) hipLaunchKernelGGL((ln_reduce_wide_kernel<T, NS, L2>), grid, block, 0, s, h, slab, bias, w, b, w2, b2, y, M, D); \
+    else hipLaunchKernelGGL((ln_reduce_kernel<T, NV, NS, L2>), grid, block, 0, s, h, slab, bias, w, b, w2, b2, y, M, D);     \
+  } while (0)
   if (nslab == 0) {
     if (two) ITTS_LNR(0, true); else ITTS_LNR(0, false);
   } else if (nslab == 4) {
@@ -466,7 +574,8 @@ extern "C" int itts_aa_snake_fwd(const void* x, void* y, const float* alpha_log,
     ITTS_REQUIRE(C % 4 == 0, "itts_aa_snake_fwd: C=%d must be a multiple of 4", C);
     int CS = (C % 64 == 0) ? 64 : (C % 48 == 0) ? 48 : (C % 32 == 0) ? 32 : (C % 24 == 0) ? 24 : 0;
     ITTS_REQUIRE(CS != 0, "itts_aa_snake_fwd: unsupported channel count %d (need a multiple of 24 or 32)", C);
-    dim3 grid((T + AA_TT - 1) / AA_TT, C / CS, B), block(256);
+    const int tt = CS == 64 ? AaTile<64>::TT : CS == 48 ? AaTile<48>::TT : CS == 32 ? AaTile<32>::TT : AaTile<24>::TT;
+    dim3 grid((T + tt - 1) / tt, C / CS, B), block(256);
     ITTS_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "itts_aa_snake_fwd: grid too large");
 #define ITTS_AA_LAUNCH(TT_, CS_) \
   hipLaunchKernelGGL((aa_snake_btc_kernel<TT_, CS_>), grid, block, 0, s, (const TT_*)x, (TT_*)y, alpha_log, beta_log, f, T, C)
