@@ -330,23 +330,40 @@ class IndexTTS:
 
     def _latents(self, conds, text_rows: List[torch.Tensor], code_rows: List[torch.Tensor]):
         """Teacher-forced pass for several utterances at once (right-padded; causal attention makes padding inert).
-        Each row reproduces gpt(cond, text, [L], codes, code_len*1024, return_latent=True) of infer.py:864-874."""
+        Each row reproduces gpt(cond, text, [L], codes, code_len*1024, return_latent=True) of infer.py:864-874.
+        The [cond | text | mel] embedding batch is assembled with two gathers from index arrays built on the host (one
+        upload) instead of a dozen small launches per utterance."""
         g, eng, dev = self.gpt, self.gpt.engine, self.device
-        embs, spans = [], []
-        for t, c in zip(text_rows, code_rows):
-            t = t.reshape(-1).long().to(dev)
-            c = c.reshape(-1).long().to(dev)
-            ti = torch.cat([torch.tensor([g.start_text_token], device=dev), t, torch.tensor([g.stop_text_token], device=dev)])
-            mi = torch.cat([torch.tensor([g.start_mel_token], device=dev), c, torch.tensor([g.stop_mel_token], device=dev)])
-            te = eng.text_emb[ti] + eng.text_pos[: ti.numel()]
-            me = eng.mel_emb[mi] + eng.mel_pos[: mi.numel()]
-            e = torch.cat([conds[0].to(dev, torch.float32), te, me], dim=0)
-            embs.append(e)
-            spans.append((conds.shape[1] + ti.numel(), c.numel()))
-        S = max(e.shape[0] for e in embs)
-        batch = torch.zeros(len(embs), S, embs[0].shape[1], dtype=torch.float32, device=dev)
-        for i, e in enumerate(embs):
-            batch[i, : e.shape[0]] = e
+
+        def flat_host(rows):
+            flat = torch.cat([r.reshape(-1).long() for r in rows]) if rows else torch.zeros(0, dtype=torch.long)
+            return flat.cpu().numpy()
+
+        tl = [int(t.numel()) for t in text_rows]
+        cl = [int(c.numel()) for c in code_rows]
+        tflat, cflat = flat_host(text_rows), flat_host(code_rows)
+        nc = int(conds.shape[1])
+        S = max(nc + t + 2 + c + 2 for t, c in zip(tl, cl))
+        ri, ci, tok, pos, spans = ([], []), ([], []), ([], []), ([], []), []
+        to = co = 0
+        for i, (t, c) in enumerate(zip(tl, cl)):
+            ti = np.concatenate([[g.start_text_token], tflat[to: to + t], [g.stop_text_token]])
+            mi = np.concatenate([[g.start_mel_token], cflat[co: co + c], [g.stop_mel_token]])
+            to, co = to + t, co + c
+            for k, (ids, c0) in enumerate(((ti, nc), (mi, nc + ti.size))):
+                ri[k].append(np.full(ids.size, i))
+                ci[k].append(c0 + np.arange(ids.size))
+                tok[k].append(ids)
+                pos[k].append(np.arange(ids.size))
+            spans.append((nc + ti.size, c))
+        n_t = sum(a.size for a in tok[0])
+        packed = np.stack([np.concatenate(ri[0] + ri[1]), np.concatenate(ci[0] + ci[1]), np.concatenate(tok[0] + tok[1]),
+                           np.concatenate(pos[0] + pos[1])]).astype(np.int64)
+        idx = torch.from_numpy(packed).to(dev)
+        batch = torch.zeros(len(tl), S, conds.shape[2], dtype=torch.float32, device=dev)
+        batch[:, :nc] = conds[0].to(dev, torch.float32)
+        batch[idx[0, :n_t], idx[1, :n_t]] = eng.text_emb[idx[2, :n_t]] + eng.text_pos[idx[3, :n_t]]
+        batch[idx[0, n_t:], idx[1, n_t:]] = eng.mel_emb[idx[2, n_t:]] + eng.mel_pos[idx[3, n_t:]]
         enc = eng.latent(batch)
         return [enc[i, s0: s0 + n] for i, (s0, n) in enumerate(spans)]
 
@@ -499,9 +516,12 @@ class IndexTTS:
         conds, spk = self._prompt_features(cond_mel)
         L = max(int(t.numel()) for t in text_token_rows)
         stop = self.cfg.gpt.stop_text_token
-        batch = torch.full((len(text_token_rows), L), stop, dtype=torch.int32, device=self.device)
+        batch_h = torch.full((len(text_token_rows), L), stop, dtype=torch.int32)
+        if text_token_rows and text_token_rows[0].is_cuda:
+            text_token_rows = [t.cpu() for t in text_token_rows]
         for i, t in enumerate(text_token_rows):
-            batch[i, : t.numel()] = t.reshape(-1).to(self.device, torch.int32)
+            batch_h[i, : t.numel()] = t.reshape(-1).to(torch.int32)
+        batch = batch_h.to(self.device)   # one upload for the whole batch
         g = self.gpt
         _, emb, mask = g.prepare_gpt_inputs(conds, batch)
         pad = (mask == 0).sum(dim=1).to(torch.int32)
@@ -515,7 +535,8 @@ class IndexTTS:
         codes = g.engine.decode(max_mel_tokens, sp, force_stop=force_stop)
         self._mark(phase_events, "decoded")
         codes_c, lens = self.remove_long_silence(codes)
-        rows = [codes_c[i, : int(lens[i])] for i in range(codes_c.shape[0])]
+        codes_h, lens_h = codes_c.cpu(), lens.tolist()   # host copies: one transfer each instead of a sync per row
+        rows = [codes_h[i, : lens_h[i]] for i in range(codes_h.shape[0])]
         return dict(conds=conds, spk=spk, rows=rows, texts=[t.reshape(-1) for t in text_token_rows])
 
     def _batch_waveforms(self, st, phase_events=None):
