@@ -345,8 +345,16 @@ def main():
         torch.cuda.synchronize()
         us_launch = 1e3 * e0.elapsed_time(e1) / (reps * n_l)
         ach = (by_l / n_l) / (us_launch * 1e-6) / 1e9
+        # HBM traffic per launch: rocprofv3 PMC passes cannot run inside this process; the committed summary of the
+        # separate FETCH_SIZE / WRITE_SIZE passes over exactly these launches (tools/pmc_decode_gemm.py) is reported.
+        traffic, traffic_src = None, None
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_gemm_skinny.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
+            traffic_src = "profiles/r01_pmc_gemm_skinny.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 read correction)"
         roof = {"kernel": "gemm_skinny_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "launches_per_decode_step": n_l,
+                "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "launches_per_decode_step": n_l,
                 "avg_launch_us": round(us_launch, 2), "algorithmic_MB_per_launch": round(by_l / n_l / 1e6, 3),
                 "how": "graph replay of one decode step's GEMM launches, 50 replays between one HIP event pair"}
         if "gemm_conv" in agg:
