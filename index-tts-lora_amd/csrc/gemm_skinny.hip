@@ -36,8 +36,10 @@ struct SkinnyParams {
 // slice, the slices are merged across the waves with Chan's parallel-variance formula through LDS (one barrier), and the
 // normalised values are rounded to T only then -- same numerics as LayerNorm in fp32 followed by a T-typed matmul.
 // Requires ksplit == 1 and the wave's whole K slice in one register chunk.
-template <typename T, int MT, int SPW, int NTB, bool LNF>
-__global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
+// MAXT = threads per workgroup the register budget is sized for (512: up to 8 waves; 1024: up to 16 waves, which halves
+// the loads queued per lane at the price of a 128-register cap).
+template <typename T, int MT, int SPW, int NTB, bool LNF, int MAXT = 512>
+__global__ __launch_bounds__(MAXT) void gemm_skinny_kernel(SkinnyParams p) {
   typedef Elem<T> EL;
   typedef typename EL::frag frag;
   constexpr int E = EL::E, KS = EL::KS;
@@ -245,11 +247,14 @@ static int launch_skinny(const SkinnyParams& p, hipStream_t s) {
   constexpr int KS = Elem<T>::KS;
   const int KT = p.K / KS;
   const int SB = (KT + p.ksplit - 1) / p.ksplit;
-  // waves per workgroup: ~5 k-steps per wave, at most 8 waves; more than 5 steps per wave -> 10-step register chunks
-  int NW = (SB + 4) / 5;
+  // waves per workgroup: 8 whenever the slice has 8 k-steps (measured: the split-K 3 out-projection, 14 k-steps, takes
+  // 3.8 us with 8 waves x 2 steps against 4.4 us with 3 waves x 5; 10-16 waves change nothing for any of the four GEMMs);
+  // more than 5 steps per wave -> 10-step register chunks
+  int NW = SB;
   if (NW > 8) NW = 8;
   if (NW < 1) NW = 1;
-  if (g_tune_nw > 0 && !p.lnf) NW = g_tune_nw > 8 ? 8 : g_tune_nw;
+  if (g_tune_nw > 0 && !p.lnf) NW = g_tune_nw > 16 ? 16 : g_tune_nw;
+  if (NW > 8 && (SB + NW - 1) / NW > 5) NW = 8;  // the 16-wave build only exists for 5-step register chunks
   const int spw = (SB + NW - 1) / NW;
   const int NT = (p.N + 15) / 16;
   // keep the grid within one round of the 256 CUs
@@ -266,6 +271,10 @@ static int launch_skinny(const SkinnyParams& p, hipStream_t s) {
       return ITTS_ERR_INVALID;
     }
     if (ntb == 1) ITTS_SK(5, 1, true); else if (ntb == 2) ITTS_SK(5, 2, true); else ITTS_SK(5, 3, true);
+  } else if (spw <= 5 && NW > 8) {
+#define ITTS_SK16(NTB_) hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 5, NTB_, false, 1024>), grid, block, lds, s, p)
+    if (ntb == 1) ITTS_SK16(1); else if (ntb == 2) ITTS_SK16(2); else ITTS_SK16(3);
+#undef ITTS_SK16
   } else if (spw <= 5) {
     if (ntb == 1) ITTS_SK(5, 1, false); else if (ntb == 2) ITTS_SK(5, 2, false); else ITTS_SK(5, 3, false);
   } else {
