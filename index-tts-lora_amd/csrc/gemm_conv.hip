@@ -511,11 +511,126 @@ static int launch_plain(const ConvParams& p, hipStream_t s) {
   return check_launch("itts_gemm_conv");
 }
 
+// -------------------------------------------------------------------------------------------------------------------
+// Narrow convolution (Cin <= 64, N <= 64: the last two BigVGAN stages, conv_post and the last upsampler).  These layers
+// are HBM-bound (a k = 7 conv over 48 channels does 84 FLOP per byte moved), so the kernel is built around the row
+// stream, not the MFMA pipe:
+//   * the whole packed weight tensor of the layer (taps x KT x NT KiB, <= 66 KiB) is copied to LDS once per workgroup and
+//     the workgroup then walks several 64-row-per-wave tiles (persistent grid), so weights cost nothing per row;
+//   * activation fragments go straight from global memory to MFMA operand registers (a 16-row x 64-byte fragment is one
+//     16-byte load per lane; the taps' overlapping rows are served by L1), no activation staging and no barrier in the
+//     row loop; the next tap's fragments are requested before the current tap is multiplied.
+// -------------------------------------------------------------------------------------------------------------------
+template <typename T, int KT, int NT>
+__global__ __launch_bounds__(256) void conv_narrow_kernel(ConvParams p) {
+  typedef Elem<T> EL;
+  typedef typename EL::frag frag;
+  constexpr int E = EL::E, KS = EL::KS, TM = 4, BM = 4 * TM * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, r = lane & 15;
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+
+  // weights -> LDS (same block order as in memory: ((tap*NT + nt)*KT + ks) KiB)
+  const int wbytes = p.taps * NT * KT * 1024;
+  for (int off = tid * 16; off < wbytes; off += 256 * 16) st16(lds + off, ld16<frag>((const unsigned char*)p.wp + off));
+  __syncthreads();
+
+  const int ntiles = p.MB * p.B;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / p.MB, mblk = tile - b * p.MB;
+    const int row0 = mblk * BM + wave * (TM * 16);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>((const T*)p.x + (int64_t)b * p.x_bstride), 0, (int)((int64_t)p.Tin * p.Cin * (int)sizeof(T)), 0x00020000);
+    f32x4 acc[TM][NT];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto load_a = [&](frag (&af)[TM][KT], int j) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int tin = row0 + tm * 16 + r + p.off0 + j * p.dil;
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) {
+          const int col = ks * KS + g * E;
+          const bool ok = (j < p.taps) && (tin >= 0) && (tin < p.Tin) && (col < p.Cin);
+          const unsigned off = ok ? (unsigned)((tin * p.Cin + col) * (int)sizeof(T)) : OOB;
+          af[tm][ks] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+        }
+      }
+    };
+    auto mma_tap = [&](frag (&af)[TM][KT], int j) {
+      const unsigned char* wb = lds + (size_t)j * NT * KT * 1024 + lane * 16;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) {
+          const frag bf = ld16<frag>(wb + (nt * KT + ks) * 1024);
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) acc[tm][nt] = EL::mma(bf, af[tm][ks], acc[tm][nt]);  // weights as A: transposed tile
+        }
+    };
+    frag a0[TM][KT], a1[TM][KT];
+    load_a(a0, 0);
+    for (int j = 0; j < p.taps; j += 2) {
+      load_a(a1, j + 1);            // past the last tap: out-of-range offsets, no memory traffic
+      mma_tap(a0, j);
+      load_a(a0, j + 2);
+      if (j + 1 < p.taps) mma_tap(a1, j + 1);
+    }
+    conv_epilogue<T, TM, NT>(p, acc, b, row0, 0, g, r);
+  }
+}
+
+template <typename T, int KT, int NT>
+static int launch_narrow(const ConvParams& p, hipStream_t s) {
+  constexpr int BM = 256;
+  ConvParams q = p;
+  q.MB = (p.Tout + BM - 1) / BM;
+  q.NB = 1;
+  q.GM = 1;
+  const int64_t tiles = (int64_t)q.MB * p.B;
+  const size_t ldsb = (size_t)p.taps * NT * KT * 1024;
+  // persistent grid: as many workgroups as stay resident (LDS- and register-bound), each walking tiles with stride grid
+  int per_cu = (int)((160 * 1024) / (ldsb > 0 ? ldsb : 1));
+  per_cu = per_cu < 1 ? 1 : (per_cu > 6 ? 6 : per_cu);
+  int64_t grid = 256 * (int64_t)per_cu;
+  if (grid > tiles) grid = tiles;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_narrow_kernel<T, KT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL((conv_narrow_kernel<T, KT, NT>), dim3((unsigned)grid), dim3(256), ldsb, s, q);
+  return check_launch("itts_gemm_conv");
+}
+
+// (k-steps, column tiles) pairs built for the narrow kernel; everything else takes the tiled kernel
+template <typename T>
+static int dispatch_narrow(const ConvParams& p, hipStream_t s, bool& handled) {
+  handled = true;
+  const int kt = p.KT, nt = p.NT;
+  if (kt == 1 && nt == 1) return launch_narrow<T, 1, 1>(p, s);
+  if (kt == 1 && nt == 2) return launch_narrow<T, 1, 2>(p, s);
+  if (kt == 2 && nt == 1) return launch_narrow<T, 2, 1>(p, s);
+  if (kt == 2 && nt == 2) return launch_narrow<T, 2, 2>(p, s);
+  if (kt == 2 && nt == 3) return launch_narrow<T, 2, 3>(p, s);
+  if (kt == 3 && nt == 3) return launch_narrow<T, 3, 3>(p, s);
+  handled = false;
+  return ITTS_OK;
+}
+
 int g_conv_cfg = 0;  // itts_debug_set(3, id): plain-GEMM kernel override for A/B measurements (0 = default)
 
 template <typename T>
 static int dispatch_conv(const ConvParams& p, hipStream_t s) {
   const bool plain = (p.taps == 1);  // GEMM: no halo, 4 k-steps per chunk
+  if (p.Cin <= 64 && p.N <= 64 && g_conv_cfg != 2 && (size_t)p.taps * p.NT * p.KT * 1024 <= 150 * 1024) {
+    bool handled;
+    int rc = dispatch_narrow<T>(p, s, handled);
+    if (handled) return rc;
+  }
   if (plain && p.N % 128 == 0) {
     // Measured on MI355X (bf16, M = 3008 / 7488, N = 1280..5120, K = 1280 / 5120): 128 x 128 pipelined 435-720 TFLOP/s,
     // 256 x 128 pipelined 300-625, the unpipelined 256 x 128 tile of the convolution kernel 260-540.

@@ -179,6 +179,8 @@ CONV_CASES = [
     (1, 37, 1280, 1536, 7, 1), (2, 50, 768, 768, 3, 5), (1, 70, 384, 384, 11, 3), (2, 300, 192, 192, 7, 5),
     (1, 700, 96, 96, 11, 5), (2, 1000, 48, 48, 3, 1), (1, 1500, 24, 24, 11, 5), (2, 900, 24, 1, 7, 1),
     (1, 5, 96, 96, 3, 3),
+    # narrow persistent kernel: tile tails, several batch rows, every (k, dilation) class of the AMP blocks
+    (3, 777, 48, 48, 7, 3), (2, 1030, 48, 48, 11, 1), (3, 257, 24, 24, 3, 5), (1, 4100, 24, 24, 7, 1), (2, 3, 48, 48, 11, 5),
 ]
 
 
