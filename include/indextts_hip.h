@@ -199,6 +199,45 @@ typedef struct itts_sample_args {
 } itts_sample_args;
 int itts_sample(const itts_sample_args* a, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Beam search / beam-sample step (num_beams > 1) -- replaces, for the generate() call at indextts/gpt/model.py:710-715,
+ * transformers 4.44.2 GenerationMixin._beam_search + BeamSearchScorer.process + BeamHypotheses.add/is_done
+ * (third-party; restated in oracle/beam_ref.py).  Rows are laid out batch-major: row = b*num_beams + beam.
+ * One call = one decoding step for all batch elements: log-softmax, repetition penalty, (temperature, top-k, top-p with
+ * min_tokens_to_keep = 2 when do_sample), running beam scores, 2*num_beams candidates drawn without replacement (own
+ * Philox stream: counter (b, step, draw, 0)) or taken, scorer bookkeeping, hypothesis store, per-row token histories.
+ * state[0] = step, state[1] = cache position (both advanced by the call), state[2] = finished batch elements.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct itts_beam_args {
+  const float* logits; /* [B*num_beams][ldl] */
+  int B, num_beams, V, ldl;
+  int32_t* tokens;      /* [B*num_beams] out: token appended to each row */
+  int32_t* src;         /* [B*num_beams] out: row (absolute index) each row continues */
+  float* beam_scores;   /* [B*num_beams] in/out: running sum of log-probabilities (init 0, -1e9, -1e9, ... per batch element) */
+  int32_t* hist;        /* [2][B*num_beams][hist_cap] generated tokens, ping-pong by step parity (input = step & 1) */
+  int hist_cap;
+  float* hyp_score;     /* [B][num_beams] closed hypotheses: score, generated length, tokens */
+  int32_t* hyp_len;
+  int32_t* hyp_tok;     /* [B][num_beams][hist_cap] */
+  int32_t* n_hyp;       /* [B] */
+  float* worst;         /* [B] lowest score among the closed hypotheses (init +1e9) */
+  int32_t* done;        /* [B] */
+  int32_t* state;       /* [8] */
+  const int32_t* extra_ids; /* ids always penalised (the fake prefix: 1 and 8192) */
+  int n_extra;
+  float rep_penalty, temperature, top_p, length_penalty;
+  int top_k, do_sample;
+  uint64_t seed;
+  int eos_token;
+} itts_beam_args;
+int itts_beam_step(const itts_beam_args* a, void* stream);
+
+/* KV cache rows follow their beams (GPT2InferenceModel._reorder_cache, model.py:207-218): row r <- row src[r] for cache
+ * positions [0, state[1]), every layer, K and V; batch elements whose rows map to themselves are skipped.
+ * Cache layout [layers][rows][heads][smax][64]; layer_stride in elements. */
+int itts_beam_reorder_kv(void* kcache, void* vcache, const int32_t* src, const int32_t* state, int layers, int B, int num_beams,
+                         int heads, int smax, int64_t layer_stride, int dtype, void* stream);
+
 /* pcm[b][i] = trunc( clamp(32767 * tanh(x[b][i]), -32767, 32767) ) as int16; also writes fp32 wav if wav != NULL.
  * apply_tanh = 0 skips the tanh (input already in (-1,1)). */
 int itts_tanh_pcm(const void* x, float* wav, int16_t* pcm, int64_t n, int dtype, int apply_tanh, void* stream);

@@ -46,6 +46,16 @@ class SampleArgs(C.Structure):
                 ("do_sample", C.c_int), ("seed", C.c_uint64), ("stop_token", C.c_int), ("dbg_scores", C.c_void_p)]
 
 
+class BeamArgs(C.Structure):
+    _fields_ = [("logits", C.c_void_p), ("B", C.c_int), ("num_beams", C.c_int), ("V", C.c_int), ("ldl", C.c_int),
+                ("tokens", C.c_void_p), ("src", C.c_void_p), ("beam_scores", C.c_void_p), ("hist", C.c_void_p),
+                ("hist_cap", C.c_int), ("hyp_score", C.c_void_p), ("hyp_len", C.c_void_p), ("hyp_tok", C.c_void_p),
+                ("n_hyp", C.c_void_p), ("worst", C.c_void_p), ("done", C.c_void_p), ("state", C.c_void_p),
+                ("extra_ids", C.c_void_p), ("n_extra", C.c_int), ("rep_penalty", C.c_float), ("temperature", C.c_float),
+                ("top_p", C.c_float), ("length_penalty", C.c_float), ("top_k", C.c_int), ("do_sample", C.c_int),
+                ("seed", C.c_uint64), ("eos_token", C.c_int)]
+
+
 _SIGNATURES = {
     "itts_abi_version": (C.c_int, []),
     "itts_last_error": (C.c_char_p, []),
@@ -68,6 +78,9 @@ _SIGNATURES = {
     "itts_attn_prefill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_sample": (C.c_int, [C.POINTER(SampleArgs), C.c_void_p]),
+    "itts_beam_step": (C.c_int, [C.POINTER(BeamArgs), C.c_void_p]),
+    "itts_beam_reorder_kv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_int64, C.c_int, C.c_void_p]),
     "itts_tanh_pcm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
 }
 
@@ -237,6 +250,30 @@ def sample(logits, tokens, history, finished, state, extra_ids, force_stop, rep_
     a.top_k, a.do_sample, a.seed, a.stop_token = int(top_k), int(bool(do_sample)), int(seed), int(stop_token)
     a.dbg_scores = _p(dbg_scores)
     _check(lib().itts_sample(C.byref(a), _stream()), "itts_sample")
+
+
+def beam_step(logits, num_beams, tokens, src, beam_scores, hist, hyp_score, hyp_len, hyp_tok, n_hyp, worst, done, state,
+              extra_ids, rep_penalty, temperature, top_k, top_p, do_sample, length_penalty, seed, eos_token):
+    """logits fp32 [B*num_beams, V]; hist int32 [2, B*num_beams, cap]; see include/indextts_hip.h (itts_beam_args)."""
+    a = BeamArgs()
+    R, V = logits.shape
+    a.logits, a.B, a.num_beams, a.V, a.ldl = _p(logits), R // num_beams, int(num_beams), V, logits.stride(0)
+    a.tokens, a.src, a.beam_scores = _p(tokens), _p(src), _p(beam_scores)
+    a.hist, a.hist_cap = _p(hist), hist.shape[2]
+    a.hyp_score, a.hyp_len, a.hyp_tok, a.n_hyp, a.worst = _p(hyp_score), _p(hyp_len), _p(hyp_tok), _p(n_hyp), _p(worst)
+    a.done, a.state = _p(done), _p(state)
+    a.extra_ids, a.n_extra = _p(extra_ids), 0 if extra_ids is None else extra_ids.numel()
+    a.rep_penalty, a.temperature, a.top_p, a.length_penalty = float(rep_penalty), float(temperature), float(top_p), float(length_penalty)
+    a.top_k, a.do_sample, a.seed, a.eos_token = int(top_k), int(bool(do_sample)), int(seed), int(eos_token)
+    _check(lib().itts_beam_step(C.byref(a), _stream()), "itts_beam_step")
+
+
+def beam_reorder_kv(kc, vc, src, state, B, num_beams):
+    """kc / vc: T [L][rows][H][smax][64]; rows of each batch element are permuted in place by src."""
+    L, rows, H, smax, hd = kc.shape
+    assert hd == 64 and rows >= B * num_beams
+    _check(lib().itts_beam_reorder_kv(_p(kc), _p(vc), _p(src), _p(state), L, B, int(num_beams), H, smax, kc.stride(0),
+                                      dt(kc.dtype), _stream()), "itts_beam_reorder_kv")
 
 
 def tanh_pcm(x, wav=None, pcm=None, apply_tanh=True):

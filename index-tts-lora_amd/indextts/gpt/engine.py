@@ -304,6 +304,100 @@ class GPTEngine:
         codes = self.history[:B, :n].to(torch.int64)
         return (codes, torch.stack(logits_trace, 0)) if return_logits else codes
 
+    # ------------------------------------------------------------------------------------------------ beam search
+    def _ensure_beam(self, B: int, nb: int):
+        R, dev = B * nb, self.device
+        if getattr(self, "_beam_cap", (0, 0)) == (B, nb):
+            return
+        cap = self.history.shape[1]
+        self.b_scores = torch.zeros(R, dtype=torch.float32, device=dev)
+        self.b_src = torch.zeros(R, dtype=torch.int32, device=dev)
+        self.b_hist = torch.zeros(2, R, cap, dtype=torch.int32, device=dev)
+        self.b_hyp_score = torch.zeros(B, nb, dtype=torch.float32, device=dev)
+        self.b_hyp_len = torch.zeros(B, nb, dtype=torch.int32, device=dev)
+        self.b_hyp_tok = torch.zeros(B, nb, cap, dtype=torch.int32, device=dev)
+        self.b_n_hyp = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.b_worst = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.b_done = torch.zeros(B, dtype=torch.int32, device=dev)
+        self._beam_cap = (B, nb)
+
+    def _beam_select(self, B, nb, sp):
+        R = B * nb
+        nat.beam_step(self.logits[:R], nb, self.tokens, self.b_src, self.b_scores, self.b_hist, self.b_hyp_score, self.b_hyp_len,
+                      self.b_hyp_tok, self.b_n_hyp, self.b_worst, self.b_done, self.state, self.extra_ids,
+                      sp["repetition_penalty"], sp["temperature"], sp["top_k"], sp["top_p"], sp["do_sample"],
+                      sp.get("length_penalty", 0.0), sp["seed"], self.stop_mel)
+        nat.beam_reorder_kv(self.kc, self.vc, self.b_src, self.state, B, nb)
+
+    def _step_kernels_beam(self, B, nb, sp):
+        self._step_transformer(B * nb)
+        self._beam_select(B, nb, sp)
+
+    def decode_beam(self, max_new: int, sp: dict, num_beams: int, use_graph=True, check_every=16):
+        """Beam search / beam-sample after prefill() of B*num_beams rows (row = b*num_beams + beam, the beams of a batch
+        element start as copies).  HF 4.44.2 semantics (oracle/beam_ref.py); returns int64 [B, n] best hypotheses,
+        right-padded with the stop token."""
+        nb = int(num_beams)
+        R = self._B
+        assert R % nb == 0, "prefill() must have been given B*num_beams rows"
+        B = R // nb
+        if self._S + max_new + 1 > self._cap_s:
+            raise ValueError("decode_beam(): max_new exceeds the capacity reserved by prefill()")
+        self._ensure_beam(B, nb)
+        self.b_scores.zero_()
+        self.b_scores.view(B, nb)[:, 1:] = -1e9
+        self.b_hist.zero_()
+        self.b_n_hyp.zero_()
+        self.b_worst.fill_(1e9)
+        self.b_done.zero_()
+        self._beam_select(B, nb, sp)  # token 1 from the prefill logits
+        n = 1
+        key = ("beam", B, nb, tuple(sorted(sp.items())))
+        while n < max_new:
+            if use_graph and not self.force_eager and n >= 2:
+                g = self._graphs.get(key)
+                if g is None:
+                    g = torch.cuda.CUDAGraph()
+                    with nat.CAPTURE_LOCK, torch.cuda.graph(g):
+                        self._step_kernels_beam(B, nb, sp)
+                    self._graphs[key] = g
+                g.replay()
+            else:
+                self._step_kernels_beam(B, nb, sp)
+            n += 1
+            if n % check_every == 0 and int(self.state[2].item()) >= B:
+                break
+        return self._beam_finalize(B, nb, n, float(sp.get("length_penalty", 0.0)))
+
+    def _beam_finalize(self, B, nb, n, length_penalty):
+        """BeamSearchScorer.finalize on the host: running beams of unfinished batch elements become hypotheses (score =
+        sum_logprobs / generated_len**length_penalty), the best hypothesis of each element is returned."""
+        hs = self.b_hyp_score.cpu().numpy()
+        hl = self.b_hyp_len.cpu().numpy()
+        ht = self.b_hyp_tok.cpu().numpy()
+        nh = self.b_n_hyp.cpu().numpy()
+        done = self.b_done.cpu().numpy()
+        sc = self.b_scores.cpu().numpy().reshape(B, nb)
+        hist = self.b_hist[n & 1].cpu().numpy().reshape(B, nb, -1)
+        best = []
+        for b in range(B):
+            hyps = [(float(hs[b, i]), i, ht[b, i, : hl[b, i]].tolist()) for i in range(int(nh[b]))]
+            if not done[b]:
+                worst = min((h[0] for h in hyps), default=1e9)
+                for k in range(nb):
+                    score = float(sc[b, k]) / (float(n) ** length_penalty if length_penalty != 0.0 else 1.0)
+                    if len(hyps) < nb or score > worst:
+                        hyps.append((score, nb + k, hist[b, k, :n].tolist()))
+                        if len(hyps) > nb:
+                            hyps.remove(min(hyps, key=lambda h: (h[0], h[1])))
+                        worst = min(h[0] for h in hyps)
+            best.append(max(hyps, key=lambda h: (h[0], h[1]))[2])
+        width = max(len(t) for t in best) + 1
+        out = torch.full((B, width), self.stop_mel, dtype=torch.int64)
+        for b, t in enumerate(best):
+            out[b, : len(t)] = torch.tensor(t, dtype=torch.int64)
+        return out.to(self.device)
+
     def _get_graph(self, B, sp, nsteps=1):
         key = (B, nsteps, tuple(sorted(sp.items())))
         g = self._graphs.get(key)

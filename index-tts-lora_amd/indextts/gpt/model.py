@@ -166,10 +166,7 @@ class UnifiedVoice:
         if input_tokens is not None or typical_sampling or num_return_sequences != 1:
             raise NotImplementedError("input_tokens / typical_sampling / num_return_sequences>1 are off the infer.py path")
         num_beams = int(hf.pop("num_beams", 1))
-        hf.pop("length_penalty", None)
-        if num_beams != 1:
-            warnings.warn("beam-sample (num_beams>1) is not implemented on device yet; decoding with num_beams=1",
-                          RuntimeWarning)
+        length_penalty = float(hf.pop("length_penalty", 1.0))  # HF default 1.0; infer.py passes 0.0
         sp = dict(do_sample=bool(hf.pop("do_sample", False)), top_p=float(hf.pop("top_p", 1.0)),
                   top_k=int(hf.pop("top_k", 50)), temperature=float(hf.pop("temperature", 1.0)),
                   repetition_penalty=float(hf.pop("repetition_penalty", 1.0)),
@@ -182,6 +179,13 @@ class UnifiedVoice:
         _, emb, mask = self.prepare_gpt_inputs(conds, text_inputs)
         pad = (mask == 0).sum(dim=1).to(torch.int32)
         max_new = (self.max_mel_tokens - 1) if max_generate_length is None else int(max_generate_length)
+        if num_beams > 1:
+            # generate() expands every row to num_beams identical rows before the first forward (beam search / beam-sample)
+            if force_stop is not None or return_logits:
+                raise NotImplementedError("force_stop / return_logits are measurement aids of the num_beams=1 loop")
+            sp["length_penalty"] = length_penalty
+            self.engine.prefill(emb.repeat_interleave(num_beams, dim=0), pad.repeat_interleave(num_beams), max_new)
+            return self.engine.decode_beam(max_new, sp, num_beams)
         self.engine.prefill(emb, pad, max_new)
         out = self.engine.decode(max_new, sp, force_stop=force_stop, return_logits=return_logits)
         return out

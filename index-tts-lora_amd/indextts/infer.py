@@ -318,13 +318,16 @@ class IndexTTS:
         g = self.gpt
         _, emb, mask = g.prepare_gpt_inputs(conds, text_tokens)
         pad = (mask == 0).sum(dim=1).to(torch.int32)
-        if gen.get("num_beams", 1) != 1:
-            warnings.warn("beam-sample (num_beams>1) is not implemented on device yet; decoding with num_beams=1", RuntimeWarning)
         sp = dict(do_sample=bool(gen["do_sample"]), top_p=float(gen["top_p"]), top_k=int(gen["top_k"]),
                   temperature=float(gen["temperature"]), repetition_penalty=float(gen["repetition_penalty"]),
                   seed=int(extra.pop("seed", torch.initial_seed() & 0x7FFFFFFFFFFFFFFF)))
         if not sp["do_sample"]:
             sp["top_p"], sp["top_k"], sp["temperature"] = 1.0, 0, 1.0
+        nb = int(gen.get("num_beams", 1))
+        if nb > 1:  # beam search / beam-sample: every row becomes num_beams rows (HF generate semantics)
+            sp["length_penalty"] = float(gen.get("length_penalty", 0.0))
+            g.engine.prefill(emb.repeat_interleave(nb, dim=0), pad.repeat_interleave(nb), max_mel_tokens)
+            return g.engine.decode_beam(max_mel_tokens, sp, nb)
         g.engine.prefill(emb, pad, max_mel_tokens)
         return g.engine.decode(max_mel_tokens, sp, force_stop=extra.pop("force_stop", None))
 
@@ -530,9 +533,18 @@ class IndexTTS:
         if not sp["do_sample"]:
             sp["top_p"], sp["top_k"], sp["temperature"] = 1.0, 0, 1.0
         self._mark(phase_events, "conditioned")
-        g.engine.prefill(emb, pad, max_mel_tokens)
-        self._mark(phase_events, "prefilled")
-        codes = g.engine.decode(max_mel_tokens, sp, force_stop=force_stop)
+        nb = int(gen.get("num_beams", 1))
+        if nb > 1:
+            if force_stop is not None:
+                raise NotImplementedError("force_stop is a measurement aid of the num_beams=1 loop")
+            sp["length_penalty"] = float(gen.get("length_penalty", 0.0))
+            g.engine.prefill(emb.repeat_interleave(nb, dim=0), pad.repeat_interleave(nb), max_mel_tokens)
+            self._mark(phase_events, "prefilled")
+            codes = g.engine.decode_beam(max_mel_tokens, sp, nb)
+        else:
+            g.engine.prefill(emb, pad, max_mel_tokens)
+            self._mark(phase_events, "prefilled")
+            codes = g.engine.decode(max_mel_tokens, sp, force_stop=force_stop)
         self._mark(phase_events, "decoded")
         codes_c, lens = self.remove_long_silence(codes)
         codes_h, lens_h = codes_c.cpu(), lens.tolist()   # host copies: one transfer each instead of a sync per row

@@ -195,3 +195,50 @@ def test_batch_pipeline_equals_serial_infer_batch():
             assert a.shape == b.shape and torch.equal(a, b)
     pipe.drain()
     pipe.close()
+
+
+@pytest.mark.parametrize("do_sample", [False, True])
+def test_beam_decode_matches_host_driven_oracle(gpt_small_fp32, do_sample):
+    """engine.decode_beam (device-side scorer, in-place KV permutation, graph replay) against a loop that runs the same
+    transformer steps but does the beam bookkeeping with oracle/beam_ref.py on the host and permutes the cache with
+    index_select -- same best hypotheses."""
+    from oracle import beam_ref
+    m = gpt_small_fp32
+    eng = m.engine
+    cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
+    conds = m.get_conditioning(cond_mel, torch.tensor([120], device=DEV))
+    text = torch.tensor([[11, 22, 33, 44, 55, 66], [77, 88, 99, 1, 1, 1]], device=DEV)
+    B, nb, max_new = 2, 3, 12
+    R = B * nb
+    _, emb, mask = m.prepare_gpt_inputs(conds, text)
+    pad = (mask == 0).sum(1).to(torch.int32)
+    sp = dict(do_sample=do_sample, top_p=0.8 if do_sample else 1.0, top_k=30 if do_sample else 0, temperature=1.0,
+              repetition_penalty=10.0, seed=5, length_penalty=0.0)
+    emb_r, pad_r = emb.repeat_interleave(nb, 0), pad.repeat_interleave(nb)
+    # host-driven oracle loop
+    eng.prefill(emb_r, pad_r, max_new)
+    ref = beam_ref.BeamSearch(B, nb, sp, [1] * int(emb.shape[1]) + [8192], eos=8193, length_penalty=0.0, seed=5)
+    n = 0
+    while True:
+        tok, src = ref.step(eng.logits[:R].cpu().numpy())
+        n += 1
+        if n >= max_new or ref.all_done():
+            break
+        idx = torch.from_numpy(src).to(DEV)
+        eng.kc[:, :R] = eng.kc[:, idx]
+        eng.vc[:, :R] = eng.vc[:, idx]
+        eng.tokens[:R] = torch.from_numpy(tok).to(torch.int32).to(DEV)
+        eng.state[0] += 1   # what the select kernel does: step and cache position advance
+        eng.state[1] += 1
+        eng._step_transformer(R)
+    want = ref.finalize()
+    for use_graph in (False, True):
+        eng.prefill(emb_r, pad_r, max_new)
+        got = eng.decode_beam(max_new, sp, nb, use_graph=use_graph, check_every=4).cpu().numpy()
+        w = min(got.shape[1], want.shape[1])
+        assert np.array_equal(got[:, :w], want[:, :w]), (use_graph, got, want)
+        assert (got[:, w:] == 8193).all() and (want[:, w:] == 8193).all()
+    # the reference-API entry point takes the same route
+    codes = m.inference_speech(cond_mel, text, do_sample=do_sample, num_beams=nb, top_k=30, top_p=0.8, temperature=1.0,
+                               repetition_penalty=10.0, length_penalty=0.0, max_generate_length=max_new, seed=5)
+    assert np.array_equal(codes.cpu().numpy()[:, :w], want[:, :w])

@@ -190,3 +190,51 @@ def test_shard_utterances():
     assert max(loads) - min(loads) <= 25 and sh[0][0] == 5
     assert shard_utterances([3, 2, 1], 1) == [[0, 1, 2]]
     assert shard_utterances([], 2) == [[], []]
+
+
+def test_beam_oracle_small_cases():
+    """oracle/beam_ref.py on cases small enough to enumerate: (1) with as many beams as prefixes, beam search is an
+    exhaustive search, so the best closed hypothesis equals the brute-force argmax over all EOS-terminated sequences;
+    (2) peaked logits make beam search reproduce the greedy path; (3) the sampling draws are reproducible per seed."""
+    import itertools
+
+    from oracle import beam_ref
+    V, eos, steps = 4, 3, 3
+    rng = np.random.default_rng(3)
+    table = rng.normal(size=(steps, V)).astype(np.float32) * 2.0          # logits depend on the step only
+    table[-1, eos] += 30.0                                                   # every path closes at the last step
+    lp = np.stack([beam_ref.log_softmax(t[None])[0] for t in table])
+    sp = dict(do_sample=False, top_k=0, top_p=1.0, temperature=1.0, repetition_penalty=1.0)
+    nb = 9                                                                   # >= 3 live prefixes x 3 tokens
+    bs = beam_ref.BeamSearch(1, nb, sp, [1, 2], eos=eos, length_penalty=0.0)
+    for k in range(steps):
+        bs.step(np.repeat(table[k][None], nb, 0))
+        if bs.all_done():
+            break
+    got = bs.finalize()[0].tolist()
+    best, best_s = None, -1e30
+    for n in range(steps):                                                   # n live tokens then EOS at step n
+        for seq in itertools.product(range(V - 1), repeat=n):
+            s = sum(lp[i, t] for i, t in enumerate(seq)) + lp[n, eos]
+            if s > best_s:
+                best, best_s = list(seq), s
+    assert got[: len(best)] == best and all(t == eos for t in got[len(best):])
+    # (2) peaked logits: the greedy path
+    peak = np.full((5, 8), -5.0, dtype=np.float32)
+    path = [4, 1, 6, 2, 7]                                                   # 7 = EOS at the last step
+    for i, t in enumerate(path):
+        peak[i, t] = 9.0
+    bs = beam_ref.BeamSearch(2, 3, sp, [1], eos=7)
+    for k in range(5):
+        bs.step(np.repeat(peak[k][None], 6, 0))
+    assert bs.finalize()[:, :4].tolist() == [path[:4], path[:4]]
+    # (3) reproducible sampling, different seeds differ somewhere
+    sps = dict(do_sample=True, top_k=4, top_p=0.9, temperature=1.0, repetition_penalty=1.0)
+    runs = []
+    for seed in (1, 1, 2):
+        bs = beam_ref.BeamSearch(1, 2, sps, [1], eos=7, seed=seed)
+        r2 = np.random.default_rng(0)
+        for k in range(6):
+            bs.step(r2.normal(size=(2, 8)).astype(np.float32))
+        runs.append(bs.finalize().tolist())
+    assert runs[0] == runs[1]

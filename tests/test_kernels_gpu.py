@@ -400,3 +400,68 @@ def test_gemm_skinny_layernorm_fused(nat, dtype, M, N):
     assert (y.float() - ref).abs().max().item() < 3e-2
     full = F.layer_norm(h, (K,), g, bb, 1e-5) @ w + c   # the un-folded fp32 computation
     assert (y.float() - full).abs().max().item() < 6e-2
+
+
+@pytest.mark.parametrize("do_sample,lp", [(True, 0.0), (False, 0.0), (True, 1.0)])
+def test_beam_step_matches_oracle(nat, do_sample, lp):
+    """itts_beam_step over several steps (EOS becomes likely half-way) against oracle/beam_ref.py: same tokens, same
+    source rows, same done flags at every step, same best hypotheses at the end."""
+    from oracle import beam_ref
+    B, nb, V, cap, steps = 3, 3, 8194, 64, 14
+    R = B * nb
+    sp = dict(do_sample=do_sample, top_k=30, top_p=0.8, temperature=1.0 if not do_sample else 0.9, repetition_penalty=10.0)
+    rng = np.random.default_rng(11)
+    ref = beam_ref.BeamSearch(B, nb, sp, [1] * 5 + [8192], eos=8193, length_penalty=lp, seed=77)
+    i32 = dict(dtype=torch.int32, device=DEV)
+    tokens, src = torch.zeros(R, **i32), torch.zeros(R, **i32)
+    scores = torch.zeros(R, device=DEV)
+    scores.view(B, nb)[:, 1:] = -1e9
+    hist = torch.zeros(2, R, cap, **i32)
+    hyp_score, hyp_len = torch.zeros(B, nb, device=DEV), torch.zeros(B, nb, **i32)
+    hyp_tok, n_hyp = torch.zeros(B, nb, cap, **i32), torch.zeros(B, **i32)
+    worst, done, state = torch.full((B,), 1e9, device=DEV), torch.zeros(B, **i32), torch.zeros(8, **i32)
+    state[1] = 40
+    extra = torch.tensor([1, 8192], **i32)
+    for k in range(steps):
+        lg = (rng.normal(size=(R, V)) * 2.5).astype(np.float32)
+        if k >= 5:
+            lg[:, 8193] += 6.0 + k   # EOS enters the candidate set
+        t_ref, s_ref = ref.step(lg)
+        nat.beam_step(torch.from_numpy(lg).to(DEV), nb, tokens, src, scores, hist, hyp_score, hyp_len, hyp_tok, n_hyp, worst, done,
+                      state, extra, sp["repetition_penalty"], sp["temperature"], sp["top_k"], sp["top_p"], do_sample, lp, 77, 8193)
+        assert tokens.cpu().tolist() == t_ref.tolist(), f"tokens at step {k}"
+        assert src.cpu().tolist() == s_ref.tolist(), f"source rows at step {k}"
+        assert [bool(x) for x in done.cpu().tolist()] == ref.done, f"done flags at step {k}"
+        assert int(state[0]) == k + 1 and int(state[1]) == 41 + k
+        live = [b for b in range(B) if not ref.done[b]]
+        got = scores.cpu().numpy().reshape(B, nb)
+        assert np.allclose(got[live], ref.scores[live], rtol=1e-5, atol=1e-4)
+        h = hist[(k + 1) & 1].cpu().numpy().reshape(B, nb, cap)
+        for b in live:
+            for j in range(nb):
+                assert h[b, j, : k + 1].tolist() == ref.hist[b][j][6:], (k, b, j)
+        if ref.all_done():
+            break
+    assert ref.all_done() or k == steps - 1
+    for b in range(B):
+        want = sorted((float(s), t) for s, t in ref.hyps[b].beams)
+        got = sorted((float(hyp_score[b, i]), hyp_tok[b, i, : int(hyp_len[b, i])].cpu().tolist()) for i in range(int(n_hyp[b])))
+        assert len(want) == len(got)
+        for (ws, wt), (gs, gt) in zip(want, got):
+            assert abs(ws - gs) < 1e-3 and wt == gt
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_beam_reorder_kv(nat, dtype):
+    L, B, nb, H, smax, ctx = 3, 4, 3, 2, 64, 37
+    R = B * nb
+    kc = rnd(L, R, H, smax, 64, seed=91).to(dtype)
+    vc = rnd(L, R, H, smax, 64, seed=92).to(dtype)
+    src = torch.tensor([2, 0, 0, 3, 4, 5, 7, 8, 6, 10, 10, 9], dtype=torch.int32, device=DEV)  # element 1 maps to itself
+    state = torch.zeros(8, dtype=torch.int32, device=DEV)
+    state[1] = ctx
+    k0, v0 = kc.clone(), vc.clone()
+    nat.beam_reorder_kv(kc, vc, src, state, B, nb)
+    idx = src.long()
+    assert torch.equal(kc[:, :, :, :ctx], k0[:, idx][:, :, :, :ctx]) and torch.equal(vc[:, :, :, :ctx], v0[:, idx][:, :, :, :ctx])
+    assert torch.equal(kc[:, :, :, ctx:], k0[:, :, :, ctx:]) and torch.equal(vc[:, :, :, ctx:], v0[:, :, :, ctx:])
