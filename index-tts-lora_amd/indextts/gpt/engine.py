@@ -367,9 +367,9 @@ class GPTEngine:
             n += 1
             if n % check_every == 0 and int(self.state[2].item()) >= B:
                 break
-        return self._beam_finalize(B, nb, n, float(sp.get("length_penalty", 0.0)))
+        return self._beam_finalize(B, nb, n, float(sp.get("length_penalty", 0.0)), max_new)
 
-    def _beam_finalize(self, B, nb, n, length_penalty):
+    def _beam_finalize(self, B, nb, n, length_penalty, max_new):
         """BeamSearchScorer.finalize on the host: running beams of unfinished batch elements become hypotheses (score =
         sum_logprobs / generated_len**length_penalty), the best hypothesis of each element is returned."""
         hs = self.b_hyp_score.cpu().numpy()
@@ -392,10 +392,10 @@ class GPTEngine:
                             hyps.remove(min(hyps, key=lambda h: (h[0], h[1])))
                         worst = min(h[0] for h in hyps)
             best.append(max(hyps, key=lambda h: (h[0], h[1]))[2])
-        width = max(len(t) for t in best) + 1
+        width = min(max(len(t) for t in best) + 1, max_new)  # sent_max_len = min(longest + 1, max_length)
         out = torch.full((B, width), self.stop_mel, dtype=torch.int64)
         for b, t in enumerate(best):
-            out[b, : len(t)] = torch.tensor(t, dtype=torch.int64)
+            out[b, : min(len(t), width)] = torch.tensor(t[:width], dtype=torch.int64)
         return out.to(self.device)
 
     def _get_graph(self, B, sp, nsteps=1):

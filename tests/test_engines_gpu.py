@@ -242,3 +242,35 @@ def test_beam_decode_matches_host_driven_oracle(gpt_small_fp32, do_sample):
     codes = m.inference_speech(cond_mel, text, do_sample=do_sample, num_beams=nb, top_k=30, top_p=0.8, temperature=1.0,
                                repetition_penalty=10.0, length_penalty=0.0, max_generate_length=max_new, seed=5)
     assert np.array_equal(codes.cpu().numpy()[:, :w], want[:, :w])
+
+
+def test_public_api_infer_and_infer_fast_write_wavs(tmp_path):
+    """BASELINE config 1 ("plumbing"): a 44.1 kHz stereo prompt wav + CJK text through IndexTTS.infer and .infer_fast with
+    the reference's default generation settings (beam-sample, num_beams=3) -> a 24 kHz PCM-16 wav of 1024 samples per
+    acoustic token (infer.py:892-917); output_path=None returns (24000, int16 [N, 1])."""
+    import wave
+
+    from indextts.infer import IndexTTS
+    from indextts.utils.audio import write_pcm16
+    cfg = weights.reference_config()
+    cfg["gpt"]["layers"] = 2
+    tts = IndexTTS.from_weights(cfg, weights.gpt_state_dict(2), weights.bigvgan_state_dict(), device="cuda:0",
+                                precision_config={"gpt": "bf16", "vocoder": "fp16"})
+    t = np.arange(int(44100 * 1.2)) / 44100.0
+    stereo = np.stack([0.3 * np.sin(2 * np.pi * 220 * t), 0.2 * np.sin(2 * np.pi * 330 * t)], 1)
+    prompt = str(tmp_path / "prompt.wav")
+    write_pcm16(prompt, (stereo * 32767).astype(np.int16), 44100)
+    text = "你好世界，今天天气很好。我们去公园散步吧！"
+    out = str(tmp_path / "gen.wav")
+    with pytest.warns(RuntimeWarning):  # random weights never emit the stop token: the max_mel_tokens warning of infer.py:850
+        ret = tts.infer(prompt, text, out, max_mel_tokens=9)
+    assert ret == out
+    with wave.open(out, "rb") as w:
+        assert (w.getframerate(), w.getnchannels(), w.getsampwidth()) == (24000, 1, 2)
+        n = w.getnframes()
+    assert n > 0 and n % 1024 == 0
+    with pytest.warns(RuntimeWarning):
+        sr, pcm = tts.infer_fast(prompt, text, None, max_mel_tokens=9, max_text_tokens_per_sentence=8, num_beams=1, do_sample=False)
+    assert sr == 24000 and pcm.dtype == np.int16 and pcm.ndim == 2 and pcm.shape[1] == 1 and pcm.shape[0] % 1024 == 0
+    with pytest.raises(ValueError):
+        tts.infer(prompt, text, None, speaker_id="nobody")
