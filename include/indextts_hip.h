@@ -109,6 +109,19 @@ typedef struct itts_skinny_args {
   int ksplit; /* split-K over workgroups (grid.y); > 1 only with ITTS_EPI_SLAB_F32 */
   int x_ln_f32; /* != 0: x is the fp32 residual stream and is normalised per row on the fly, (x - mean) * rstd with eps
                    1e-5 (LayerNorm without its affine part, which the caller folds into W and bias); needs ksplit 1 */
+  /* Producer stage in the same launch (ln_h != NULL; needs ksplit 1, M <= 32, K % 256 == 0, K / 32 <= 40 k-steps):
+   * M extra workgroups first compute x[row] = LayerNorm(ln_h[row] + ln_bias + sum of ln_nslab split-K slabs; ln_w, ln_b)
+   * exactly as itts_ln_reduce does (ln_h is updated in place), publish the row (write-through stores, one agent-scope
+   * counter add per row) and exit; the GEMM workgroups request their weight blocks first, then wait for the counter to
+   * reach M, then read x.  ln_counter must be 0 at launch; ln_counter_prev (another launch's counter, or NULL) is zeroed. */
+  float* ln_h;
+  const float* ln_slab;
+  int ln_nslab;
+  const float* ln_bias;
+  const float* ln_w;
+  const float* ln_b;
+  int32_t* ln_counter;
+  int32_t* ln_counter_prev;
 } itts_skinny_args;
 int itts_gemm_skinny(const itts_skinny_args* a, void* stream);
 

@@ -26,6 +26,14 @@ struct SkinnyParams {
   int heads, smax;
   int ksplit;
   int slab_rows;
+  float* ln_h;            // fused LayerNorm producer stage (see itts_skinny_args)
+  const float* ln_slab;
+  int ln_nslab;
+  const float* ln_bias;
+  const float* ln_w;
+  const float* ln_b;
+  int32_t* ln_counter;
+  int32_t* ln_counter_prev;
   int lnf;  // A operand is the fp32 residual stream, normalised per row (LayerNorm without affine) on the fly  // total rows of a slab (the caller's M), the stride between split-K slabs
 };
 
@@ -38,14 +46,96 @@ struct SkinnyParams {
 // Requires ksplit == 1 and the wave's whole K slice in one register chunk.
 // MAXT = threads per workgroup the register budget is sized for (512: up to 8 waves; 1024: up to 16 waves, which halves
 // the loads queued per lane at the price of a 128-register cap).
-template <typename T, int MT, int SPW, int NTB, bool LNF, int MAXT = 512>
+// Producer stage of a fused launch: one row of x = LayerNorm(h + bias + slabs) per workgroup, numerics and association
+// order of ln_reduce_wide_kernel.  The row is published for the GEMM workgroups of the SAME launch with write-through
+// (sc1) stores, a drain of every storing wave, a workgroup barrier and one agent-scope counter add (the R1 recipe of the
+// CDNA hand-off rules); the residual stream itself is only read by later launches and is stored normally.
+template <typename T>
+__device__ __forceinline__ void fused_ln_row(const SkinnyParams& p, float* red) {
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int D = p.K;
+  const bool act = tid * 4 < D;
+  const int o = act ? tid * 4 : 0;
+  float* hr = p.ln_h + (int64_t)row * D;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 v = ld16<f32x4>(hr + o);
+  const f32x4 lw = ld16<f32x4>(p.ln_w + o), lb = ld16<f32x4>(p.ln_b + o);
+  {
+    // all loads unconditional (absent operands alias the row itself and are discarded): one round trip, no branches
+    const float* bsrc = p.ln_bias != nullptr ? p.ln_bias + o : hr + o;
+    f32x4 bs = ld16<f32x4>(bsrc);
+    f32x4 sl[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float* ssrc = i < p.ln_nslab ? p.ln_slab + ((int64_t)i * p.slab_rows + row) * D + o : hr + o;
+      sl[i] = ld16<f32x4>(ssrc);
+    }
+    if (p.ln_nslab > 0) {
+      v += (p.ln_bias != nullptr) ? bs : zero;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) v += (i < p.ln_nslab) ? sl[i] : zero;
+      if (act) st16(hr + o, v);
+    }
+  }
+  if (!act) v = zero;
+  float s = wave_sum(v[0] + v[1] + v[2] + v[3]);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  float tot = 0.f;
+  for (int i = 0; i < nw; ++i) tot += red[i];
+  const float mean = tot / (float)D;
+  float q = 0.f;
+  if (act) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float d = v[e] - mean;
+      q = fmaf(d, d, q);
+    }
+  }
+  q = wave_sum(q);
+  if (lane == 0) red[32 + wave] = q;
+  __syncthreads();
+  float qt = 0.f;
+  for (int i = 0; i < nw; ++i) qt += red[32 + i];
+  const float rstd = rsqrtf(qt / (float)D + 1e-5f);
+  if (act) {
+    T* yr = (T*)const_cast<void*>(p.x) + (int64_t)row * D + o;
+    float r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (v[e] - mean) * rstd * lw[e] + lb[e];
+    if constexpr (sizeof(T) == 4) {
+      uint64_t lo = ((uint64_t)__float_as_uint(r[1]) << 32) | __float_as_uint(r[0]);
+      uint64_t hi = ((uint64_t)__float_as_uint(r[3]) << 32) | __float_as_uint(r[2]);
+      __hip_atomic_store((uint64_t*)yr, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store((uint64_t*)yr + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      typedef T t4 __attribute__((ext_vector_type(4)));
+      t4 ov = {Elem<T>::from_f(r[0]), Elem<T>::from_f(r[1]), Elem<T>::from_f(r[2]), Elem<T>::from_f(r[3])};
+      __hip_atomic_store((uint64_t*)yr, __builtin_bit_cast(uint64_t, ov), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the workgroup signals
+  __syncthreads();
+  if (tid == 0) {
+    if (row == 0 && p.ln_counter_prev != nullptr) *p.ln_counter_prev = 0;  // that launch has completed (stream order)
+    __hip_atomic_fetch_add(p.ln_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <typename T, int MT, int SPW, int NTB, bool LNF, int MAXT = 512, bool FUSE = false>
 __global__ __launch_bounds__(MAXT) void gemm_skinny_kernel(SkinnyParams p) {
   typedef Elem<T> EL;
   typedef typename EL::frag frag;
   constexpr int E = EL::E, KS = EL::KS;
   extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][NTB][MT][64][4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
-  const int nt0 = blockIdx.x * NTB, ks = blockIdx.y;
+  if constexpr (FUSE) {
+    if ((int)blockIdx.x < p.M) {
+      fused_ln_row<T>(p, red);
+      return;
+    }
+  }
+  const int nt0 = (FUSE ? (int)blockIdx.x - p.M : (int)blockIdx.x) * NTB, ks = blockIdx.y;
   const int NTtot = (p.N + 15) / 16;
   const int g = lane >> 4, r = lane & 15;
   const int KT = p.K / KS;
@@ -172,6 +262,20 @@ __global__ __launch_bounds__(MAXT) void gemm_skinny_kernel(SkinnyParams p) {
         int s = base + i;
         bf[t][i] = (s < s_end && nt0 + t < NTtot) ? ld16<frag>(bp + ((int64_t)t * KT + s) * 1024) : zero_frag<frag>();
       }
+    if constexpr (FUSE) {
+      // the weight blocks are in flight; now wait for the producer workgroups' rows: ONE lane polls the counter (relaxed),
+      // ONE agent-scope acquire drops this CU's stale lines, the barrier releases the other waves to plain loads
+      if (tid == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(p.ln_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.M) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1 << 22)) break;  // never expected: the producers are the first workgroups of this launch
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < SPW; ++i) {
       int s = base + i;
@@ -264,6 +368,18 @@ static int launch_skinny(const SkinnyParams& p, hipStream_t s) {
   if (spw > 5 && ntb > 2) ntb = 2;  // register budget of the 10-step variant
   size_t lds = (size_t)NW * ntb * MT * 256 * 4 + (p.lnf ? (size_t)NW * MT * 16 * 2 * 4 : 0);
   dim3 grid((NT + ntb - 1) / ntb, p.ksplit), block(NW * 64);
+  if (p.ln_h != nullptr) {
+    // fused producer stage: M extra workgroups in front; one pass of the k-loop only (all weight blocks in flight at once)
+    if (p.ksplit != 1 || p.lnf || spw > 5 || NW != 8 || p.K % 256 != 0 || p.K / 4 > NW * 64 || p.ln_nslab < 0 || p.ln_nslab > 3) {
+      set_error("itts_gemm_skinny: the fused LayerNorm stage needs ksplit 1, K %% 256 == 0, K <= %d, <= 3 slabs", 8 * 5 * KS);
+      return ITTS_ERR_INVALID;
+    }
+    grid.x += p.M;
+#define ITTS_SKF(NTB_) hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 5, NTB_, false, 512, true>), grid, block, lds, s, p)
+    if (ntb == 1) ITTS_SKF(1); else if (ntb == 2) ITTS_SKF(2); else ITTS_SKF(3);
+#undef ITTS_SKF
+    return check_launch("itts_gemm_skinny");
+  }
 #define ITTS_SK(SPW_, NTB_, LNF_) hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, SPW_, NTB_, LNF_>), grid, block, lds, s, p)
   if (p.lnf) {
     if (spw > 5 || p.ksplit != 1) {
@@ -304,6 +420,10 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
     ITTS_REQUIRE(a->yf, "itts_gemm_skinny: yf is null");
   else
     ITTS_REQUIRE((a->epi == ITTS_EPI_STORE || a->epi == ITTS_EPI_GELU_STORE) && a->y, "itts_gemm_skinny: bad epilogue %d", a->epi);
+  if (a->ln_h != nullptr)
+    ITTS_REQUIRE(a->ln_w && a->ln_b && a->ln_counter && (a->ln_nslab == 0 || a->ln_slab) && !a->x_ln_f32 &&
+                     a->M <= (a->dtype == ITTS_F32 ? 16 : 32),
+                 "itts_gemm_skinny: bad fused-LayerNorm arguments (needs M <= 32 rows, 16 in fp32)");
   if (a->M == 0) return ITTS_OK;
   hipStream_t s = (hipStream_t)stream;
   const int rows_per = (a->dtype == ITTS_F32) ? 16 : 32;
@@ -328,6 +448,14 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
     p.smax = a->smax;
     p.ksplit = ksplit;
     p.slab_rows = a->M;
+    p.ln_h = a->ln_h;
+    p.ln_slab = a->ln_slab;
+    p.ln_nslab = a->ln_nslab;
+    p.ln_bias = a->ln_bias;
+    p.ln_w = a->ln_w;
+    p.ln_b = a->ln_b;
+    p.ln_counter = a->ln_counter;
+    p.ln_counter_prev = a->ln_counter_prev;
     int rc;
     if (a->dtype == ITTS_F32) {
       rc = launch_skinny<float, 1>(p, s);

@@ -26,7 +26,9 @@ class SkinnyArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("wp", C.c_void_p),
                 ("bias", C.c_void_p), ("x", C.c_void_p), ("epi", C.c_int), ("y", C.c_void_p), ("yf", C.c_void_p),
                 ("kcache", C.c_void_p), ("vcache", C.c_void_p), ("pos", C.c_void_p), ("heads", C.c_int),
-                ("smax", C.c_int), ("ksplit", C.c_int), ("x_ln_f32", C.c_int)]
+                ("smax", C.c_int), ("ksplit", C.c_int), ("x_ln_f32", C.c_int), ("ln_h", C.c_void_p), ("ln_slab", C.c_void_p),
+                ("ln_nslab", C.c_int), ("ln_bias", C.c_void_p), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p),
+                ("ln_counter", C.c_void_p), ("ln_counter_prev", C.c_void_p)]
 
 
 class ConvArgs(C.Structure):
@@ -168,8 +170,14 @@ def aa_snake(x, alpha_log, beta_log, up_f, down_f, layout=0, out=None):
 
 
 def gemm_skinny(dtype, M, N, K, wp, bias=None, x=None, epi=EPI_STORE, y=None, yf=None, kcache=None, vcache=None, pos=None,
-                heads=0, smax=0, ksplit=1, x_ln_f32=False):
+                heads=0, smax=0, ksplit=1, x_ln_f32=False, ln=None):
+    """ln = dict(h, w, b, counter[, slab, nslab, bias, prev]): fused producer stage, x = LN(h + bias + slabs) computed by the
+    first M workgroups of the same launch and written to `x` (see itts_skinny_args)."""
     a = SkinnyArgs()
+    if ln is not None:
+        a.ln_h, a.ln_w, a.ln_b, a.ln_counter = _p(ln["h"]), _p(ln["w"]), _p(ln["b"]), _p(ln["counter"])
+        a.ln_slab, a.ln_nslab, a.ln_bias = _p(ln.get("slab")), int(ln.get("nslab", 0)), _p(ln.get("bias"))
+        a.ln_counter_prev = _p(ln.get("prev"))
     a.dtype, a.M, a.N, a.K = dt(dtype), M, N, K
     a.wp, a.bias, a.x = _p(wp), _p(bias), _p(x)
     a.epi, a.y, a.yf = epi, _p(y), _p(yf)

@@ -41,8 +41,13 @@ class GPTEngine:
         #           out-projection updates the residual stream directly (no split-K)             -> 6 launches per block
         #   mode 3: additionally LayerNorm-1 inside the QKV GEMM and an unsplit FC2               -> 5 launches per block
         #   mode 1: every LayerNorm is its own [residual-reduce + LN] launch                      -> 7 launches per block
+        #   mode 4: the [residual-reduce + LN] rows are produced by 32 extra workgroups of the consumer GEMM's own launch
+        #           (in-launch hand-off: write-through rows, agent-scope counter, one acquire)    -> 5 launches per block
         # Measured on MI355X (B=32, bf16): mode 1 1.29 ms/token, mode 2 1.32, mode 3 1.49 -- the unsplit N=1280 GEMMs
-        # (80 workgroups) and the heavier fused prologue cost more than the launches they save, so mode 1 is the default.
+        # (80 workgroups) and the heavier fused prologue cost more than the launches they save.  Mode 4 (after the wide
+        # ln_reduce brought mode 1 to 1.15 ms): 1.27 ms -- the hand-off (drain + counter + poll + acquire) costs ~2.4 us
+        # more per stage than the kernel boundary it removes, although the weight blocks are in flight meanwhile.  Mode 1
+        # stays the default.
         self.decode_mode = int(os.environ.get("ITTS_DECODE_MODE", "1")) if dtype != torch.float32 else 1
 
         def fold(ln_w, ln_b, w_kn, b_n):
@@ -62,9 +67,9 @@ class GPTEngine:
                 w_fc=packed(W[p + "mlp.c_fc.weight"]), b_fc=f32(p + "mlp.c_fc.bias"),
                 w_pr=packed(W[p + "mlp.c_proj.weight"]), b_pr=f32(p + "mlp.c_proj.bias"),
             )
-            if self.decode_mode >= 2:
+            if self.decode_mode in (2, 3):
                 d["w_fc_ln"], d["b_fc_ln"] = fold(p + "ln_2.weight", p + "ln_2.bias", p + "mlp.c_fc.weight", p + "mlp.c_fc.bias")
-            if self.decode_mode >= 3:
+            if self.decode_mode == 3:
                 d["w_qkv_ln"], d["b_qkv_ln"] = fold(p + "ln_1.weight", p + "ln_1.bias", p + "attn.c_attn.weight",
                                                     p + "attn.c_attn.bias")
             self.layers.append(d)
@@ -86,6 +91,7 @@ class GPTEngine:
         self.force_eager = False  # measurement aid: launch every kernel eagerly
         self.steps_per_graph = int(os.environ.get("ITTS_STEPS_PER_GRAPH", "1"))  # decode tokens per CUDA-graph replay; measured 1 > 2 > 4 > 8 (1297 / 1319 / 1342 / 1368 us per token)
         self._sink = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.ln_cnt = torch.zeros(2 * layers, dtype=torch.int32, device=dev)  # arrival counters of the fused LN stages (mode 4)
         self.weight_bytes = sum(t.numel() * t.element_size() for l in self.layers for t in
                                 (l["w_qkv"], l["w_o"], l["w_fc"], l["w_pr"])) + self.w_head.numel()
 
@@ -211,6 +217,8 @@ class GPTEngine:
         nat.embed_step(self.tokens, self.mel_emb, self.mel_pos, step, 1, h)
         pending = None  # bias of an FC2 whose split-K slabs have not been folded into h yet
         mode = self.decode_mode
+        if mode == 4 and B > 32:
+            mode = 1  # the fused producer stage handles one 32-row GEMM launch
         for i, l in enumerate(self.layers):
             if i + 1 < self.L:
                 n = self.layers[i + 1]
@@ -218,7 +226,14 @@ class GPTEngine:
             else:
                 prefetch([self.w_head])
             # --- attention half
-            if mode >= 3:
+            if mode == 4:
+                ln = dict(h=h, w=l["ln1"][0], b=l["ln1"][1], counter=self.ln_cnt[2 * i: 2 * i + 1],
+                          prev=self.ln_cnt[(2 * i - 1) % (2 * self.L):][:1])
+                if pending is not None:
+                    ln.update(slab=slab, nslab=KS, bias=pending)
+                nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv"], l["b_qkv"], x=xn, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
+                                vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s, ln=ln)
+            elif mode == 3:
                 nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv_ln"], l["b_qkv_ln"], x=h, x_ln_f32=True, epi=nat.EPI_QKV_CACHE, y=self.q,
                                 kcache=self.kc[i], vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s)
             else:
@@ -230,14 +245,19 @@ class GPTEngine:
                                 vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s)
             nat.attn_decode(self.q, self.kc[i], self.vc[i], self.a, self.pad, pos, B, H, self._cap_s)
             # --- MLP half
-            if mode >= 2:
+            if mode == 4:
+                nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS)
+                ln = dict(h=h, w=l["ln2"][0], b=l["ln2"][1], counter=self.ln_cnt[2 * i + 1: 2 * i + 2],
+                          prev=self.ln_cnt[2 * i: 2 * i + 1], slab=slab, nslab=KS, bias=l["b_o"])
+                nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f, ln=ln)
+            elif mode >= 2:
                 nat.gemm_skinny(T, B, D, D, l["w_o"], l["b_o"], x=self.a, epi=nat.EPI_RESID_F32, yf=h)
                 nat.gemm_skinny(T, B, 4 * D, D, l["w_fc_ln"], l["b_fc_ln"], x=h, x_ln_f32=True, epi=nat.EPI_GELU_STORE, y=self.f)
             else:
                 nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS)
                 nat.ln_reduce(h, l["ln2"][0], l["ln2"][1], xn, slab=slab, nslab=KS, bias=l["b_o"])
                 nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f)
-            if mode >= 3:
+            if mode == 3:
                 nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], l["b_pr"], x=self.f, epi=nat.EPI_RESID_F32, yf=h)
                 pending = None
             else:

@@ -465,3 +465,34 @@ def test_beam_reorder_kv(nat, dtype):
     idx = src.long()
     assert torch.equal(kc[:, :, :, :ctx], k0[:, idx][:, :, :, :ctx]) and torch.equal(vc[:, :, :, :ctx], v0[:, idx][:, :, :, :ctx])
     assert torch.equal(kc[:, :, :, ctx:], k0[:, :, :, ctx:]) and torch.equal(vc[:, :, :, ctx:], v0[:, :, :, ctx:])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])   # 16-bit only: fp32 needs two passes of the k-loop
+@pytest.mark.parametrize("nslab", [0, 3])
+def test_gemm_skinny_fused_layernorm_stage(nat, dtype, nslab):
+    """The fused launch (producer workgroups compute LN(h + bias + slabs), GEMM workgroups wait for them inside the same
+    launch) must reproduce the two-launch sequence itts_ln_reduce -> itts_gemm_skinny bit for bit, many times in a row
+    (the consumer CUs have the previous round's x lines in their caches), and leave h updated the same way."""
+    M, D, N = 32, 1280, 3840
+    w = (rnd(D, N, seed=70) * 0.03).to(dtype)
+    wp = nat.pack_weight(w)
+    bias = rnd(N, seed=71)
+    lw, lb = 1.0 + 0.1 * rnd(D, seed=72), 0.1 * rnd(D, seed=73)
+    ob = rnd(D, seed=74)
+    cnt = torch.zeros(2, dtype=torch.int32, device=DEV)
+    for it in range(6):
+        h0 = rnd(M, D, seed=80 + it)
+        slab = rnd(3, M, D, seed=90 + it) if nslab else None
+        h_ref, x_ref = h0.clone(), torch.empty(M, D, dtype=dtype, device=DEV)
+        nat.ln_reduce(h_ref, lw, lb, x_ref, slab=slab, nslab=nslab, bias=ob if nslab else None)
+        y_ref = torch.empty(M, N, dtype=dtype, device=DEV)
+        nat.gemm_skinny(dtype, M, N, D, wp, bias, x=x_ref, epi=nat.EPI_GELU_STORE, y=y_ref)
+        h, x, y = h0.clone(), torch.full((M, D), 7.0, dtype=dtype, device=DEV), torch.empty(M, N, dtype=dtype, device=DEV)
+        ln = dict(h=h, w=lw, b=lb, counter=cnt[it % 2: it % 2 + 1], prev=cnt[(it + 1) % 2: (it + 1) % 2 + 1])
+        if nslab:
+            ln.update(slab=slab, nslab=nslab, bias=ob)
+        nat.gemm_skinny(dtype, M, N, D, wp, bias, x=x, epi=nat.EPI_GELU_STORE, y=y, ln=ln)
+        torch.cuda.synchronize()
+        assert torch.equal(x, x_ref) and torch.equal(h, h_ref), f"round {it}"
+        assert torch.equal(y, y_ref), f"round {it}"
+        assert cnt[it % 2].item() == M and cnt[(it + 1) % 2].item() == 0
