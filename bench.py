@@ -185,13 +185,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    # Rehearsal aid for a one-GPU box (not used by the driver): ITTS_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # ITTS_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device; the control flow is the same.
+    if os.environ.get("ITTS_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("ITTS_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     torch.set_grad_enabled(False)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import weights
     from indextts import _native as nat
