@@ -175,10 +175,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--schedule", choices=["pipelined", "serial"], default="serial",
+    ap.add_argument("--inflight", type=int, default=2, help="batches in flight for --schedule concurrent")
+    ap.add_argument("--no-concurrency", action="store_true",
+                    help="skip the extra (reported, never `value`) measurement with two batch-32 requests in flight")
+    ap.add_argument("--schedule", choices=["pipelined", "serial", "concurrent"], default="serial",
                     help="pipelined: latent pass + vocoder of batch i on a second HIP stream beside the token loop of batch "
                          "i+1 (BatchPipeline; measured +1.6 %: the workgroup dispatcher serialises the big launches of one "
-                         "queue against the small ones of the other); serial: one batch at a time on one stream")
+                         "queue against the small ones of the other); serial: one batch at a time on one stream; "
+                         "concurrent: --inflight independent batch-32 requests at a time, each on its own engine instance, "
+                         "thread and HIP stream (serving concurrency; the token loops of different requests interleave on "
+                         "the CUs, which the latency-bound loop of a single request leaves mostly idle)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -215,6 +221,12 @@ def main():
     with contextlib.redirect_stdout(sys.stderr):  # keep stdout for the single JSON line
         tts = IndexTTS.from_weights(cfg, gsd_d, bsd_d, device=device,
                                     precision_config={"gpt": "bf16", "vocoder": "fp16"})
+    extra = []
+    want_conc = args.schedule == "concurrent" or (world == 1 and not args.no_concurrency)
+    if want_conc:
+        with contextlib.redirect_stdout(sys.stderr):
+            extra = [IndexTTS.from_weights(cfg, gsd_d, bsd_d, device=device, precision_config={"gpt": "bf16", "vocoder": "fp16"})
+                     for _ in range(max(2, args.inflight) - 1)]
     del gsd_d, bsd_d
     cond_mel, texts = make_inputs(rank, device)
     force = [MEL_TOKENS] * BATCH
@@ -231,11 +243,52 @@ def main():
         torch.cuda.synchronize()
 
     pipe = BatchPipeline(tts) if args.schedule == "pipelined" else None
+    workers = None
+    if want_conc:
+        import queue
+        import threading
+
+        class Worker(threading.Thread):
+            """One request at a time on its own engine instance and stream."""
+
+            def __init__(self, inst):
+                super().__init__(daemon=True)
+                self.inst, self.stream, self.jobs, self.done = inst, torch.cuda.Stream(device=device), queue.Queue(), queue.Queue()
+                self.start()
+
+            def run(self):
+                torch.cuda.set_device(device)
+                while True:
+                    seed = self.jobs.get()
+                    if seed is None:
+                        return
+                    with torch.no_grad(), torch.cuda.stream(self.stream):
+                        o = self.inst.infer_batch(cond_mel, texts, max_mel_tokens=MEL_TOKENS + 1, force_stop=force, seed=seed, **gen)
+                        self.stream.synchronize()
+                    self.done.put(o)
+
+        def make_workers():
+            ws = [Worker(t) for t in [tts] + extra]
+            for w in ws:           # graph captures happen here, one worker at a time (a capture must not see other threads' calls)
+                for sd in (900, 901):
+                    w.jobs.put(sd)
+                    w.done.get()
+            return ws
+
+        if args.schedule == "concurrent":
+            workers = make_workers()
 
     def run_steps(n, seed0):
         """n steps of the hot path; every step's waveforms are complete when this returns."""
         if n <= 0:
             return None
+        if workers is not None:
+            for k in range(n):
+                workers[k % len(workers)].jobs.put(seed0 + k)
+            o = None
+            for k in range(n):
+                o = workers[k % len(workers)].done.get()
+            return o
         if pipe is None:
             o = None
             for k in range(n):
@@ -313,7 +366,9 @@ def main():
                    "audio_seconds_per_step_per_gpu": round(audio_s_step, 3),
                    "schedule": ("2-stage batch pipeline: latent pass + vocoder of batch i on a second HIP stream beside "
                                 "the token loop of batch i+1; all steps complete inside the timed region")
-                   if pipe is not None else "serial: one batch at a time on one stream"},
+                   if pipe is not None else (f"concurrent: {len(workers)} independent batch-32 requests in flight (one engine "
+                                             "instance, thread and HIP stream each)" if workers is not None else
+                                             "serial: one batch at a time on one stream")},
         "serial_ms_per_step": round(serial_ms, 3),
         "first_token_ms_p50": round(first_token_ms, 2),
         "phases_ms": phases,
@@ -321,6 +376,31 @@ def main():
                         "GBps": round(dec_bytes / (step_us * 1e-6) / 1e9, 1),
                         "frac_of_hbm_peak": round(dec_bytes / (step_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)},
     }
+
+    if rank == 0 and world == 1 and want_conc and args.schedule != "concurrent":
+        # Reported beside `value`, never as `value`: two independent batch-32 requests in flight (one engine instance,
+        # thread and HIP stream each).  A single request's token loop is latency-bound and leaves the CUs mostly idle.
+        ws = make_workers()
+        nrun = max(4, 2 * len(ws))
+
+        def run_conc(seed0):
+            for k in range(nrun):
+                ws[k % len(ws)].jobs.put(seed0 + k)
+            for k in range(nrun):
+                ws[k % len(ws)].done.get()
+        run_conc(5000)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        run_conc(6000)
+        torch.cuda.synchronize()
+        dtc = time.perf_counter() - tc
+        result["concurrent_requests"] = {"inflight": len(ws), "steps": nrun, "value": round(audio_s_step * nrun / dtc, 2),
+                                         "unit": "audio-seconds/sec", "ms_per_step": round(1e3 * dtc / nrun, 3),
+                                         "note": "serving concurrency: independent batch-32 requests overlap; `value` above "
+                                                 "is one request at a time"}
+        for w in ws:
+            w.jobs.put(None)
+        log(f"[bench] {len(ws)} requests in flight: {result['concurrent_requests']['value']} audio-s/s")
 
     if rank == 0 and not args.no_roofline:
         # one more identical step with per-launch HIP events (eager launches instead of graph replay)

@@ -206,7 +206,7 @@ typedef struct itts_sample_args {
   const int32_t* force_stop; /* [B] or NULL */
   float rep_penalty, temperature, top_p;
   int top_k, do_sample;
-  uint64_t seed;
+  uint64_t seed;     /* Philox key = seed + the 64-bit value in state[4..5] (lo, hi): a captured launch serves any seed */
   int stop_token;
   float* dbg_scores; /* optional [B][V] processed scores (-inf = removed), for parity tests; NULL in production */
 } itts_sample_args;
@@ -240,7 +240,7 @@ typedef struct itts_beam_args {
   int n_extra;
   float rep_penalty, temperature, top_p, length_penalty;
   int top_k, do_sample;
-  uint64_t seed;
+  uint64_t seed;        /* Philox key = seed + the 64-bit value in state[4..5], as in itts_sample_args */
   int eos_token;
 } itts_beam_args;
 int itts_beam_step(const itts_beam_args* a, void* stream);

@@ -231,11 +231,13 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p) {
       int npick = 0;
       const int want = min(2 * nb, np);
       if (p.do_sample) {
+        // key = launch argument + the 64-bit seed held in state[4..5] (lets a captured launch serve every seed)
+        const uint64_t key = (((uint64_t)p.seed_hi << 32) | p.seed_lo) + (((uint64_t)(uint32_t)p.state[5] << 32) | (uint32_t)p.state[4]);
         for (int j = 0; j < np; ++j) { cs[j] = expf(ss[j] - ss[0]); ci[j] = 1; }
         for (int i = 0; i < want; ++i) {
           float total = 0.f;
           for (int j = 0; j < np; ++j) if (ci[j]) total += cs[j];
-          uint32_t x = philox_first3((uint32_t)b, (uint32_t)k, (uint32_t)i, p.seed_lo, p.seed_hi);
+          uint32_t x = philox_first3((uint32_t)b, (uint32_t)k, (uint32_t)i, (uint32_t)key, (uint32_t)(key >> 32));
           float u = (float)(x >> 8) * (1.0f / 16777216.0f);
           float thr2 = u * total, run = 0.f;
           int pick = -1, last = -1;

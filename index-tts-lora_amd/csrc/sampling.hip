@@ -186,7 +186,9 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
         }
       }
       sh_keep = keep;
-      uint32_t x = philox_first((uint32_t)b, (uint32_t)k, 0u, 0u, p.seed_lo, p.seed_hi);
+      // key = launch argument + the 64-bit seed held in state[4..5] (lets a captured launch serve every seed)
+      const uint64_t key = (((uint64_t)p.seed_hi << 32) | p.seed_lo) + (((uint64_t)(uint32_t)p.state[5] << 32) | (uint32_t)p.state[4]);
+      uint32_t x = philox_first((uint32_t)b, (uint32_t)k, 0u, 0u, (uint32_t)key, (uint32_t)(key >> 32));
       float u = (float)(x >> 8) * (1.0f / 16777216.0f);
       float tot2 = 0.f;
       for (int i = 0; i < keep; ++i) tot2 += cs[i];

@@ -305,6 +305,7 @@ class GPTEngine:
         else:
             self.force_stop[:B] = torch.as_tensor(force_stop, dtype=torch.int32).to(self.device)
         logits_trace = [self.logits[:B].clone()] if return_logits else None
+        sp = self._seed_to_state(sp)
         self._sample(B, sp)  # token 1 from the prefill logits
         n = 1
         G = 1 if return_logits else self.steps_per_graph
@@ -370,6 +371,7 @@ class GPTEngine:
         self.b_n_hyp.zero_()
         self.b_worst.fill_(1e9)
         self.b_done.zero_()
+        sp = self._seed_to_state(sp)
         self._beam_select(B, nb, sp)  # token 1 from the prefill logits
         n = 1
         key = ("beam", B, nb, tuple(sorted(sp.items())))
@@ -417,6 +419,17 @@ class GPTEngine:
         for b, t in enumerate(best):
             out[b, : min(len(t), width)] = torch.tensor(t[:width], dtype=torch.int64)
         return out.to(self.device)
+
+    def _seed_to_state(self, sp):
+        """The draw key is launch-argument seed + state[4..5]; the loop keeps the argument at 0 and the real seed in the
+        device state, so one captured step serves every seed (no re-capture per call)."""
+        seed = int(sp.get("seed", 0)) & 0xFFFFFFFFFFFFFFFF
+        lo, hi = seed & 0xFFFFFFFF, seed >> 32
+        as_i32 = lambda v: v - (1 << 32) if v >= (1 << 31) else v  # noqa: E731
+        self.state[4:6] = torch.tensor([as_i32(lo), as_i32(hi)], dtype=torch.int32).to(self.device)
+        out = dict(sp)
+        out["seed"] = 0
+        return out
 
     def _get_graph(self, B, sp, nsteps=1):
         key = (B, nsteps, tuple(sorted(sp.items())))
