@@ -209,7 +209,7 @@ def main():
 
     import weights
     from indextts import _native as nat
-    from indextts.infer import BatchPipeline, IndexTTS
+    from indextts.infer import BatchPipeline, IndexTTS, RequestPool
 
     gsd = bsd = None
     if rank == 0:
@@ -243,52 +243,24 @@ def main():
         torch.cuda.synchronize()
 
     pipe = BatchPipeline(tts) if args.schedule == "pipelined" else None
-    workers = None
-    if want_conc:
-        import queue
-        import threading
+    pool = None
 
-        class Worker(threading.Thread):
-            """One request at a time on its own engine instance and stream."""
+    def make_pool():
+        pl = RequestPool([tts] + extra)
+        pl.warm_up(cond_mel, texts, max_mel_tokens=MEL_TOKENS + 1, force_stop=force, seed=900, **gen)
+        return pl
 
-            def __init__(self, inst):
-                super().__init__(daemon=True)
-                self.inst, self.stream, self.jobs, self.done = inst, torch.cuda.Stream(device=device), queue.Queue(), queue.Queue()
-                self.start()
-
-            def run(self):
-                torch.cuda.set_device(device)
-                while True:
-                    seed = self.jobs.get()
-                    if seed is None:
-                        return
-                    with torch.no_grad(), torch.cuda.stream(self.stream):
-                        o = self.inst.infer_batch(cond_mel, texts, max_mel_tokens=MEL_TOKENS + 1, force_stop=force, seed=seed, **gen)
-                        self.stream.synchronize()
-                    self.done.put(o)
-
-        def make_workers():
-            ws = [Worker(t) for t in [tts] + extra]
-            for w in ws:           # graph captures happen here, one worker at a time (a capture must not see other threads' calls)
-                for sd in (900, 901):
-                    w.jobs.put(sd)
-                    w.done.get()
-            return ws
-
-        if args.schedule == "concurrent":
-            workers = make_workers()
+    if args.schedule == "concurrent":
+        pool = make_pool()
 
     def run_steps(n, seed0):
         """n steps of the hot path; every step's waveforms are complete when this returns."""
         if n <= 0:
             return None
-        if workers is not None:
-            for k in range(n):
-                workers[k % len(workers)].jobs.put(seed0 + k)
-            o = None
-            for k in range(n):
-                o = workers[k % len(workers)].done.get()
-            return o
+        if pool is not None:
+            jobs = [pool.submit(cond_mel, texts, max_mel_tokens=MEL_TOKENS + 1, force_stop=force, seed=seed0 + k, **gen)
+                    for k in range(n)]
+            return [j.result() for j in jobs][-1]
         if pipe is None:
             o = None
             for k in range(n):
@@ -366,8 +338,8 @@ def main():
                    "audio_seconds_per_step_per_gpu": round(audio_s_step, 3),
                    "schedule": ("2-stage batch pipeline: latent pass + vocoder of batch i on a second HIP stream beside "
                                 "the token loop of batch i+1; all steps complete inside the timed region")
-                   if pipe is not None else (f"concurrent: {len(workers)} independent batch-32 requests in flight (one engine "
-                                             "instance, thread and HIP stream each)" if workers is not None else
+                   if pipe is not None else (f"concurrent: {len(pool.instances)} independent batch-32 requests in flight (one "
+                                             "engine instance, thread and HIP stream each)" if pool is not None else
                                              "serial: one batch at a time on one stream")},
         "serial_ms_per_step": round(serial_ms, 3),
         "first_token_ms_p50": round(first_token_ms, 2),
@@ -380,27 +352,26 @@ def main():
     if rank == 0 and world == 1 and want_conc and args.schedule != "concurrent":
         # Reported beside `value`, never as `value`: two independent batch-32 requests in flight (one engine instance,
         # thread and HIP stream each).  A single request's token loop is latency-bound and leaves the CUs mostly idle.
-        ws = make_workers()
-        nrun = max(4, 2 * len(ws))
+        pl = make_pool()
+        nrun = max(4, 2 * len(pl.instances))
 
         def run_conc(seed0):
-            for k in range(nrun):
-                ws[k % len(ws)].jobs.put(seed0 + k)
-            for k in range(nrun):
-                ws[k % len(ws)].done.get()
+            jobs = [pl.submit(cond_mel, texts, max_mel_tokens=MEL_TOKENS + 1, force_stop=force, seed=seed0 + k, **gen)
+                    for k in range(nrun)]
+            for j in jobs:
+                j.result()
         run_conc(5000)
         torch.cuda.synchronize()
         tc = time.perf_counter()
         run_conc(6000)
         torch.cuda.synchronize()
         dtc = time.perf_counter() - tc
-        result["concurrent_requests"] = {"inflight": len(ws), "steps": nrun, "value": round(audio_s_step * nrun / dtc, 2),
+        result["concurrent_requests"] = {"inflight": len(pl.instances), "steps": nrun, "value": round(audio_s_step * nrun / dtc, 2),
                                          "unit": "audio-seconds/sec", "ms_per_step": round(1e3 * dtc / nrun, 3),
-                                         "note": "serving concurrency: independent batch-32 requests overlap; `value` above "
-                                                 "is one request at a time"}
-        for w in ws:
-            w.jobs.put(None)
-        log(f"[bench] {len(ws)} requests in flight: {result['concurrent_requests']['value']} audio-s/s")
+                                         "note": "serving concurrency (indextts.infer.RequestPool): independent batch-32 requests "
+                                                 "overlap; `value` above is one request at a time"}
+        pl.close()
+        log(f"[bench] {len(pl.instances)} requests in flight: {result['concurrent_requests']['value']} audio-s/s")
 
     if rank == 0 and not args.no_roofline:
         # one more identical step with per-launch HIP events (eager launches instead of graph replay)

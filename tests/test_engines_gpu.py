@@ -274,3 +274,31 @@ def test_public_api_infer_and_infer_fast_write_wavs(tmp_path):
     assert sr == 24000 and pcm.dtype == np.int16 and pcm.ndim == 2 and pcm.shape[1] == 1 and pcm.shape[0] % 1024 == 0
     with pytest.raises(ValueError):
         tts.infer(prompt, text, None, speaker_id="nobody")
+
+
+def test_request_pool_matches_serial_infer_batch():
+    """RequestPool (two replicas, two threads, two streams, requests overlapping on the GPU) returns what infer_batch
+    returns for the same (batch, seed) on one instance."""
+    from indextts.infer import IndexTTS, RequestPool
+    cfg = weights.reference_config()
+    cfg["gpt"]["layers"] = 2
+    gsd, bsd = weights.gpt_state_dict(2), weights.bigvgan_state_dict()
+    insts = [IndexTTS.from_weights(cfg, gsd, bsd, device="cuda:0", precision_config={"gpt": "bf16", "vocoder": "fp16"})
+             for _ in range(2)]
+    cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
+    rng = np.random.default_rng(9)
+    batches = [[torch.from_numpy(rng.integers(2, 12000, size=int(n))).to(torch.int32) for n in rng.integers(5, 20, size=4)]
+               for _ in range(5)]
+    gen = dict(do_sample=True, top_k=30, top_p=0.8, temperature=1.0, repetition_penalty=10.0, num_beams=1)
+    kw = dict(max_mel_tokens=11, force_stop=[10, 8, 10, 6])
+    serial = [insts[0].infer_batch(cond_mel, b, seed=300 + i, **kw, **gen) for i, b in enumerate(batches)]
+    torch.cuda.synchronize()
+    pool = RequestPool(insts)
+    pool.warm_up(cond_mel, batches[0], seed=1, **kw, **gen)
+    jobs = [pool.submit(cond_mel, b, seed=300 + i, **kw, **gen) for i, b in enumerate(batches)]
+    for want, job in zip(serial, jobs):
+        got = job.result()
+        assert len(got) == len(want)
+        for a, b in zip(want, got):
+            assert a.shape == b.shape and torch.equal(a, b)
+    pool.close()
