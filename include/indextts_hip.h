@@ -153,6 +153,7 @@ typedef struct itts_conv_args {
 } itts_conv_args;
 int itts_gemm_conv(const itts_conv_args* a, void* stream);
 
+
 /* LayerNorm over the last dim of fp32 rows; y is T (y_f32 = 0) or fp32 (y_f32 = 1).  If w2 != NULL a second LayerNorm
  * (w2,b2) is applied to the result of the first (ln_f followed by final_norm). */
 int itts_layernorm(const float* h, const float* w, const float* b, const float* w2, const float* b2, void* y, int y_f32,

@@ -1,12 +1,9 @@
 // Bandwidth-bound kernels: anti-aliased SnakeBeta activation, LayerNorm, embedding step, tanh -> PCM16.
 #include "common.h"
+#include "aa_tile.h"
 
 namespace itts {
 
-struct Fir24 {
-  float up[12];
-  float down[12];
-};
 
 // -------------------------------------------------------------------------------------------------------------------
 // Anti-aliased SnakeBeta, channels-last [B][T][C].
@@ -20,35 +17,22 @@ struct Fir24 {
 // rows are staged in LDS as fp32, so every input element is read from HBM once (the CUDA original re-reads a 44-element
 // window per thread from global memory).
 // -------------------------------------------------------------------------------------------------------------------
-constexpr int AA_R = 4;     // consecutive rows per thread (register blocking along time)
-// Output rows per workgroup, by channel-slice width: the largest tile whose two compute phases (ceil((TT+6)/R) pair groups
-// and TT/R output groups, times CS/4 channel quads) each fit one pass of the 256 threads.
-template <int CS> struct AaTile { static constexpr int TT = CS == 64 ? 56 : CS == 48 ? 76 : CS == 32 ? 120 : 160; };
-
-// sin for the periodic term: exact library sinf in fp32 (parity) mode, hardware v_sin_f32 for 16-bit storage types
-template <typename T>
-__device__ __forceinline__ float aa_sin(float x) {
-  if constexpr (sizeof(T) == 4) return sinf(x);
-  else return __sinf(x);
-}
-
 // Work is vectorised over 4 adjacent channels everywhere (8/16-byte LDS and global accesses) and register-blocked over
 // AA_R consecutive rows, so that a thread re-uses the FIR windows it has read (the un-blocked form was LDS-bandwidth
 // bound: 19 16-byte LDS reads per 4 outputs against 7 here):
 //   x tile  rows  t0-6 .. t0+TT+5            (XR = TT+12, replicate-clamped at load, kept in the storage type T)
 //   s tile  rows  m = 2*t0-6 .. 2*t0+2*TT+5  (SR = 2*TT+12, fp32), row pair (2i, 2i+1) from x rows i .. i+6
 //   y[t0+tt] = sum_j down[j] * s_tile[2*tt + 1 + j]
+// The tile computation lives in aa_tile.h (shared with the fused activation+convolution kernel).
 template <typename T, int CS>
 __global__ __launch_bounds__(256) void aa_snake_btc_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                             const float* __restrict__ alpha_log,
                                                             const float* __restrict__ beta_log, Fir24 f, int T_len, int C) {
-  constexpr int TT = AaTile<CS>::TT, R = AA_R;
-  constexpr int SR = 2 * TT + 12, NQ = TT + 6, C4 = CS / 4;
-  constexpr int QG = (NQ + R - 1) / R;       // pair groups (the last one may be partial)
-  constexpr int XRP = QG * R + 6;            // x rows the pair groups may touch (>= XR; the excess is never used)
+  constexpr int TT = AaTile<CS>::TT;
+  typedef AaShape<CS, TT> SH;
   typedef T t4 __attribute__((ext_vector_type(4)));
-  __shared__ __attribute__((aligned(16))) T xs[XRP * CS];
-  __shared__ __attribute__((aligned(16))) float ss[SR * CS];
+  __shared__ __attribute__((aligned(16))) T xs[SH::XRP * CS];
+  __shared__ __attribute__((aligned(16))) float ss[SH::SR * CS];
   __shared__ __attribute__((aligned(16))) float ca[CS];
   __shared__ __attribute__((aligned(16))) float cb[CS];
   const int t0 = blockIdx.x * TT;
@@ -57,112 +41,17 @@ __global__ __launch_bounds__(256) void aa_snake_btc_kernel(const T* __restrict__
   const int tid = threadIdx.x;
   const T* xb = x + (int64_t)b * T_len * C + c0;
   T* yb = y + (int64_t)b * T_len * C + c0;
-
   if (tid < CS) {
     ca[tid] = expf(alpha_log[c0 + tid]);
     cb[tid] = 1.0f / (expf(beta_log[c0 + tid]) + 1e-9f);
   }
-  // phase 1: x tile (rows past TT+12 only pad the last pair group; they are clamped like the rest and never contribute).
-  // All of a thread's loads are issued before the first LDS write: one HBM round trip per workgroup, not one per pass.
-  {
-    constexpr int NLD = (XRP * C4 + 255) / 256;
-    t4 v[NLD];
-#pragma unroll
-    for (int q = 0; q < NLD; ++q) {
-      int idx = min(tid + q * 256, XRP * C4 - 1);
-      int i = idx / C4, c4 = idx - i * C4;
-      int row = min(max(t0 - 6 + i, 0), T_len - 1);
-      v[q] = *reinterpret_cast<const t4*>(xb + (int64_t)row * C + c4 * 4);
+  aa_tile<T, CS, TT>(xb, C, T_len, t0, f, xs, ss, ca, cb, [&](int tt, int c4, const f32x4& acc) {
+    const int t = t0 + tt;
+    if (t < T_len) {
+      t4 o = {Elem<T>::from_f(acc[0]), Elem<T>::from_f(acc[1]), Elem<T>::from_f(acc[2]), Elem<T>::from_f(acc[3])};
+      *reinterpret_cast<t4*>(yb + (int64_t)t * C + c4 * 4) = o;
     }
-#pragma unroll
-    for (int q = 0; q < NLD; ++q) {
-      int idx = tid + q * 256;
-      int i = idx / C4, c4 = idx - i * C4;
-      if (idx < XRP * C4) *reinterpret_cast<t4*>(&xs[i * CS + c4 * 4]) = v[q];
-    }
-  }
-  __syncthreads();
-  // phase 2: upsample (polyphase, gain 2) + SnakeBeta -> s tile; R pairs per thread from R+6 x rows
-  for (int idx = tid; idx < QG * C4; idx += 256) {
-    int qg = idx / C4, c4 = idx - qg * C4;
-    const int i0 = qg * R;
-    f32x4 xv[R + 6];
-#pragma unroll
-    for (int k = 0; k < R + 6; ++k) {
-      t4 v = *reinterpret_cast<const t4*>(&xs[(i0 + k) * CS + c4 * 4]);
-      xv[k] = f32x4{Elem<T>::to_f(v[0]), Elem<T>::to_f(v[1]), Elem<T>::to_f(v[2]), Elem<T>::to_f(v[3])};
-    }
-    const f32x4 a = *reinterpret_cast<const f32x4*>(&ca[c4 * 4]);
-    const f32x4 ib = *reinterpret_cast<const f32x4*>(&cb[c4 * 4]);
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-      if (i0 + q < NQ) {
-        f32x4 ue = {0.f, 0.f, 0.f, 0.f}, uo = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          float we = f.up[11 - 2 * k], wo = f.up[10 - 2 * k];  // even: x[i-3+k]*up[11-2k]; odd: x[i-2+k]*up[10-2k]
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            ue[e] = fmaf(xv[q + k][e], we, ue[e]);
-            uo[e] = fmaf(xv[q + k + 1][e], wo, uo[e]);
-          }
-        }
-        f32x4 se, so;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float u = 2.0f * ue[e];
-          float sn = aa_sin<T>(u * a[e]);
-          se[e] = u + ib[e] * sn * sn;
-          u = 2.0f * uo[e];
-          sn = aa_sin<T>(u * a[e]);
-          so[e] = u + ib[e] * sn * sn;
-        }
-        *reinterpret_cast<f32x4*>(&ss[(2 * (i0 + q)) * CS + c4 * 4]) = se;
-        *reinterpret_cast<f32x4*>(&ss[(2 * (i0 + q) + 1) * CS + c4 * 4]) = so;
-      }
-    }
-  }
-  __syncthreads();
-  // phase 2b: replicate padding of the UPSAMPLED signal at the sequence ends (block-uniform conditions)
-  const int m_base = 2 * t0 - 6;
-  if (m_base < 0) {
-    for (int idx = tid; idx < (-m_base) * CS; idx += 256) {
-      int mi = idx / CS, c = idx - mi * CS;
-      ss[mi * CS + c] = ss[(-m_base) * CS + c];
-    }
-    __syncthreads();
-  }
-  if (m_base + SR > 2 * T_len) {
-    const int last = 2 * T_len - 1 - m_base;  // tile row of m = 2T-1
-    for (int idx = tid; idx < (SR - 1 - last) * CS; idx += 256) {
-      int mi = last + 1 + idx / CS, c = idx % CS;
-      ss[mi * CS + c] = ss[last * CS + c];
-    }
-    __syncthreads();
-  }
-  // phase 3: 12-tap low-pass, stride 2; R outputs per thread from 2R+10 s rows
-  static_assert(TT % R == 0, "row groups tile the workgroup tile");
-  for (int idx = tid; idx < (TT / R) * C4; idx += 256) {
-    int tg = idx / C4, c4 = idx - tg * C4;
-    const int tt0 = tg * R;
-    if (t0 + tt0 >= T_len) continue;
-    f32x4 sv[2 * R + 10];
-#pragma unroll
-    for (int j = 0; j < 2 * R + 10; ++j) sv[j] = *reinterpret_cast<const f32x4*>(&ss[(2 * tt0 + 1 + j) * CS + c4 * 4]);
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < 12; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = fmaf(f.down[j], sv[2 * q + j][e], acc[e]);
-      const int t = t0 + tt0 + q;
-      if (t < T_len) {
-        t4 o = {Elem<T>::from_f(acc[0]), Elem<T>::from_f(acc[1]), Elem<T>::from_f(acc[2]), Elem<T>::from_f(acc[3])};
-        *reinterpret_cast<t4*>(yb + (int64_t)t * C + c4 * 4) = o;
-      }
-    }
-  }
+  });
 }
 
 // Reference-op layout [B][C][T] (drop-in for anti_alias_activation_cuda.forward): one thread per output sample.

@@ -156,7 +156,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f32x4 (&
         for (int jj = 0; jj < 4; ++jj) {
           float v = acc[tm0 + u][tn][jj] + bs[jj];
           if (p.act == 1) v = gelu_new(v);
-          v = (v + (has_r ? rv[u][jj] : 0.f)) * p.scale + (has_a ? av[u][jj] : 0.f);
+          v = fmaf(v + (has_r ? rv[u][jj] : 0.f), p.scale, has_a ? av[u][jj] : 0.f);  // explicit fma: same rounding in every instantiation
           o[jj] = v;
         }
         if constexpr (VEC) st4(offs[u][0], o);
@@ -653,15 +653,17 @@ static int dispatch_conv(const ConvParams& p, hipStream_t s) {
 
 using namespace itts;
 
-extern "C" int itts_gemm_conv(const itts_conv_args* a, void* stream) {
-  ITTS_REQUIRE(a && a->x && a->wp && a->y, "itts_gemm_conv: null pointer");
-  ITTS_REQUIRE(a->B >= 0 && a->Tin >= 0 && a->Tout >= 0 && a->Cin > 0 && a->N > 0 && a->taps > 0 && a->dil >= 0,
-               "itts_gemm_conv: bad shape");
-  ITTS_REQUIRE(a->Cin % 8 == 0, "itts_gemm_conv: Cin=%d must be a multiple of 8", a->Cin);
-  ITTS_REQUIRE((a->taps - 1) * a->dil <= CV_MAX_HALO, "itts_gemm_conv: (taps-1)*dil = %d exceeds %d", (a->taps - 1) * a->dil,
-               CV_MAX_HALO);
-  if (a->B == 0 || a->Tout == 0) return ITTS_OK;
-  ConvParams p;
+static int conv_params_from_args(const itts_conv_args* a, ConvParams& p, const char* who) {
+  if (!(a && a->x && a->wp && a->y)) { set_error("%s: null pointer", who); return ITTS_ERR_INVALID; }
+  if (!(a->B >= 0 && a->Tin >= 0 && a->Tout >= 0 && a->Cin > 0 && a->N > 0 && a->taps > 0 && a->dil >= 0)) {
+    set_error("%s: bad shape", who);
+    return ITTS_ERR_INVALID;
+  }
+  if (a->Cin % 8 != 0) { set_error("%s: Cin=%d must be a multiple of 8", who, a->Cin); return ITTS_ERR_INVALID; }
+  if ((a->taps - 1) * a->dil > CV_MAX_HALO) {
+    set_error("%s: (taps-1)*dil = %d exceeds %d", who, (a->taps - 1) * a->dil, CV_MAX_HALO);
+    return ITTS_ERR_INVALID;
+  }
   p.B = a->B;
   p.Tin = a->Tin;
   p.Tout = a->Tout;
@@ -687,6 +689,15 @@ extern "C" int itts_gemm_conv(const itts_conv_args* a, void* stream) {
   const int ks = a->dtype == ITTS_F32 ? 16 : 32;
   p.NT = (a->N + 15) / 16;
   p.KT = (a->Cin + ks - 1) / ks;
+  p.MB = p.NB = p.GM = 1;
+  return ITTS_OK;
+}
+
+extern "C" int itts_gemm_conv(const itts_conv_args* a, void* stream) {
+  ConvParams p;
+  int rc = conv_params_from_args(a, p, "itts_gemm_conv");
+  if (rc != ITTS_OK) return rc;
+  if (a->B == 0 || a->Tout == 0) return ITTS_OK;
   hipStream_t s = (hipStream_t)stream;
   switch (a->dtype) {
     case ITTS_F32:
