@@ -238,3 +238,28 @@ def test_beam_oracle_small_cases():
             bs.step(r2.normal(size=(2, 8)).astype(np.float32))
         runs.append(bs.finalize().tolist())
     assert runs[0] == runs[1]
+
+
+def test_cli_exit_codes(tmp_path, capsys):
+    """indextts/cli.py:10-42: exit 1 on empty text, missing voice, missing config, existing output without --force;
+    without a GPU the run stops with exit 1 before any model is loaded (this build has no CPU path)."""
+    from indextts.cli import main
+    voice, cfg, out = tmp_path / "v.wav", tmp_path / "config.yaml", tmp_path / "gen.wav"
+    voice.write_bytes(b"RIFF")
+    cfg.write_text("version: 1.5\n")
+
+    def code(argv):
+        with pytest.raises(SystemExit) as e:
+            main(argv)
+        capsys.readouterr()
+        return e.value.code
+
+    assert code(["   ", "-v", str(voice), "-c", str(cfg)]) == 1
+    assert code(["hello", "-v", str(tmp_path / "nope.wav"), "-c", str(cfg)]) == 1
+    assert code(["hello", "-v", str(voice), "-c", str(tmp_path / "nope.yaml")]) == 1
+    out.write_bytes(b"x")
+    assert code(["hello", "-v", str(voice), "-c", str(cfg), "-o", str(out)]) == 1
+    assert out.exists()
+    if not torch.cuda.is_available():
+        assert code(["hello", "-v", str(voice), "-c", str(cfg), "-o", str(out), "-f"]) == 1
+        assert not out.exists()   # --force removed the stale output before the device check, like the reference
