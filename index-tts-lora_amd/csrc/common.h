@@ -78,6 +78,12 @@ __device__ __forceinline__ F ld16(const void* p) {
   B16 v = *reinterpret_cast<const B16*>(p);
   return __builtin_bit_cast(F, v);
 }
+// 16-byte load with the non-temporal cache policy: for bytes a launch reads exactly once (streamed weights, KV rows)
+template <typename F>
+__device__ __forceinline__ F ld16_nt(const void* p) {
+  u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  return __builtin_bit_cast(F, v);
+}
 template <typename F>
 __device__ __forceinline__ void st16(void* p, F f) {
   *reinterpret_cast<B16*>(p) = __builtin_bit_cast(B16, f);
