@@ -221,12 +221,8 @@ def main():
     with contextlib.redirect_stdout(sys.stderr):  # keep stdout for the single JSON line
         tts = IndexTTS.from_weights(cfg, gsd_d, bsd_d, device=device,
                                     precision_config={"gpt": "bf16", "vocoder": "fp16"})
-    extra = []
     want_conc = args.schedule == "concurrent" or (world == 1 and not args.no_concurrency)
-    if want_conc:
-        with contextlib.redirect_stdout(sys.stderr):
-            extra = [IndexTTS.from_weights(cfg, gsd_d, bsd_d, device=device, precision_config={"gpt": "bf16", "vocoder": "fp16"})
-                     for _ in range(max(2, args.inflight) - 1)]
+    extra = [tts.replica() for _ in range(max(2, args.inflight) - 1)] if want_conc else []  # shared weights, private state
     del gsd_d, bsd_d
     cond_mel, texts = make_inputs(rank, device)
     force = [MEL_TOKENS] * BATCH

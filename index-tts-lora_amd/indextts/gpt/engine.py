@@ -95,6 +95,19 @@ class GPTEngine:
         self.weight_bytes = sum(t.numel() * t.element_size() for l in self.layers for t in
                                 (l["w_qkv"], l["w_o"], l["w_fc"], l["w_pr"])) + self.w_head.numel()
 
+    def fork(self) -> "GPTEngine":
+        """A second engine over the SAME packed weights (read-only, shared) with its own KV cache, scratch buffers, loop
+        state and captured graphs: what a concurrent request needs (infer.RequestPool)."""
+        import copy
+        e = copy.copy(self)
+        e._cap_b = e._cap_s = 0
+        e._graphs = {}
+        e._side = None
+        e._beam_cap = (0, 0)
+        e._sink = torch.zeros(4, dtype=torch.int32, device=self.device)
+        e.ln_cnt = torch.zeros_like(self.ln_cnt)
+        return e
+
     # ------------------------------------------------------------------------------------------------ buffers
     def _ensure(self, B: int, smax: int):
         if B <= self._cap_b and smax <= self._cap_s:

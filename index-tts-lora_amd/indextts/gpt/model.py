@@ -190,6 +190,14 @@ class UnifiedVoice:
         out = self.engine.decode(max_new, sp, force_stop=force_stop, return_logits=return_logits)
         return out
 
+    def replica(self) -> "UnifiedVoice":
+        """Same weights (shared tensors), separate decode state: see GPTEngine.fork()."""
+        import copy
+        r = copy.copy(self)
+        r.engine = self.engine.fork()
+        r.inference_model = r.engine
+        return r
+
     # ---- teacher-forced latent pass -----------------------------------------------------------------------------
     def forward(self, speech_conditioning_latent, text_inputs, text_lengths, mel_codes, wav_lengths,
                 cond_mel_lengths=None, types=None, text_first=True, raw_mels=None, return_attentions=False,

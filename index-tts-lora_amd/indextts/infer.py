@@ -156,6 +156,16 @@ class IndexTTS:
         return cls(model_dir="", is_fp16=is_fp16, device=device, precision_config=precision_config, _cfg=cfg,
                    _weights={"gpt": gpt_state_dict, "bigvgan": bigvgan_state_dict})
 
+    def replica(self) -> "IndexTTS":
+        """Another instance over the same weight tensors (GPT packed weights, conditioner, vocoder) with its own KV cache,
+        decode state, prompt caches and captured graphs -- for RequestPool."""
+        import copy
+        r = copy.copy(self)
+        r.gpt = self.gpt.replica()
+        r._feat_graphs = {}
+        r.cache_audio_prompt = r.cache_cond_mel = r._cache_conds = r._cache_spk = None
+        return r
+
     # ------------------------------------------------------------------------------------------------ helpers
     def remove_long_silence(self, codes: torch.Tensor, silent_token=52, max_consecutive=30):
         """infer.py:446-497: cut at the first stop token; when a row holds more than `max_consecutive` silent tokens,
@@ -662,8 +672,8 @@ class RequestPool:
     its own IndexTTS instance, host thread and HIP stream.  A single request's token loop is a chain of ~170 dependent
     microsecond-scale launches per token and leaves most CUs idle; the loops of different requests interleave on the
     chip (measured on MI355X, batch 32: 1.4x the audio-seconds/s of one request at a time with two in flight).
-    Instances are full replicas (weights included: 1.3 GB each at bf16/fp16 out of 288 GB), so no state is shared.
-    Results are those of infer_batch() on the same instance."""
+    Instances come from IndexTTS.replica() (shared read-only weights, private KV cache / state / graphs) or are
+    independent objects.  Results are those of infer_batch() on one instance."""
 
     class _Job:
         def __init__(self):
@@ -674,6 +684,10 @@ class RequestPool:
             if self.err is not None:
                 raise self.err
             return self.out
+
+    @classmethod
+    def of(cls, tts: "IndexTTS", inflight: int = 2) -> "RequestPool":
+        return cls([tts] + [tts.replica() for _ in range(max(1, inflight) - 1)])
 
     def __init__(self, instances: List["IndexTTS"]):
         assert instances, "need at least one instance"

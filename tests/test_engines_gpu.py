@@ -282,9 +282,10 @@ def test_request_pool_matches_serial_infer_batch():
     from indextts.infer import IndexTTS, RequestPool
     cfg = weights.reference_config()
     cfg["gpt"]["layers"] = 2
-    gsd, bsd = weights.gpt_state_dict(2), weights.bigvgan_state_dict()
-    insts = [IndexTTS.from_weights(cfg, gsd, bsd, device="cuda:0", precision_config={"gpt": "bf16", "vocoder": "fp16"})
-             for _ in range(2)]
+    first = IndexTTS.from_weights(cfg, weights.gpt_state_dict(2), weights.bigvgan_state_dict(), device="cuda:0",
+                                  precision_config={"gpt": "bf16", "vocoder": "fp16"})
+    insts = [first, first.replica()]          # shared weights, private KV cache / state / graphs
+    assert insts[1].gpt.engine.layers is first.gpt.engine.layers and insts[1].gpt.engine is not first.gpt.engine
     cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
     rng = np.random.default_rng(9)
     batches = [[torch.from_numpy(rng.integers(2, 12000, size=int(n))).to(torch.int32) for n in rng.integers(5, 20, size=4)]
