@@ -186,6 +186,13 @@ int itts_attn_decode(const void* q, const void* kcache, const void* vcache, void
 int itts_attn_prefill(const void* qkv, void* out, void* kcache, void* vcache, const int32_t* pad, int B, int S, int H,
                       int smax, int dtype, void* stream);
 
+/* The same over PACKED rows: no padding rows exist; the rows of batch element b are [row_off[b], row_off[b+1]) of qkv /
+ * out (row_off: int32 [B+1], device), each at most Smax long, plain causal attention inside each element.  With caches,
+ * local row i of element b is written to cache row cache_shift[b] + i (cache_shift NULL = 0): with cache_shift = the
+ * element's left padding this reproduces the cache layout of the padded form. */
+int itts_attn_prefill_packed(const void* qkv, void* out, void* kcache, void* vcache, const int32_t* row_off,
+                             const int32_t* cache_shift, int B, int Smax, int H, int smax, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Token selection for one decode step, on device (no host sync in the loop).
  * state (int32[8], device): [0] = step k (number of tokens already generated), [1] = cache position of the NEXT token

@@ -140,7 +140,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                             T* __restrict__ kc, T* __restrict__ vc,
-                                                            const int32_t* __restrict__ pad, int S, int H, int smax) {
+                                                            const int32_t* __restrict__ pad, int S, int H, int smax,
+                                                            const int32_t* __restrict__ row_off,
+                                                            const int32_t* __restrict__ cache_shift) {
   typedef Elem<T> EL;
   typedef typename EL::frag frag;
   constexpr int E = EL::E, KS = EL::KS, NKS = HD / KS;
@@ -154,8 +156,14 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const T* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int D = H * HD;
-  const int j0 = pad ? pad[b] : 0;
-  const T* base = qkv + (int64_t)b * S * 3 * D;
+  // packed form (row_off != NULL): the rows of batch element b are [row_off[b], row_off[b+1]) of qkv / out, there is no
+  // padding row at all, and cache row = cache_shift[b] + local index (the left-padded cache layout of the decode loop)
+  const int rbeg = row_off ? row_off[b] : b * S;
+  if (row_off) S = row_off[b + 1] - rbeg;
+  if (q0 >= S) return;  // workgroup-uniform
+  const int cshift = (row_off && cache_shift) ? cache_shift[b] : 0;
+  const int j0 = (pad && !row_off) ? pad[b] : 0;
+  const T* base = qkv + (int64_t)rbeg * 3 * D;
 
   frag qf[NKS];
   {
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const T* __restrict__
         kv = ld16<frag>(src);
         vv = ld16<frag>(src + D);
         if (kc != nullptr && jt == q0) {
-          const int64_t o = (((int64_t)b * H + h) * smax + key) * HD + dc * E;
+          const int64_t o = (((int64_t)b * H + h) * smax + key + cshift) * HD + dc * E;
           st16(kc + o, kv);
           st16(vc + o, vv);
         }
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const T* __restrict__
     const int q = q0 + wave * 16 + 4 * g + j;
     if (q >= S) continue;
     const float inv = l[j] > 0.f ? 1.0f / l[j] : 0.f;
-    T* orow = out + ((int64_t)b * S + q) * D + h * HD;
+    T* orow = out + ((int64_t)rbeg + q) * D + h * HD;
 #pragma unroll
     for (int n = 0; n < 4; ++n) orow[16 * n + c] = EL::from_f(O[n][j] * inv);
   }
@@ -298,8 +306,8 @@ extern "C" int itts_attn_decode(const void* q, const void* kcache, const void* v
   return check_launch("itts_attn_decode");
 }
 
-extern "C" int itts_attn_prefill(const void* qkv, void* out, void* kcache, void* vcache, const int32_t* pad, int B, int S,
-                                 int H, int smax, int dtype, void* stream) {
+static int attn_prefill_impl(const void* qkv, void* out, void* kcache, void* vcache, const int32_t* pad, int B, int S, int H,
+                             int smax, int dtype, const int32_t* row_off, const int32_t* cache_shift, void* stream) {
   ITTS_REQUIRE(qkv && out, "itts_attn_prefill: null pointer");
   ITTS_REQUIRE((kcache == nullptr) == (vcache == nullptr), "itts_attn_prefill: pass both caches or neither");
   ITTS_REQUIRE(B > 0 && S > 0 && H > 0 && (!kcache || S <= smax), "itts_attn_prefill: bad shape B=%d S=%d H=%d smax=%d", B, S, H, smax);
@@ -308,16 +316,27 @@ extern "C" int itts_attn_prefill(const void* qkv, void* out, void* kcache, void*
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
     case ITTS_F32:
-      hipLaunchKernelGGL(attn_prefill_kernel<float>, grid, block, 0, s, (const float*)qkv, (float*)out, (float*)kcache, (float*)vcache, pad, S, H, smax);
+      hipLaunchKernelGGL(attn_prefill_kernel<float>, grid, block, 0, s, (const float*)qkv, (float*)out, (float*)kcache, (float*)vcache, pad, S, H, smax, row_off, cache_shift);
       break;
     case ITTS_BF16:
-      hipLaunchKernelGGL(attn_prefill_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, (bf16_t*)kcache, (bf16_t*)vcache, pad, S, H, smax);
+      hipLaunchKernelGGL(attn_prefill_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, (bf16_t*)kcache, (bf16_t*)vcache, pad, S, H, smax, row_off, cache_shift);
       break;
     case ITTS_F16:
-      hipLaunchKernelGGL(attn_prefill_kernel<f16_t>, grid, block, 0, s, (const f16_t*)qkv, (f16_t*)out, (f16_t*)kcache, (f16_t*)vcache, pad, S, H, smax);
+      hipLaunchKernelGGL(attn_prefill_kernel<f16_t>, grid, block, 0, s, (const f16_t*)qkv, (f16_t*)out, (f16_t*)kcache, (f16_t*)vcache, pad, S, H, smax, row_off, cache_shift);
       break;
     default:
       ITTS_REQUIRE(false, "itts_attn_prefill: unknown dtype %d", dtype);
   }
   return check_launch("itts_attn_prefill");
+}
+
+extern "C" int itts_attn_prefill(const void* qkv, void* out, void* kcache, void* vcache, const int32_t* pad, int B, int S,
+                                 int H, int smax, int dtype, void* stream) {
+  return attn_prefill_impl(qkv, out, kcache, vcache, pad, B, S, H, smax, dtype, nullptr, nullptr, stream);
+}
+
+extern "C" int itts_attn_prefill_packed(const void* qkv, void* out, void* kcache, void* vcache, const int32_t* row_off,
+                                        const int32_t* cache_shift, int B, int Smax, int H, int smax, int dtype, void* stream) {
+  ITTS_REQUIRE(row_off, "itts_attn_prefill_packed: row_off is null");
+  return attn_prefill_impl(qkv, out, kcache, vcache, nullptr, B, Smax, H, smax, dtype, row_off, cache_shift, stream);
 }

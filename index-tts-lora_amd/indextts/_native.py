@@ -79,6 +79,8 @@ _SIGNATURES = {
                                    C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_attn_prefill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "itts_attn_prefill_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_sample": (C.c_int, [C.POINTER(SampleArgs), C.c_void_p]),
     "itts_beam_step": (C.c_int, [C.POINTER(BeamArgs), C.c_void_p]),
     "itts_beam_reorder_kv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -243,6 +245,12 @@ def attn_decode(q, kcache, vcache, out, pad, pos, B, H, smax):
 def attn_prefill(qkv, out, kcache, vcache, pad, B, S, H, smax):
     _check(lib().itts_attn_prefill(_p(qkv), _p(out), _p(kcache), _p(vcache), _p(pad), B, S, H, smax, dt(qkv.dtype),
                                    _stream()), "itts_attn_prefill")
+
+
+def attn_prefill_packed(qkv, out, kcache, vcache, row_off, cache_shift, B, Smax, H, smax):
+    """Packed rows (no padding): row_off int32 [B+1]; cache row of local row i = cache_shift[b] + i."""
+    _check(lib().itts_attn_prefill_packed(_p(qkv), _p(out), _p(kcache), _p(vcache), _p(row_off), _p(cache_shift), B, Smax, H,
+                                          smax, dt(qkv.dtype), _stream()), "itts_attn_prefill_packed")
 
 
 def sample(logits, tokens, history, finished, state, extra_ids, force_stop, rep_penalty, temperature, top_k, top_p,

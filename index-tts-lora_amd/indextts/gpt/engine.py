@@ -137,10 +137,12 @@ class GPTEngine:
         self._graphs.clear()
 
     # ------------------------------------------------------------------------------------------------ big-M passes
-    def _blocks_full(self, h, B, S, pad, use_cache):
-        """All transformer blocks over h fp32 [B*S, D] (in place).  pad: int32 [B] device or None."""
+    def _blocks_full(self, h, B, S, pad, use_cache, row_off=None, cache_shift=None):
+        """All transformer blocks over h fp32 [M, D] (in place).  Padded form: M = B*S rows, pad int32 [B] (left padding)
+        or None.  Packed form (row_off int32 [B+1] on device): only real rows exist, batch element b owns rows
+        [row_off[b], row_off[b+1]), S is the longest element, cache row = cache_shift[b] + local row."""
         T, D, H = self.dtype, self.D, self.H
-        M = B * S
+        M = h.shape[0]
         dev = self.device
         xn = torch.empty(M, D, dtype=T, device=dev)
         qkv = torch.empty(M, 3 * D, dtype=T, device=dev)
@@ -149,8 +151,11 @@ class GPTEngine:
         for i, l in enumerate(self.layers):
             nat.layernorm(h, l["ln1"][0], l["ln1"][1], xn)
             nat.gemm_conv(T, 1, M, M, D, 3 * D, l["w_qkv"], xn, qkv, bias=l["b_qkv"])
-            nat.attn_prefill(qkv, att, self.kc[i] if use_cache else None, self.vc[i] if use_cache else None, pad, B, S, H,
-                             self._cap_s)
+            kc, vc = (self.kc[i], self.vc[i]) if use_cache else (None, None)
+            if row_off is None:
+                nat.attn_prefill(qkv, att, kc, vc, pad, B, S, H, self._cap_s)
+            else:
+                nat.attn_prefill_packed(qkv, att, kc, vc, row_off, cache_shift, B, S, H, self._cap_s)
             nat.gemm_conv(T, 1, M, M, D, D, l["w_o"], att, h, bias=l["b_o"], y_f32=True, resid=h)
             nat.layernorm(h, l["ln2"][0], l["ln2"][1], xn)
             nat.gemm_conv(T, 1, M, M, D, 4 * D, l["w_fc"], xn, ff, bias=l["b_fc"], act=1)
@@ -169,16 +174,28 @@ class GPTEngine:
 
     def prefill(self, prefix_emb: torch.Tensor, pad: torch.Tensor, max_new: int):
         """prefix_emb fp32 [B,P,D] (left-padded with zeros), pad int [B].  Runs prefix + start token (mel position 0,
-        model.py:152-162), fills the KV cache rows [0,P], leaves logits of the last position in self.logits."""
+        model.py:152-162), fills the KV cache rows [pad_b, P] of every element, leaves logits of the last position in
+        self.logits.  The left-padding rows are never computed: the real rows are packed (one gather), the GEMMs run over
+        sum(P + 1 - pad_b) rows instead of B*(P+1), and the attention kernel writes each element's keys at its padded
+        cache position, so the decode loop sees the reference's left-padded cache layout."""
         B, P, D = prefix_emb.shape
         S = P + 1
         self._ensure(B, S + max_new + 1)
+        dev = self.device
         start = self.mel_emb[self.start_mel] + self.mel_pos[0]
-        emb = torch.cat([prefix_emb.to(self.device, torch.float32), start.expand(B, 1, D)], dim=1).contiguous()
-        self.pad[:B] = pad.to(self.device, torch.int32)
-        h = self._blocks_full(emb.view(B * S, D), B, S, self.pad, True)
-        last = h.view(B, S, D)[:, -1, :].contiguous()
-        self._head(last, B)
+        emb = torch.cat([prefix_emb.to(dev, torch.float32), start.expand(B, 1, D)], dim=1).contiguous()
+        pad_h = [int(v) for v in torch.as_tensor(pad).tolist()]
+        self.pad[:B] = torch.tensor(pad_h, dtype=torch.int32).to(dev)
+        lens = [S - p for p in pad_h]
+        off = [0]
+        for n in lens:
+            off.append(off[-1] + n)
+        idx = torch.cat([torch.arange(b * S + pad_h[b], (b + 1) * S) for b in range(B)])
+        meta = torch.tensor(off + [b_off - 1 for b_off in off[1:]], dtype=torch.int32).to(dev)   # row_off | last rows
+        row_off, last_rows = meta[: B + 1], meta[B + 1:].long()
+        h = emb.view(B * S, D)[idx.to(dev)]
+        h = self._blocks_full(h, B, S, None, True, row_off=row_off, cache_shift=self.pad[:B])
+        self._head(h[last_rows].contiguous(), B)
         self.state.zero_()
         self.state[1] = S - 1
         self.finished[:B] = 0
@@ -186,15 +203,32 @@ class GPTEngine:
         self._B, self._S = B, S
         return self.logits[:B]
 
-    def latent(self, emb: torch.Tensor) -> torch.Tensor:
+    def latent(self, emb: torch.Tensor, lengths=None) -> torch.Tensor:
         """Teacher-forced pass (model.py:459-474): emb fp32 [B,S,D] (right-padded rows allowed) ->
-        final_norm(ln_f(blocks(emb))) fp32 [B,S,D]."""
+        final_norm(ln_f(blocks(emb))) fp32 [B,S,D].  With `lengths` (host ints, real rows per element) only the real rows
+        are computed (packed); the padding rows of the result are zero."""
         B, S, D = emb.shape
         self._ensure(1, 64)
-        h = emb.to(self.device, torch.float32).contiguous().view(B * S, D).clone()
-        self._blocks_full(h, B, S, None, False)
-        out = torch.empty_like(h)
-        nat.layernorm(h, self.ln_f[0], self.ln_f[1], out, self.final_norm[0], self.final_norm[1])
+        dev = self.device
+        src = emb.to(dev, torch.float32).contiguous().view(B * S, D)
+        if lengths is None:
+            h = src.clone()
+            self._blocks_full(h, B, S, None, False)
+            out = torch.empty_like(h)
+            nat.layernorm(h, self.ln_f[0], self.ln_f[1], out, self.final_norm[0], self.final_norm[1])
+            return out.view(B, S, D)
+        lens = [int(n) for n in lengths]
+        off = [0]
+        for n in lens:
+            off.append(off[-1] + n)
+        idx = torch.cat([torch.arange(b * S, b * S + lens[b]) for b in range(B)]).to(dev)
+        row_off = torch.tensor(off, dtype=torch.int32).to(dev)
+        h = src[idx]
+        self._blocks_full(h, B, max(lens), None, False, row_off=row_off)
+        packed = torch.empty_like(h)
+        nat.layernorm(h, self.ln_f[0], self.ln_f[1], packed, self.final_norm[0], self.final_norm[1])
+        out = torch.zeros(B * S, D, dtype=torch.float32, device=dev)
+        out[idx] = packed
         return out.view(B, S, D)
 
     # ------------------------------------------------------------------------------------------------ decode loop

@@ -377,7 +377,7 @@ class IndexTTS:
         batch[:, :nc] = conds[0].to(dev, torch.float32)
         batch[idx[0, :n_t], idx[1, :n_t]] = eng.text_emb[idx[2, :n_t]] + eng.text_pos[idx[3, :n_t]]
         batch[idx[0, n_t:], idx[1, n_t:]] = eng.mel_emb[idx[2, n_t:]] + eng.mel_pos[idx[3, n_t:]]
-        enc = eng.latent(batch)
+        enc = eng.latent(batch, lengths=[s0 + n + 2 for s0, n in spans])   # real rows only (cond | text | mel incl. start/stop)
         return [enc[i, s0: s0 + n] for i, (s0, n) in enumerate(spans)]
 
     def _finish(self, wavs, output_path, start_time, gpt_gen_time, gpt_forward_time, bigvgan_time, sampling_rate=24000):

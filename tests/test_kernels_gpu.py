@@ -496,3 +496,31 @@ def test_gemm_skinny_fused_layernorm_stage(nat, dtype, nslab):
         assert torch.equal(x, x_ref) and torch.equal(h, h_ref), f"round {it}"
         assert torch.equal(y, y_ref), f"round {it}"
         assert cnt[it % 2].item() == M and cnt[(it + 1) % 2].item() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attn_prefill_packed_equals_left_padded(nat, dtype):
+    """Packed rows (no padding rows at all) give the attention outputs and the KV cache contents of the left-padded form
+    for every real position."""
+    B, H, S, smax = 3, 2, 150, 192
+    D = H * 64
+    pads = [0, 37, 101]
+    qkv = rnd(B, S, 3 * D, seed=95).to(dtype)
+    pad = torch.tensor(pads, dtype=torch.int32, device=DEV)
+    out_ref = torch.empty(B, S, D, dtype=dtype, device=DEV)
+    kc_ref, vc_ref = torch.zeros(B, H, smax, 64, dtype=dtype, device=DEV), torch.zeros(B, H, smax, 64, dtype=dtype, device=DEV)
+    nat.attn_prefill(qkv, out_ref, kc_ref, vc_ref, pad, B, S, H, smax)
+    rows = torch.cat([torch.arange(b * S + pads[b], (b + 1) * S) for b in range(B)]).to(DEV)
+    off = [0]
+    for p in pads:
+        off.append(off[-1] + S - p)
+    row_off = torch.tensor(off, dtype=torch.int32, device=DEV)
+    q_p = qkv.view(B * S, 3 * D)[rows].contiguous()
+    out_p = torch.empty(q_p.shape[0], D, dtype=dtype, device=DEV)
+    kc, vc = torch.zeros_like(kc_ref), torch.zeros_like(vc_ref)
+    nat.attn_prefill_packed(q_p, out_p, kc, vc, row_off, pad, B, S, H, smax)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert (out_p.float() - out_ref.view(B * S, D)[rows].float()).abs().max().item() < tol
+    for b in range(B):
+        assert torch.equal(kc[b, :, pads[b]:S], kc_ref[b, :, pads[b]:S]) and torch.equal(vc[b, :, pads[b]:S], vc_ref[b, :, pads[b]:S])
+        assert kc[b, :, :pads[b]].abs().max().item() == 0 if pads[b] else True
