@@ -718,7 +718,9 @@ class RequestPool:
 
     def warm_up(self, *args, rounds=2, **kw):
         """Run `rounds` requests on every instance, ONE INSTANCE AT A TIME: the first calls capture CUDA graphs, and a
-        capture (global error mode) must not see another thread allocating or synchronising."""
+        capture (global error mode) must not see another thread allocating or synchronising.  Call it once for every
+        (batch size, generation settings, prompt length) combination that will be served concurrently; a capture that
+        happens later, while other requests are running, fails that request loudly (result() raises)."""
         for i in range(len(self.instances)):
             for _ in range(rounds):
                 self.submit(*args, _instance=i, **kw).result()
