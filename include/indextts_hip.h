@@ -166,11 +166,6 @@ int itts_layernorm(const float* h, const float* w, const float* b, const float* 
 int itts_ln_reduce(float* h, const float* slab, int nslab, const float* bias, const float* w, const float* b,
                    const float* w2, const float* b2, void* y, int M, int D, int dtype, void* stream);
 
-/* Cache warm-up: reads up to 4 byte ranges (16-byte aligned) with `blocks` workgroups and discards them, so that the
- * data sits in the Infinity Cache when the kernels that need it start (used on a side stream for the next transformer
- * block's weights).  sink: 4 writable bytes (never written in practice). */
-int itts_prefetch(const void* const* ptrs, const int64_t* bytes, int n, int blocks, void* sink, void* stream);
-
 /* h[b][:] = table[tokens[b]][:] + pos_table[*step + pos_add][:]   (fp32 tables, fp32 h) */
 int itts_embed_step(const int32_t* tokens, const float* table, const float* pos_table, const int32_t* step, int pos_add,
                     float* h, int B, int D, void* stream);

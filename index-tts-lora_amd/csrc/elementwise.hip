@@ -414,34 +414,6 @@ __global__ __launch_bounds__(256) void tanh_pcm_kernel(const T* __restrict__ x, 
   }
 }
 
-// Streams up to 4 byte ranges through the cache hierarchy without keeping them: pulls the NEXT block's weights into the
-// 256-MiB Infinity Cache while the current block's (latency-bound) kernels run on another stream.
-struct PrefetchRanges {
-  const void* ptr[4];
-  int64_t bytes[4];
-  int n;
-};
-__global__ __launch_bounds__(256) void prefetch_kernel(PrefetchRanges r, uint32_t* __restrict__ sink) {
-  uint32_t acc = 0;
-  for (int k = 0; k < r.n; ++k) {
-    const u32x4* p = reinterpret_cast<const u32x4*>(r.ptr[k]);
-    int64_t n16 = r.bytes[k] / 16;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 7 * stride < n16; i += 8 * stride) {  // 8 independent 16-byte loads in flight per lane
-      u32x4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p[i + u * stride];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc ^= v[u][0] ^ v[u][1] ^ v[u][2] ^ v[u][3];
-    }
-    for (; i < n16; i += stride) {
-      u32x4 v = p[i];
-      acc ^= v[0] ^ v[1] ^ v[2] ^ v[3];
-    }
-  }
-  if (acc == 0x9E3779B9u && sink != nullptr) sink[0] = acc;  // practically never true; keeps the loads alive
-}
 
 }  // namespace itts
 
@@ -587,15 +559,3 @@ extern "C" int itts_tanh_pcm(const void* x, float* wav, int16_t* pcm, int64_t n,
   return check_launch("itts_tanh_pcm");
 }
 
-extern "C" int itts_prefetch(const void* const* ptrs, const int64_t* bytes, int n, int blocks, void* sink, void* stream) {
-  ITTS_REQUIRE(ptrs && bytes && n >= 0 && n <= 4 && blocks > 0, "itts_prefetch: bad arguments");
-  if (n == 0) return ITTS_OK;
-  PrefetchRanges r;
-  r.n = n;
-  for (int i = 0; i < 4; ++i) {
-    r.ptr[i] = i < n ? ptrs[i] : nullptr;
-    r.bytes[i] = i < n ? bytes[i] : 0;
-  }
-  hipLaunchKernelGGL(prefetch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, r, (uint32_t*)sink);
-  return check_launch("itts_prefetch");
-}

@@ -72,7 +72,6 @@ _SIGNATURES = {
                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_ln_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "itts_prefetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "itts_embed_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                   C.c_int, C.c_void_p]),
     "itts_attn_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -220,15 +219,6 @@ def ln_reduce(h, w, b, out, slab=None, nslab=0, bias=None, w2=None, b2=None):
     _check(lib().itts_ln_reduce(_p(h), _p(slab), nslab, _p(bias), _p(w), _p(b), _p(w2), _p(b2), _p(out), M, D,
                                 dt(out.dtype), _stream()), "itts_ln_reduce")
     return out
-
-
-def prefetch(tensors, blocks, sink):
-    """Warm the Infinity Cache with up to 4 device tensors (see itts_prefetch)."""
-    n = len(tensors)
-    ptrs = (C.c_void_p * 4)(*[t.data_ptr() for t in tensors] + [None] * (4 - n))
-    sizes = (C.c_int64 * 4)(*[t.numel() * t.element_size() for t in tensors] + [0] * (4 - n))
-    _check(lib().itts_prefetch(C.cast(ptrs, C.c_void_p), C.cast(sizes, C.c_void_p), n, blocks, _p(sink), _stream()),
-           "itts_prefetch")
 
 
 def embed_step(tokens, table, pos_table, step, pos_add, h):

@@ -86,8 +86,6 @@ class GPTEngine:
         self._cap_b = self._cap_s = 0
         self._graphs = {}
         self.KSPLIT = 3  # split-K of the two N=1280 GEMMs of a block: 80 column tiles x 3 = 240 workgroups (one round of 256 CUs)
-        self.prefetch_blocks = int(os.environ.get("ITTS_PREFETCH_BLOCKS", "0"))  # side-stream weight prefetch: measured 1.5x SLOWER in-graph, off
-        self._side = None
         self.force_eager = False  # measurement aid: launch every kernel eagerly
         self.steps_per_graph = int(os.environ.get("ITTS_STEPS_PER_GRAPH", "1"))  # decode tokens per CUDA-graph replay; measured 1 > 2 > 4 > 8 (1297 / 1319 / 1342 / 1368 us per token)
         self._sink = torch.zeros(4, dtype=torch.int32, device=dev)
@@ -102,7 +100,6 @@ class GPTEngine:
         e = copy.copy(self)
         e._cap_b = e._cap_s = 0
         e._graphs = {}
-        e._side = None
         e._beam_cap = (0, 0)
         e._sink = torch.zeros(4, dtype=torch.int32, device=self.device)
         e.ln_cnt = torch.zeros_like(self.ln_cnt)
@@ -246,32 +243,12 @@ class GPTEngine:
         step, pos = self.state[0:1], self.state[1:2]
         h, xn = self.h[:B], self.xn[:B]
         slab = self.slab.view(-1)[: KS * B * D].view(KS, B, D)  # [ks][B][D] on a contiguous prefix of the buffer
-        # Side stream: while block i runs (latency-bound launches), block i+1's weights are pulled into the Infinity Cache.
-        main = torch.cuda.current_stream()
-        side = None
-        if self.prefetch_blocks > 0:
-            if self._side is None:
-                self._side = torch.cuda.Stream()
-            side = self._side
-
-        def prefetch(tensors):
-            if side is None:
-                return
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                nat.prefetch(tensors, self.prefetch_blocks, self._sink)
-
         nat.embed_step(self.tokens, self.mel_emb, self.mel_pos, step, 1, h)
         pending = None  # bias of an FC2 whose split-K slabs have not been folded into h yet
         mode = self.decode_mode
         if mode == 4 and B > 32:
             mode = 1  # the fused producer stage handles one 32-row GEMM launch
         for i, l in enumerate(self.layers):
-            if i + 1 < self.L:
-                n = self.layers[i + 1]
-                prefetch([n["w_qkv"], n["w_o"], n["w_fc"], n["w_pr"]])
-            else:
-                prefetch([self.w_head])
             # --- attention half
             if mode == 4:
                 ln = dict(h=h, w=l["ln1"][0], b=l["ln1"][1], counter=self.ln_cnt[2 * i: 2 * i + 1],
@@ -310,11 +287,7 @@ class GPTEngine:
             else:
                 nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], None, x=self.f, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS)
                 pending = l["b_pr"]
-        n0 = self.layers[0]
-        prefetch([n0["w_qkv"], n0["w_o"], n0["w_fc"], n0["w_pr"]])  # for the next token, under the head + sampling
         self._head(h, B, pending=None if pending is None else (slab, KS, pending))
-        if side is not None:
-            main.wait_stream(side)
 
     def _step_kernels(self, B, sp):
         self._step_transformer(B)
