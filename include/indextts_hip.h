@@ -53,7 +53,8 @@ extern "C" {
 int itts_abi_version(void);
 const char* itts_last_error(void);
 /* tuning/debug knob, not part of the product path: key 1 = column tiles per skinny-GEMM workgroup, key 2 = waves per
- * skinny-GEMM workgroup, key 3 = plain-GEMM kernel override (0 restores the built-in heuristic) */
+ * skinny-GEMM workgroup, key 3 = plain-GEMM kernel override (0 restores the built-in heuristic), key 4 = waves per
+ * decode-attention workgroup (4 or 8; measured equal) */
 int itts_debug_set(int key, int value);
 
 /* ------------------------------------------------------------------------------------------------------------------

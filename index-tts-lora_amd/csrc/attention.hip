@@ -27,8 +27,8 @@ __device__ __forceinline__ void softmax_merge(float& m, float& l, float m2, floa
   m = M;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ kc,
+template <typename T, int NWV>
+__global__ __launch_bounds__(NWV * 64) void attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ kc,
                                                            const T* __restrict__ vc, T* __restrict__ out,
                                                            const int32_t* __restrict__ pad, const int32_t* __restrict__ pos,
                                                            int H, int smax) {
@@ -37,8 +37,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
   constexpr int E = EL::E;
   constexpr int LPR = HD / E;        // lanes per row: 8 (16-bit) / 16 (fp32)
   constexpr int RPW = 64 / LPR;      // rows per wave-load: 8 / 4
-  __shared__ float w_m[4], w_l[4];
-  __shared__ float w_o[4][HD];
+  constexpr int CH = AD_CH * 4 / NWV;   // chunks per wave: a workgroup pass always covers 4 * RPW * AD_CH keys
+  __shared__ float w_m[NWV], w_l[NWV];
+  __shared__ float w_o[NWV][HD];
   const int h = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int part = lane % LPR, rg = lane / LPR;
@@ -58,24 +59,24 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
   for (int e = 0; e < E; ++e) o[e] = 0.f;
 
   for (int base = j0; base < ctx; base += 4 * RPW * AD_CH) {
-    frag kf[AD_CH], vf[AD_CH];
+    frag kf[CH], vf[CH];
 #pragma unroll
-    for (int i = 0; i < AD_CH; ++i) {
-      int j = base + (i * 4 + wave) * RPW + rg;
+    for (int i = 0; i < CH; ++i) {
+      int j = base + (i * NWV + wave) * RPW + rg;
       bool ok = j < ctx;
       kf[i] = ok ? ld16<frag>(kb + (int64_t)j * HD) : zero_frag<frag>();
       vf[i] = ok ? ld16<frag>(vb + (int64_t)j * HD) : zero_frag<frag>();
     }
-    float sc[AD_CH];
+    float sc[CH];
     float cmax = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < AD_CH; ++i) {
+    for (int i = 0; i < CH; ++i) {
       float d = 0.f;
 #pragma unroll
       for (int e = 0; e < E; ++e) d = fmaf(qf[e], EL::to_f(kf[i][e]), d);
 #pragma unroll
       for (int off = 1; off < LPR; off <<= 1) d += __shfl_xor(d, off, 64);
-      int j = base + (i * 4 + wave) * RPW + rg;
+      int j = base + (i * NWV + wave) * RPW + rg;
       sc[i] = (j < ctx) ? d : -INFINITY;
       cmax = fmaxf(cmax, sc[i]);
     }
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
 #pragma unroll
       for (int e = 0; e < E; ++e) o[e] *= corr;
 #pragma unroll
-      for (int i = 0; i < AD_CH; ++i) {
+      for (int i = 0; i < CH; ++i) {
         float pv = __expf(sc[i] - M);  // -inf -> 0
         l += pv;
 #pragma unroll
@@ -117,10 +118,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
   }
   __syncthreads();
   if (tid < HD) {
-    float M = fmaxf(fmaxf(w_m[0], w_m[1]), fmaxf(w_m[2], w_m[3]));
+    float M = w_m[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) M = fmaxf(M, w_m[w]);
     float L = 0.f, acc = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NWV; ++w) {
       float sw = (w_m[w] == -INFINITY) ? 0.f : __expf(w_m[w] - M);
       L += w_l[w] * sw;
       acc += w_o[w][tid] * sw;
@@ -283,22 +286,40 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const T* __restrict__
 
 using namespace itts;
 
+namespace itts { int g_attn_waves = 4; }  // itts_debug_set(4, 4|8): waves per decode-attention workgroup
+
 extern "C" int itts_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, const int32_t* pad,
                                 const int32_t* pos, int B, int H, int smax, int dtype, void* stream) {
   ITTS_REQUIRE(q && kcache && vcache && out && pad && pos, "itts_attn_decode: null pointer");
   ITTS_REQUIRE(B > 0 && H > 0 && smax > 0 && smax <= AD_MAXCTX, "itts_attn_decode: bad shape B=%d H=%d smax=%d (max %d)", B, H,
                smax, AD_MAXCTX);
-  dim3 grid(H, B), block(256);
+  dim3 grid(H, B), block(g_attn_waves * 64);
   hipStream_t s = (hipStream_t)stream;
+  if (g_attn_waves == 8) {
+    switch (dtype) {
+      case ITTS_F32:
+        hipLaunchKernelGGL((attn_decode_kernel<float, 8>), grid, block, 0, s, (const float*)q, (const float*)kcache, (const float*)vcache, (float*)out, pad, pos, H, smax);
+        break;
+      case ITTS_BF16:
+        hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 8>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)kcache, (const bf16_t*)vcache, (bf16_t*)out, pad, pos, H, smax);
+        break;
+      case ITTS_F16:
+        hipLaunchKernelGGL((attn_decode_kernel<f16_t, 8>), grid, block, 0, s, (const f16_t*)q, (const f16_t*)kcache, (const f16_t*)vcache, (f16_t*)out, pad, pos, H, smax);
+        break;
+      default:
+        ITTS_REQUIRE(false, "itts_attn_decode: unknown dtype %d", dtype);
+    }
+    return check_launch("itts_attn_decode");
+  }
   switch (dtype) {
     case ITTS_F32:
-      hipLaunchKernelGGL(attn_decode_kernel<float>, grid, block, 0, s, (const float*)q, (const float*)kcache, (const float*)vcache, (float*)out, pad, pos, H, smax);
+      hipLaunchKernelGGL((attn_decode_kernel<float, 4>), grid, block, 0, s, (const float*)q, (const float*)kcache, (const float*)vcache, (float*)out, pad, pos, H, smax);
       break;
     case ITTS_BF16:
-      hipLaunchKernelGGL(attn_decode_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)kcache, (const bf16_t*)vcache, (bf16_t*)out, pad, pos, H, smax);
+      hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 4>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)kcache, (const bf16_t*)vcache, (bf16_t*)out, pad, pos, H, smax);
       break;
     case ITTS_F16:
-      hipLaunchKernelGGL(attn_decode_kernel<f16_t>, grid, block, 0, s, (const f16_t*)q, (const f16_t*)kcache, (const f16_t*)vcache, (f16_t*)out, pad, pos, H, smax);
+      hipLaunchKernelGGL((attn_decode_kernel<f16_t, 4>), grid, block, 0, s, (const f16_t*)q, (const f16_t*)kcache, (const f16_t*)vcache, (f16_t*)out, pad, pos, H, smax);
       break;
     default:
       ITTS_REQUIRE(false, "itts_attn_decode: unknown dtype %d", dtype);

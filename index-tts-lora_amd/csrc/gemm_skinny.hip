@@ -483,12 +483,13 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
   return ITTS_OK;
 }
 
-namespace itts { extern int g_conv_cfg; }
+namespace itts { extern int g_conv_cfg; extern int g_attn_waves; }
 
 extern "C" int itts_debug_set(int key, int value) {
   if (key == 1) itts::g_tune_ntb = value;
   else if (key == 2) itts::g_tune_nw = value;
   else if (key == 3) itts::g_conv_cfg = value;
+  else if (key == 4) itts::g_attn_waves = (value == 8) ? 8 : 4;
   else return ITTS_ERR_INVALID;
   return ITTS_OK;
 }
