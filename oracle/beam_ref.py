@@ -4,8 +4,11 @@ The reference reaches this through `GenerationMixin.generate` (indextts/gpt/mode
 IndexTTS.infer are do_sample=True, num_beams=3, infer.py:807-814).  The algorithm lives in the third-party dependency
 transformers==4.44.2 (requirements.txt:5), which is NOT installed here (the image has 5.15, whose beam search was
 rewritten), so this file restates the published 4.44.2 algorithm -- `GenerationMixin._beam_search` +
-`BeamSearchScorer.process/finalize` + `BeamHypotheses.add/is_done` -- and its parity is UNPINNED (no reference-run
-fixture can be produced offline).  Restated behaviour:
+`BeamSearchScorer.process/finalize` + `BeamHypotheses.add/is_done`.  Pinning: no reference-run fixture can be produced
+offline, but tests/test_oracle_vs_golden.py::test_beam_oracle_matches_transformers_beam_search holds the beam-search mode
+(do_sample=False: scorer bookkeeping, EOS handling, length penalty <= 1, repetition penalty on log-probabilities,
+finalize) to the INSTALLED transformers' generate() on a toy GPT-2, token for token; the sampling mode differs only in how
+the 2*num_beams candidates are drawn (own Philox stream below) and is unpinned.  Restated behaviour:
 
   per step, per batch element (num_beams rows):
     scores   = log_softmax(logits)                                   (fp32)

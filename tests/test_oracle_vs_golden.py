@@ -132,3 +132,61 @@ def test_bigvgan_forward():
     spk2 = torch.from_numpy(g["spk_b2"]).transpose(1, 2)
     wav2 = bigvgan_ref.forward(torch.from_numpy(g["latent_b2"]), spk2, W)
     assert np.sqrt(np.mean((wav2.numpy() - g["wav_b2"]) ** 2)) < 1e-5
+
+
+def test_beam_oracle_matches_transformers_beam_search():
+    """Pins oracle/beam_ref.py (beam search mode: scorer bookkeeping, EOS handling, length penalty, is_done heuristic,
+    finalize, repetition penalty on log-probabilities) against the installed transformers' own `generate(num_beams=3,
+    do_sample=False)` on a toy GPT-2 with seeded random weights.  (The reference pins transformers 4.44.2; the image has a
+    newer release whose beam search is a vectorised rewrite of the same algorithm -- agreement on every case here is the
+    evidence that the restatement is the published algorithm.  The sampling variant differs only in how the 2*num_beams
+    candidates are drawn, which cannot be matched to torch.multinomial.)"""
+    transformers = pytest.importorskip("transformers")
+    import warnings
+
+    from oracle import beam_ref
+    torch.manual_seed(0)
+    V, eos = 24, 23
+    cfg = transformers.GPT2Config(vocab_size=V, n_positions=64, n_embd=16, n_layer=2, n_head=2, bos_token_id=0, eos_token_id=eos,
+                                  pad_token_id=eos)
+    class Boosted(transformers.GPT2LMHeadModel):
+        boost = 0.0
+
+        def forward(self, *a, **k):
+            out = super().forward(*a, **k)
+            out.logits[..., eos] += self.boost   # seen by generate() and by the oracle's drive alike
+            return out
+
+    m = Boosted(cfg).eval()
+    for p in m.parameters():
+        torch.nn.init.normal_(p, std=0.35)   # flat enough for the beams to compete
+    n_eos = 0
+    for trial in range(24):
+        m.boost = [0.0, 1.0, 1.5, 2.0, 2.5, 3.0][trial // 4]  # later cases: EOS is likely, hypotheses close, elements finish
+        g = torch.Generator().manual_seed(100 + trial)
+        B, P, nb, max_new = 2, 4, 3, 10
+        prompt = torch.randint(1, V - 1, (B, P), generator=g)
+        # length_penalty 0.0 is what infer.py passes (infer.py:807-814).  Above 1 the two transformers generations differ in
+        # the early-stop heuristic (5.x compares the best RUNNING beam, 4.44.2 the best candidate of the step; oracle = 4.44.2)
+        lp = [0.0, 1.0, 0.0, 0.5][trial % 4]
+        rp = [1.0, 1.3][trial % 2]
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = m.generate(prompt, attention_mask=torch.ones_like(prompt), num_beams=nb, do_sample=False, max_new_tokens=max_new,
+                             length_penalty=lp, repetition_penalty=rp, early_stopping=False, num_return_sequences=1,
+                             pad_token_id=eos, eos_token_id=eos)
+        hf = out[:, P:].numpy()
+        sp = dict(do_sample=False, top_k=0, top_p=1.0, temperature=1.0, repetition_penalty=rp)
+        for b in range(B):
+            bs = beam_ref.BeamSearch(1, nb, sp, prompt[b].tolist(), eos=eos, length_penalty=lp)
+            for _ in range(max_new):
+                with torch.no_grad():
+                    lg = m(torch.tensor(bs.hist[0])).logits[:, -1, :].float().numpy()
+                bs.step(lg)
+                if bs.all_done():
+                    break
+            ref, got = bs.finalize()[0].tolist(), hf[b].tolist()
+            n = min(len(ref), len(got))
+            assert ref[:n] == got[:n] and all(t == eos for t in ref[n:] + got[n:]), (trial, b, got, ref)
+            n_eos += int(eos in got)
+    assert n_eos >= 4, "the EOS-heavy cases must actually close hypotheses"
