@@ -190,3 +190,30 @@ def test_beam_oracle_matches_transformers_beam_search():
             assert ref[:n] == got[:n] and all(t == eos for t in ref[n:] + got[n:]), (trial, b, got, ref)
             n_eos += int(eos in got)
     assert n_eos >= 4, "the EOS-heavy cases must actually close hypotheses"
+
+
+def test_beam_sample_row_processing_matches_transformers_processors():
+    """oracle/beam_ref.process_row (log-softmax -> repetition penalty -> temperature -> top-k -> top-p with
+    min_tokens_to_keep = 2, the beam-sample chain) against the installed transformers processor classes."""
+    transformers = pytest.importorskip("transformers")
+    from transformers.generation.logits_process import (RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper,
+                                                        TopKLogitsWarper, TopPLogitsWarper)
+
+    from oracle import beam_ref
+    rng = np.random.default_rng(21)
+    V = 8194
+    for case in range(6):
+        logits = (rng.normal(size=(1, V)) * [1.0, 3.0, 6.0][case % 3]).astype(np.float32)
+        hist = rng.integers(0, V, size=(1, 40))
+        sp = dict(do_sample=True, top_k=[30, 5, 1][case % 3], top_p=[0.8, 0.3, 0.95][case % 3], temperature=[1.0, 0.7][case % 2],
+                  repetition_penalty=[10.0, 1.0][case % 2])
+        ids, s = torch.from_numpy(hist), torch.log_softmax(torch.from_numpy(logits), -1)
+        if sp["repetition_penalty"] != 1.0:
+            s = RepetitionPenaltyLogitsProcessor(sp["repetition_penalty"])(ids, s)
+        if sp["temperature"] != 1.0:
+            s = TemperatureLogitsWarper(sp["temperature"])(ids, s)
+        s = TopKLogitsWarper(sp["top_k"], min_tokens_to_keep=2)(ids, s)
+        s = TopPLogitsWarper(sp["top_p"], min_tokens_to_keep=2)(ids, s).numpy()[0]
+        got = beam_ref.process_row(logits[0], hist[0], sp, 3)
+        assert np.array_equal(np.isfinite(got), np.isfinite(s)), case
+        np.testing.assert_allclose(got[np.isfinite(got)], s[np.isfinite(s)], rtol=2e-6, atol=2e-6)
