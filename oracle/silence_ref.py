@@ -1,7 +1,8 @@
 """ORACLE (test infrastructure): IndexTTS.remove_long_silence, indextts/infer.py:446-497, restated on numpy.
 
-Parity unpinned by reference-run fixtures (indextts/infer.py is not importable here: torchaudio/soundfile/omegaconf
-absent); pinned only by hand-derived cases in tests/test_silence.py that follow the source text.
+Pinned by tests/golden/host_logic.json: outputs of the reference's own method (imported in the build container with
+inert stand-ins for the packages it only touches at import time, tests/golden/make_host_golden.py), checked in
+tests/test_host_logic.py::test_host_helpers_match_reference_fixture.
 """
 import numpy as np
 

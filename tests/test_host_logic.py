@@ -263,3 +263,50 @@ def test_cli_exit_codes(tmp_path, capsys):
     if not torch.cuda.is_available():
         assert code(["hello", "-v", str(voice), "-c", str(cfg), "-o", str(out), "-f"]) == 1
         assert not out.exists()   # --force removed the stale output before the device check, like the reference
+
+
+def _host_golden():
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "host_logic.json"), encoding="utf-8") as f:
+        return json.load(f)
+
+
+def test_host_helpers_match_reference_fixture():
+    """remove_long_silence, bucket_sentences, pad_tokens_cat, split_sentences_by_token and the CJK tokenisers against
+    outputs of the reference's own functions (tests/golden/make_host_golden.py; infer.py:446-580, front.py:341-424,
+    common.py:39-87)."""
+    import types
+
+    from indextts.infer import IndexTTS
+    from indextts.utils import front
+    from oracle import silence_ref
+    g = _host_golden()
+    me = types.SimpleNamespace(stop_mel_token=8193)
+    for c in g["remove_long_silence"]:
+        codes = torch.tensor(c["codes"])
+        out, lens = IndexTTS.remove_long_silence(me, codes)
+        assert out.tolist() == c["out"] and lens.tolist() == c["lens"]
+        o2, l2 = silence_ref.remove_long_silence(np.asarray(c["codes"]), stop_mel_token=8193)
+        assert np.asarray(o2).tolist() == c["out"] and list(l2) == c["lens"]
+    for c in g["bucket_sentences"]:
+        sents = [["a"] * n for n in c["lens"]]
+        got = IndexTTS.bucket_sentences(types.SimpleNamespace(), sents, bucket_max_size=c["max"])
+        assert [[{"idx": it["idx"], "len": it["len"]} for it in b] for b in got] == c["buckets"]
+    cfgns = types.SimpleNamespace(gpt=types.SimpleNamespace(stop_text_token=1, start_text_token=0))
+    for c in g["pad_tokens_cat"]:
+        toks = [torch.arange(2, 2 + n, dtype=torch.int32)[None] for n in c["lens"]]
+        got = IndexTTS.pad_tokens_cat(types.SimpleNamespace(model_version=c["version"], cfg=cfgns), toks)
+        assert got.tolist() == c["out"], c["version"]
+    punct = [".", "!", "?", "▁.", "▁?", "▁...", "。", "？", "！"]
+    import warnings
+    for c in g["split_sentences_by_token"]:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if "error" in c:
+                with pytest.raises(Exception):
+                    front.TextTokenizer.split_sentences_by_token(list(c["tokens"]), punct, c["max"])
+            else:
+                assert front.TextTokenizer.split_sentences_by_token(list(c["tokens"]), punct, c["max"]) == c["out"], (c["max"], c["tokens"][:6])
+    for c in g["tokenize_by_CJK_char"]:
+        assert front.tokenize_by_CJK_char(c["text"]) == c["upper"]
+        assert front.tokenize_by_CJK_char(c["text"], do_upper_case=False) == c["keep"]
