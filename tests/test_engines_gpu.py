@@ -303,3 +303,21 @@ def test_request_pool_matches_serial_infer_batch():
         for a, b in zip(want, got):
             assert a.shape == b.shape and torch.equal(a, b)
     pool.close()
+
+
+def test_beam_decode_full_size_bf16_graph_equals_eager():
+    """24 layers, bf16, 2 batch elements x 3 beams, beam-sample with the reference's default settings: the captured step
+    (171 launches + beam step + in-place KV permutation) reproduces the eagerly launched loop token for token."""
+    m = make_gpt(24, torch.bfloat16)
+    eng = m.engine
+    cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
+    conds = m.get_conditioning(cond_mel, torch.tensor([120], device=DEV))
+    text = torch.tensor([[11, 22, 33, 44, 55, 66, 77, 88], [99, 111, 222, 1, 1, 1, 1, 1]], device=DEV)
+    _, emb, mask = m.prepare_gpt_inputs(conds, text)
+    pad = (mask == 0).sum(1).to(torch.int32)
+    sp = dict(do_sample=True, top_p=0.8, top_k=30, temperature=1.0, repetition_penalty=10.0, seed=11, length_penalty=0.0)
+    outs = []
+    for use_graph in (False, True):
+        eng.prefill(emb.repeat_interleave(3, 0), pad.repeat_interleave(3), 14)
+        outs.append(eng.decode_beam(14, sp, 3, use_graph=use_graph, check_every=4).cpu())
+    assert outs[0].shape[0] == 2 and torch.equal(outs[0], outs[1])
