@@ -16,6 +16,8 @@ Prints ONE JSON line on rank 0 (see the driver contract), including
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -47,11 +49,47 @@ def build_weights_rank0():
 
 
 def broadcast_state(sd_or_none, rank, world, device):
-    """rank 0 -> all: one flat fp32 arena over RCCL (xGMI inside a node)."""
+    """rank 0 -> all: one flat arena per dtype over RCCL (xGMI inside a node); dtypes are preserved."""
     from indextts.utils.dist import broadcast_state_dict
     if world == 1:
         return sd_or_none
     return broadcast_state_dict(sd_or_none, src=0, device=device)
+
+
+def self_launch(n: int, argv) -> int:
+    """`python bench.py --gpus N` without an external launcher: start N fresh child processes (one rank per GPU) BEFORE
+    this process touches the GPU, wait for them, forward rank 0's JSON line, fail if any child fails.  Nothing is
+    re-executed in place: the parent stays a plain supervisor."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    import tempfile
+    procs = []
+    out0 = tempfile.TemporaryFile()
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    deadline = time.time() + float(os.environ.get("ITTS_BENCH_TIMEOUT_S", "3000"))
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs) or time.time() > deadline:
+            failed = True   # one rank died (or the job hung): the others would wait in a barrier forever
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    rcs = [p.wait() for p in procs]
+    if failed or any(rc != 0 for rc in rcs):
+        log(f"[bench] child exit codes {rcs}: FAILED")
+        return 1
+    out0.seek(0)
+    out0 = out0.read().decode()
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return 0
 
 
 class KernelTimer:
@@ -128,44 +166,132 @@ class KernelTimer:
         return agg
 
 
-def make_inputs(rank, device):
-    g = torch.Generator().manual_seed(2 + 1000 * rank)
-    lens = torch.randint(20, 61, (BATCH,), generator=g)
-    texts = [torch.randint(2, 12000, (int(n),), generator=g).to(torch.int32) for n in lens]
-    import synth
-    cond_mel = torch.from_numpy(synth.uniform("bench.cond_mel", (1, 100, 300), -6.0, 2.0)).to(device)
-    return cond_mel, texts
+def make_workload(config: int, world: int):
+    """The GLOBAL utterance list of a run (32 per GPU), identical on every rank:
+    config 3: text lengths U{20..60} (seed 2), every row stopped after 140 acoustic tokens;
+    config 4: text lengths U{8..100}, stop steps U{40..400} (seed 3) -- BASELINE config 4 is this at world = 8 (256 rows).
+    Returns (text token rows, stop steps)."""
+    n = BATCH * world
+    g = torch.Generator().manual_seed(2 if config == 3 else 3)
+    if config == 3:
+        lens = torch.randint(20, 61, (n,), generator=g)
+        stops = [MEL_TOKENS] * n
+    else:
+        lens = torch.randint(8, 101, (n,), generator=g)
+        stops = [int(v) for v in torch.randint(40, 401, (n,), generator=g)]
+    texts = [torch.randint(2, 12000, (int(k),), generator=g).to(torch.int32) for k in lens]
+    return texts, stops
 
 
-def cpu_baseline(gsd, bsd, cond_conds, n_tokens=96):
-    """Oracle (oracle/*.py, fp32, torch CPU) on ONE utterance of the same workload, n_tokens acoustic tokens:
-    prefill + cached greedy steps + latent pass + vocoder.  Returns (audio_s_per_s, cores, description)."""
-    from oracle import bigvgan_ref, gpt_ref
+def cpu_baseline(gsd, bsd, cond_conds, texts, rows=4, n_tokens=MEL_TOKENS, seed=2000):
+    """Oracle (oracle/*.py, fp32, torch CPU) on `rows` of the benched utterances as ONE left-padded batch, the benched
+    sampling settings (repetition penalty 10, top-k 30, top-p 0.8, Philox draw), n_tokens acoustic tokens each:
+    prefix -> prefill -> cached sampling loop -> latent pass -> BigVGAN.  Returns (audio_s_per_s, cores, description)."""
+    from oracle import bigvgan_ref, gpt_ref, sampling_ref
     cores = min(len(os.sched_getaffinity(0)), 16)  # the box's CPU share, not the host's core count
     torch.set_num_threads(cores)
     W = {k: v.float() for k, v in gsd.items() if k.startswith(("gpt.", "final_norm", "mel_", "text_"))}
-    g = torch.Generator().manual_seed(2)
-    text = torch.randint(2, 12000, (1, 40), generator=g)
+    sel = texts[:rows]
+    L = max(int(t.numel()) for t in sel)
+    text = torch.full((rows, L), 1, dtype=torch.long)  # stop_text_token right padding, stripped by the prefix builder
+    for i, t in enumerate(sel):
+        text[i, : t.numel()] = t.long()
     conds = cond_conds.cpu().float()
     VW = bigvgan_ref.Weights({k: v.numpy() for k, v in bsd.items()})
     spk = torch.zeros(1, 512, 1)
     t0 = time.perf_counter()
     emb, mask, _ = gpt_ref.prepare_gpt_inputs(conds, text, W)
     lg, past = gpt_ref.decode_prefill(emb, mask, W)
-    codes = []
+    hist = [[1, 8192] for _ in range(rows)]   # the fake prefix ids the repetition penalty sees (model.py:658-667)
+    codes = [[] for _ in range(rows)]
     for s in range(1, n_tokens + 1):
-        tok = lg.argmax(-1)
-        codes.append(int(tok))
+        toks = []
+        sc = sampling_ref.process(lg.numpy(), np.array(hist), 10.0, 1.0, 30, 0.8)
+        for b in range(rows):
+            tok = sampling_ref.pick(sc[b], sampling_ref.uniform01(seed, b, s - 1))
+            toks.append(tok)
+            hist[b].append(tok)
+            codes[b].append(tok)
         if s == n_tokens:
             break
-        mask = torch.cat([mask, torch.ones(1, 1, dtype=torch.bool)], 1)
-        lg, past = gpt_ref.decode_step(tok, s, mask, past, W)
-    lat = gpt_ref.latent_pass(conds, text[0], torch.tensor(codes), W)
-    wav = bigvgan_ref.forward(lat, spk, VW)
+        mask = torch.cat([mask, torch.ones(rows, 1, dtype=torch.bool)], 1)
+        lg, past = gpt_ref.decode_step(torch.tensor(toks), s, mask, past, W)
+    n_audio = 0
+    for b in range(rows):
+        lat = gpt_ref.latent_pass(conds, sel[b].long(), torch.tensor(codes[b]), W)
+        wav = bigvgan_ref.forward(lat, spk, VW)
+        n_audio += wav.shape[-1]
     dt = time.perf_counter() - t0
-    audio_s = wav.shape[-1] / 24000.0
-    return audio_s / dt, cores, (f"oracle fp32 on {cores} host threads: 1 utterance, 40 text tokens, {n_tokens} acoustic tokens "
-                                 f"(prefill + cached decode + latent pass + BigVGAN), {dt:.1f}s of CPU work")
+    return n_audio / 24000.0 / dt, cores, (
+        f"oracle fp32 on {cores} host threads: {rows} of the 32 benched rows as one batch, top-k/top-p sampling, {n_tokens} "
+        f"acoustic tokens each (prefix + prefill + cached sampling loop + latent pass + BigVGAN), {dt:.1f}s of CPU work")
+
+
+def stub_main(args, rank, world):
+    """Rank body of `--stub`: everything bench.py does around the engine, on CPU over gloo.  The stub "decodes" a shard by
+    sleeping 1 ms per utterance and returning waveforms of the contract's length (stop step x 1024 samples)."""
+    import torch.distributed as dist
+    from indextts.utils import dist as idist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    if os.environ.get("ITTS_BENCH_STUB_FAIL_RANK") == str(rank):
+        log(f"[bench] rank {rank}: injected failure")
+        os._exit(3)
+    me = {"rank": rank, "device": "cpu", "name": "stub", "pci_bus_id": None, "uuid": f"stub-{os.getpid()}"}
+    ranks_seen = [me]
+    if world > 1:
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, me)
+    sd = None
+    if rank == 0:
+        g = torch.Generator().manual_seed(0)
+        sd = {"gpt.h.0.attn.c_attn.weight": torch.randn(64, 192, generator=g), "gpt.h.0.ln_1.weight": torch.randn(64, generator=g),
+              "steps": torch.tensor(2 ** 24 + 1)}
+        sd = idist.compact_gpt_state_dict(sd, torch.bfloat16)
+    sd = broadcast_state(sd, rank, world, "cpu")
+    assert sd["gpt.h.0.attn.c_attn.weight"].dtype == torch.bfloat16 and int(sd["steps"]) == 2 ** 24 + 1
+    all_texts, all_stops = make_workload(args.config, world)
+    mine = idist.shard_utterances_even([int(t.numel()) for t in all_texts], world)[rank]
+    force = [all_stops[i] for i in mine]
+
+    def step():
+        time.sleep(1e-3 * len(mine))
+        return [torch.zeros(f * 1024) for f in force]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        outs = step()
+    my_elapsed = time.perf_counter() - t0
+    barrier()
+    elapsed = time.perf_counter() - t0
+    samples = sum(int(o.numel()) for o in outs)
+    per_rank = [{"rank": rank, "seconds": my_elapsed, "audio_s_per_step": samples / 24000.0, "rows": sorted(mine)}]
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "seconds": my_elapsed, "audio_s_per_step": samples / 24000.0,
+                                          "rows": sorted(mine)})
+    audio_s_job = sum(p["audio_s_per_step"] for p in per_rank)
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": round(audio_s_job * args.steps / elapsed, 2), "unit": "audio-seconds/sec",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+                          "scaling": "weak", "data": "stub", "ranks_seen": ranks_seen, "per_rank": per_rank,
+                          "audio_seconds_per_step_job": audio_s_job, "config": {"workload": f"stub of config {args.config}"}}),
+              flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -173,6 +299,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=3, choices=[3, 4],
+                    help="3 (default, BASELINE metric): 32 utterances/GPU, 140 tokens each; 4: mixed lengths (stop steps "
+                         "U{40..400}, text U{8..100}), 32 per GPU sharded longest-first from one global list (256 at 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight for --schedule concurrent")
@@ -185,20 +314,32 @@ def main():
                          "concurrent: --inflight independent batch-32 requests at a time, each on its own engine instance, "
                          "thread and HIP stream (serving concurrency; the token loops of different requests interleave on "
                          "the CUs, which the latency-bound loop of a single request leaves mostly idle)")
+    ap.add_argument("--stub", action="store_true",
+                    help="CPU rehearsal of the multi-rank control flow (tests/test_distributed_cpu.py): gloo, no GPU, a stub "
+                         "in place of the engine; launcher, rendezvous, broadcast, sharding, timing and JSON are the real ones")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no external launcher: become the supervisor of N ranks.  This happens before ANY GPU call in this process.
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if world != args.gpus:
+        log(f"[bench] WORLD_SIZE={world} does not match --gpus {args.gpus}: start this script once per GPU "
+            f"(torch.distributed.run --nproc-per-node {args.gpus}) or without a launcher")
+        sys.exit(2)
     # Rehearsal aid for a one-GPU box (not used by the driver): ITTS_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
     # ITTS_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device; the control flow is the same.
     if os.environ.get("ITTS_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
     backend = os.environ.get("ITTS_BENCH_BACKEND", "nccl")
+    torch.set_grad_enabled(False)
+    if args.stub:
+        return stub_main(args, rank, world)
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
-    torch.set_grad_enabled(False)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -210,26 +351,56 @@ def main():
     import weights
     from indextts import _native as nat
     from indextts.infer import BatchPipeline, IndexTTS, RequestPool
+    from indextts.utils import dist as idist
 
-    gsd = bsd = None
+    # who is here: every rank reports its device; rank 0 prints the list (the launcher's promise, checked)
+    props = torch.cuda.get_device_properties(local_rank)
+    me = {"rank": rank, "device": device, "name": props.name, "pci_bus_id": getattr(props, "pci_bus_id", None),
+          "uuid": str(getattr(props, "uuid", ""))}
+    ranks_seen = [me]
+    if world > 1:
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, me)
+
+    gsd = bsd = gsd_c = bsd_c = None
     if rank == 0:
         gsd, bsd = build_weights_rank0()
-    gsd_d = broadcast_state(gsd, rank, world, device)
-    bsd_d = broadcast_state(bsd, rank, world, device)
+        # what travels: the GEMM weights already in their compute dtype (bf16 GPT, fp16 vocoder with weight norm folded);
+        # every rank then packs identical bits.  fp32 only for what stays fp32 on the device.
+        gsd_c = idist.compact_gpt_state_dict(gsd, torch.bfloat16)
+        bsd_c = idist.compact_bigvgan_state_dict(bsd, torch.float16)
+    bc = None
+    if world > 1:
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+    gsd_d = broadcast_state(gsd_c, rank, world, device)
+    bsd_d = broadcast_state(bsd_c, rank, world, device)
+    if world > 1:
+        torch.cuda.synchronize()
+        bc = {"bytes": idist.arena_bytes(gsd_d) + idist.arena_bytes(bsd_d), "seconds": round(time.perf_counter() - tb, 3),
+              "backend": "rccl" if backend == "nccl" else backend}
     cfg = weights.reference_config()
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):  # keep stdout for the single JSON line
         tts = IndexTTS.from_weights(cfg, gsd_d, bsd_d, device=device,
                                     precision_config={"gpt": "bf16", "vocoder": "fp16"})
-    want_conc = args.schedule == "concurrent" or (world == 1 and not args.no_concurrency)
+    want_conc = args.schedule == "concurrent" or (world == 1 and not args.no_concurrency and args.config == 3)
     extra = [tts.replica() for _ in range(max(2, args.inflight) - 1)] if want_conc else []  # shared weights, private state
-    del gsd_d, bsd_d
-    cond_mel, texts = make_inputs(rank, device)
-    force = [MEL_TOKENS] * BATCH
+    del gsd_d, bsd_d, gsd_c, bsd_c
+
+    # ONE global utterance list, sharded longest-first (by text length, the only length known up front) into equal shards
+    import synth
+    cond_mel = torch.from_numpy(synth.uniform("bench.cond_mel", (1, 100, 300), -6.0, 2.0)).to(device)
+    all_texts, all_stops = make_workload(args.config, world)
+    shards = idist.shard_utterances_even([int(t.numel()) for t in all_texts], world)
+    mine = shards[rank]
+    texts = [all_texts[i] for i in mine]
+    force = [all_stops[i] for i in mine]
+    max_new = max(all_stops) + 1
     gen = dict(do_sample=True, top_k=30, top_p=0.8, temperature=1.0, repetition_penalty=10.0, num_beams=1)
 
     def step(seed, phase_events=None):
-        return tts.infer_batch(cond_mel, texts, max_mel_tokens=MEL_TOKENS + 1, force_stop=force, seed=seed,
+        return tts.infer_batch(cond_mel, texts, max_mel_tokens=max_new, force_stop=force, seed=seed,
                                phase_events=phase_events, **gen)
 
     def barrier():
@@ -243,7 +414,7 @@ def main():
 
     def make_pool():
         pl = RequestPool([tts] + extra)
-        pl.warm_up(cond_mel, texts, max_mel_tokens=MEL_TOKENS + 1, force_stop=force, seed=900, **gen)
+        pl.warm_up(cond_mel, texts, max_mel_tokens=max_new, force_stop=force, seed=900, **gen)
         return pl
 
     if args.schedule == "concurrent":
@@ -254,7 +425,7 @@ def main():
         if n <= 0:
             return None
         if pool is not None:
-            jobs = [pool.submit(cond_mel, texts, max_mel_tokens=MEL_TOKENS + 1, force_stop=force, seed=seed0 + k, **gen)
+            jobs = [pool.submit(cond_mel, texts, max_mel_tokens=max_new, force_stop=force, seed=seed0 + k, **gen)
                     for k in range(n)]
             return [j.result() for j in jobs][-1]
         if pipe is None:
@@ -264,7 +435,7 @@ def main():
             return o
         tickets, marks = [], [time.perf_counter()]
         for k in range(n):
-            tickets.append(pipe.submit(cond_mel, texts, max_mel_tokens=MEL_TOKENS + 1, force_stop=force, seed=seed0 + k, **gen))
+            tickets.append(pipe.submit(cond_mel, texts, max_mel_tokens=max_new, force_stop=force, seed=seed0 + k, **gen))
             marks.append(time.perf_counter())
         o = [t.result() for t in tickets][-1]
         marks.append(time.perf_counter())
@@ -275,17 +446,23 @@ def main():
     barrier()
     t0 = time.perf_counter()
     outs = run_steps(args.steps, 2000)
+    torch.cuda.synchronize()
+    my_elapsed = time.perf_counter() - t0   # this rank's own work, before it waits for the slowest rank
     barrier()
     elapsed = time.perf_counter() - t0
+    samples = sum(int(o.numel()) for o in outs)
+    assert samples == sum(force) * 1024, f"unexpected audio length {samples} (expected {sum(force) * 1024})"
+    per_rank = [{"rank": rank, "seconds": my_elapsed, "audio_s_per_step": samples / 24000.0}]
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    log(f"[bench] rank {rank}: {args.steps} steps in {elapsed:.3f}s")
-    samples = sum(int(o.numel()) for o in outs)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "seconds": my_elapsed, "audio_s_per_step": samples / 24000.0})
+    log(f"[bench] rank {rank}: {args.steps} steps in {my_elapsed:.3f}s (job {elapsed:.3f}s)")
     audio_s_step = samples / 24000.0
-    assert samples == BATCH * MEL_TOKENS * 1024, f"unexpected audio length {samples}"
-    value = audio_s_step * world * args.steps / elapsed
+    audio_s_job = sum(p["audio_s_per_step"] for p in per_rank)   # all ranks' utterances of one step
+    value = audio_s_job * args.steps / elapsed
 
     # phase split of one more (un-instrumented, graph-replayed) step, run serially on one stream
     pe = {}
@@ -299,20 +476,21 @@ def main():
     phases = {f"{a}->{b}": round(pe[a].elapsed_time(pe[b]), 3) for a, b in zip(names[:-1], names[1:])}
     eng = tts.gpt.engine
     S0 = eng._S
+    n_tok = max(force)
     dec_ms = phases["prefilled->decoded"]
-    step_us = 1e3 * dec_ms / MEL_TOKENS
-    ctx_mid = S0 + MEL_TOKENS // 2
+    step_us = 1e3 * dec_ms / n_tok
+    ctx_mid = S0 + n_tok // 2
     dec_bytes = eng.step_bytes(BATCH, ctx_mid)
     log(f"[bench] phases (ms): {phases}; decode step {step_us:.1f} us, {dec_bytes / 1e6:.0f} MB/step -> "
         f"{dec_bytes / (step_us * 1e-6) / 1e9:.0f} GB/s")
 
-    # p50 first-token latency: cached prompt mel -> conditioner + prefix + prefill + first sample
+    # p50 first-token latency: cached prompt mel -> conditioner + prefix + prefill + first sample  (30 samples)
     lat_ms = []
     batch_tokens = torch.full((BATCH, max(int(t.numel()) for t in texts)), 1, dtype=torch.int32, device=device)
     for i, t in enumerate(texts):
         batch_tokens[i, : t.numel()] = t.to(device)
     sp = dict(do_sample=True, top_p=0.8, top_k=30, temperature=1.0, repetition_penalty=10.0, seed=1)
-    for _ in range(5):
+    for _ in range(32):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         conds = tts.gpt.get_conditioning(cond_mel, None)
@@ -321,24 +499,37 @@ def main():
         tts.gpt.engine._sample(BATCH, sp)
         torch.cuda.synchronize()
         lat_ms.append((time.perf_counter() - t1) * 1e3)
+    lat_ms = lat_ms[2:]   # 2 warm-up calls, 30 samples
     first_token_ms = float(np.median(lat_ms))
 
+    workload = ("BASELINE config 3: batch=32 utterances/GPU, top-k sampling (k=30,p=0.8), 140 acoustic tokens (5.97 s) each, "
+                "shared 3.2 s prompt, text U{20..60} tokens, random-init weights at real shapes") if args.config == 3 else (
+                "BASELINE config 4: mixed-length utterances, 32/GPU sharded longest-first from one global list "
+                f"({BATCH * world} rows; 256 at 8 GPUs), stop steps U{{40..400}}, text U{{8..100}} tokens, top-k sampling, shared prompt")
+    secs = [p["seconds"] for p in per_rank]
     result = {
         "metric": "audio-seconds/sec (RTF^-1) at batch 32, whole pipeline (GPT decode + latent pass + BigVGAN)",
         "value": round(value, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "BASELINE config 3: batch=32 utterances/GPU, top-k sampling (k=30,p=0.8), 140 acoustic tokens "
-                               "(5.97 s) each, shared 3.2 s prompt, text U{20..60} tokens, random-init weights at real shapes",
+        "config": {"workload": workload,
                    "gpt_dtype": "bf16", "vocoder_dtype": "fp16", "parallelism": f"dp{world} (utterance sharding, no collectives)",
                    "audio_seconds_per_step_per_gpu": round(audio_s_step, 3),
+                   "audio_seconds_per_step_job": round(audio_s_job, 3),
                    "schedule": ("2-stage batch pipeline: latent pass + vocoder of batch i on a second HIP stream beside "
                                 "the token loop of batch i+1; all steps complete inside the timed region")
                    if pipe is not None else (f"concurrent: {len(pool.instances)} independent batch-32 requests in flight (one "
                                              "engine instance, thread and HIP stream each)" if pool is not None else
                                              "serial: one batch at a time on one stream")},
+        "ranks_seen": ranks_seen,
+        "per_rank": [{"rank": p["rank"], "ms_per_step": round(1e3 * p["seconds"] / args.steps, 3),
+                      "audio_s_per_s": round(p["audio_s_per_step"] * args.steps / p["seconds"], 2)} for p in per_rank],
+        "tail_imbalance": round(max(secs) / (sum(secs) / len(secs)), 4),
+        "weight_broadcast": bc,
         "serial_ms_per_step": round(serial_ms, 3),
         "first_token_ms_p50": round(first_token_ms, 2),
+        "first_token_ms": {"n": len(lat_ms), "p50": round(first_token_ms, 2), "p90": round(float(np.percentile(lat_ms, 90)), 2),
+                           "min": round(min(lat_ms), 2)},
         "phases_ms": phases,
         "decode_step": {"us": round(step_us, 2), "algorithmic_MB": round(dec_bytes / 1e6, 1), "ctx": ctx_mid,
                         "GBps": round(dec_bytes / (step_us * 1e-6) / 1e9, 1),
@@ -352,7 +543,7 @@ def main():
         nrun = max(4, 2 * len(pl.instances))
 
         def run_conc(seed0):
-            jobs = [pl.submit(cond_mel, texts, max_mel_tokens=MEL_TOKENS + 1, force_stop=force, seed=seed0 + k, **gen)
+            jobs = [pl.submit(cond_mel, texts, max_mel_tokens=max_new, force_stop=force, seed=seed0 + k, **gen)
                     for k in range(nrun)]
             for j in jobs:
                 j.result()
@@ -403,10 +594,13 @@ def main():
         # HBM traffic per launch: rocprofv3 PMC passes cannot run inside this process; the committed summary of the
         # separate FETCH_SIZE / WRITE_SIZE passes over exactly these launches (tools/pmc_decode_gemm.py) is reported.
         traffic, traffic_src = None, None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_gemm_skinny.json")
-        if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
-            traffic_src = "profiles/r01_pmc_gemm_skinny.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 read correction)"
+        here = os.path.dirname(os.path.abspath(__file__))
+        for name in ("r02_pmc_gemm_skinny.json", "r01_pmc_gemm_skinny.json"):
+            pmc = os.path.join(here, "profiles", name)
+            if os.path.exists(pmc):
+                traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
+                traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 read correction)"
+                break
         roof = {"kernel": "gemm_skinny_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches_per_decode_step": n_l,
@@ -417,6 +611,22 @@ def main():
             roof["gemm_conv_mfma"] = {"achieved_TFLOPs": round(fl2 / (ms2 * 1e-3) / 1e12, 1), "peak": PEAK_MFMA_TFLOPS,
                                       "frac": round(fl2 / (ms2 * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS, 4), "launches": c2,
                                       "avg_launch_us": round(1e3 * ms2 / c2, 1)}
+        # phase-level rooflines: latent pass against the MFMA peak (0.966 GFLOP per token + attention),
+        # vocoder against both of its co-equal bounds (3.01 GFLOP and 9.7 MB of fp16 activation traffic per frame)
+        frames = sum(force)
+        lat_tokens = sum(32 + int(t.numel()) + 2 + f + 2 for t, f in zip(texts, force))
+        lat_fl = lat_tokens * 0.966e9 + sum(4.0 * 1280 * (32 + int(t.numel()) + f + 4) ** 2 / 2 * 24 for t, f in zip(texts, force))
+        lat_s = phases["decoded->latents"] * 1e-3
+        voc_s = phases["latents->vocoded"] * 1e-3
+        roof["latent_pass_mfma"] = {"tokens": lat_tokens, "TFLOP": round(lat_fl / 1e12, 2), "ms": phases["decoded->latents"],
+                                    "achieved_TFLOPs": round(lat_fl / lat_s / 1e12, 1), "peak": PEAK_MFMA_TFLOPS,
+                                    "frac": round(lat_fl / lat_s / 1e12 / PEAK_MFMA_TFLOPS, 4),
+                                    "note": "whole phase incl. host-side index building, LayerNorm and attention launches"}
+        roof["vocoder"] = {"frames": frames, "ms": phases["latents->vocoded"],
+                           "mfma": {"achieved_TFLOPs": round(frames * 3.01e9 / voc_s / 1e12, 1), "peak": PEAK_MFMA_TFLOPS,
+                                    "frac": round(frames * 3.01e9 / voc_s / 1e12 / PEAK_MFMA_TFLOPS, 4)},
+                           "hbm": {"achieved": round(frames * 9.7e6 / voc_s / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": round(frames * 9.7e6 / voc_s / 1e9 / PEAK_HBM_GBS, 4)}}
         result["roofline"] = roof
         result["kernel_breakdown"] = breakdown
         result["event_pair_overhead_us"] = round(1e3 * kt.overhead_ms, 2)
@@ -424,8 +634,11 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         conds = tts.gpt.get_conditioning(cond_mel, None)
-        v, cores, desc = cpu_baseline(gsd, bsd, conds)
+        v, cores, desc = cpu_baseline(gsd, bsd, conds, texts)
         result["cpu_baseline"] = {"value": round(v, 4), "unit": "audio-seconds/sec", "cores": cores, "kind": "port", "sample": desc}
+        ref = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_cpu_reference.json")
+        if os.path.exists(ref):   # the reference's own modules, timed in the build container (they cannot travel)
+            result["cpu_baseline"]["reference_in_build_container"] = json.load(open(ref))
 
     if rank == 0:
         print(json.dumps(result), flush=True)

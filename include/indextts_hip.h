@@ -209,7 +209,7 @@ typedef struct itts_sample_args {
   int n_extra;
   const int32_t* force_stop; /* [B] or NULL */
   float rep_penalty, temperature, top_p;
-  int top_k, do_sample;
+  int top_k, do_sample; /* do_sample != 0 requires 1 <= top_k <= 1024 (candidate store; top_k <= 0 is refused, not truncated) */
   uint64_t seed;     /* Philox key = seed + the 64-bit value in state[4..5] (lo, hi): a captured launch serves any seed */
   int stop_token;
   float* dbg_scores; /* optional [B][V] processed scores (-inf = removed), for parity tests; NULL in production */
@@ -243,7 +243,7 @@ typedef struct itts_beam_args {
   const int32_t* extra_ids; /* ids always penalised (the fake prefix: 1 and 8192) */
   int n_extra;
   float rep_penalty, temperature, top_p, length_penalty;
-  int top_k, do_sample;
+  int top_k, do_sample; /* do_sample != 0 requires 1 <= top_k <= 128 (one 1024-entry candidate pool per batch element) */
   uint64_t seed;        /* Philox key = seed + the 64-bit value in state[4..5], as in itts_sample_args */
   int eos_token;
 } itts_beam_args;

@@ -402,6 +402,10 @@ extern "C" int itts_beam_step(const itts_beam_args* a, void* stream) {
   ITTS_REQUIRE(a->V > 0 && a->V <= BM_MAXV && a->ldl >= a->V, "itts_beam_step: bad vocabulary V=%d (max %d)", a->V, BM_MAXV);
   ITTS_REQUIRE(a->rep_penalty > 0.f && a->temperature > 0.f && a->hist_cap > 0, "itts_beam_step: bad parameters");
   ITTS_REQUIRE(a->top_k <= BM_MAXC / BM_MAXB, "itts_beam_step: top_k=%d exceeds %d", a->top_k, BM_MAXC / BM_MAXB);
+  // the candidate pool of a batch element holds BM_MAXC entries for all its beams: beam-SAMPLE over the whole vocabulary
+  // (top-k disabled) would clip later beams silently -- refuse it (infer.py passes top_k = 30)
+  ITTS_REQUIRE(!a->do_sample || a->top_k > 0, "itts_beam_step: do_sample needs 1 <= top_k <= %d (top_k=%d)", BM_MAXC / BM_MAXB,
+               a->top_k);
   BeamParams p;
   p.logits = a->logits;
   p.B = a->B;

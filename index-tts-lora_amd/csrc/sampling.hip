@@ -236,6 +236,9 @@ extern "C" int itts_sample(const itts_sample_args* a, void* stream) {
   ITTS_REQUIRE(a->B > 0 && a->V > 0 && a->V <= SM_MAXV && a->ldl >= a->V, "itts_sample: bad shape B=%d V=%d (max %d)", a->B, a->V, SM_MAXV);
   ITTS_REQUIRE(a->rep_penalty > 0.f && a->temperature > 0.f, "itts_sample: rep_penalty/temperature must be positive");
   ITTS_REQUIRE(a->top_k <= SM_MAXC, "itts_sample: top_k=%d exceeds %d", a->top_k, SM_MAXC);
+  // the candidate store holds SM_MAXC entries: sampling from the whole vocabulary (top-k disabled) would be truncated to
+  // the 1024 best logits, silently -- refuse it instead (every caller on the infer.py path passes k = 30 or 50)
+  ITTS_REQUIRE(!a->do_sample || a->top_k > 0, "itts_sample: do_sample needs 1 <= top_k <= %d (top_k=%d)", SM_MAXC, a->top_k);
   SampleParams p;
   p.logits = a->logits;
   p.B = a->B;

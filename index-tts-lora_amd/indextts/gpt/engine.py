@@ -350,6 +350,10 @@ class GPTEngine:
         R, dev = B * nb, self.device
         if getattr(self, "_beam_cap", (0, 0)) == (B, nb):
             return
+        # the buffers below are about to be replaced: every captured beam step holds their addresses, so those graphs
+        # must go with them (a B=4 -> B=3 -> B=4 sequence would otherwise replay a graph over freed memory)
+        for key in [k for k in self._graphs if k and k[0] == "beam"]:
+            del self._graphs[key]
         cap = self.history.shape[1]
         self.b_scores = torch.zeros(R, dtype=torch.float32, device=dev)
         self.b_src = torch.zeros(R, dtype=torch.int32, device=dev)

@@ -173,6 +173,9 @@ class UnifiedVoice:
                   seed=int(torch.initial_seed() & 0x7FFFFFFFFFFFFFFF) if seed is None else int(seed))
         if not sp["do_sample"]:
             sp["top_p"], sp["top_k"], sp["temperature"] = 1.0, 0, 1.0
+        elif sp["top_k"] <= 0:
+            raise ValueError("do_sample=True needs top_k >= 1: the device sampler keeps at most 1024 candidates per row "
+                             "(128 per beam) and refuses to truncate an unrestricted distribution silently")
         if hf:
             raise TypeError(f"unsupported generate() arguments: {sorted(hf)}")
         conds = self.get_conditioning(speech_conditioning_mel, cond_mel_lengths, speaker_ids=speaker_ids)

@@ -305,8 +305,12 @@ class IndexTTS:
         return conds.clone(), spk.clone()
 
     def _conds(self, cond_mel, speaker_id=None):
-        if speaker_id:
-            return self.gpt.get_conditioning(None, None, speaker_ids=[speaker_id])
+        """Conditioning latents of the call.  The reference passes BOTH the prompt mel and speaker_ids=[speaker_id] to
+        gpt.inference_speech / gpt.forward (infer.py:833-847, :864-874), and get_conditioning uses a stored
+        mean_condition_{id} only when there is NO prompt mel (model.py:488-509): with an audio prompt -- which infer()
+        always has -- the encoder path wins and speaker_id only has to be a known id.  Same here."""
+        if cond_mel is None:
+            return self.gpt.get_conditioning(None, None, speaker_ids=[speaker_id] if speaker_id else None)
         if self._cache_conds is None:
             self._cache_conds = self.gpt.get_conditioning(cond_mel, torch.tensor([cond_mel.shape[-1]], device=self.device))
         return self._cache_conds

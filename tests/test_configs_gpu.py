@@ -1,0 +1,390 @@
+"""BASELINE.json configs at their FULL sizes on the GPU, each against the oracle or a size-independent
+property.  The fixture-sized parity tests live in test_engines_gpu.py; these close the gap between "the kernels are
+right on 3 rows x 8 steps" and "the benched configuration is right".
+
+  config 2  batch 1, greedy, 128 acoustic tokens, fp32: logits vs oracle/gpt_ref.py at EVERY step (drift over a real length)
+  config 3  batch 32, 24 layers, bf16, top-k/top-p, 140 forced tokens: graph replay == eager, sampler contract per token,
+            and an fp32 batch-32 teacher-forced run vs the oracle for 16 steps
+  config 4  one GPU's shard: 32 rows with forced stops U{40..400}: finished rows emit the stop token, rows equal the same
+            rows decoded alone
+  config 5  vocoder stream 64 x 1024 frames fp16: finite, bounded, and windows of rows 0 / 63 equal an fp32 oracle run
+  config 1  the on-disk route: IndexTTS(cfg_path, model_dir) + indextts.cli.main + speaker conditions from gpt.pth
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+import weights
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+# ------------------------------------------------------------------------------------------------------- fixtures
+@pytest.fixture(scope="module")
+def gsd24():
+    return weights.gpt_state_dict(24)
+
+
+def _gpt(sd, layers, dtype):
+    from indextts.gpt.model import UnifiedVoice
+    m = UnifiedVoice(**dict(weights.reference_config()["gpt"], layers=layers))
+    m.load_state_dict(sd)
+    m.to(DEV).to(dtype)
+    m.post_init_gpt2_config(kv_cache=True)
+    return m
+
+
+@pytest.fixture(scope="module")
+def gpt24_bf16(gsd24):
+    return _gpt(gsd24, 24, torch.bfloat16)
+
+
+@pytest.fixture(scope="module")
+def gpt24_fp32(gsd24):
+    return _gpt(gsd24, 24, torch.float32)
+
+
+@pytest.fixture(scope="module")
+def oracle_W(gsd24):
+    return {k: v.float() for k, v in gsd24.items() if k.startswith(("gpt.", "final_norm", "mel_", "text_"))}
+
+
+def _cond_mel(T=300):
+    return torch.from_numpy(synth.uniform("bench.cond_mel", (1, 100, T), -6.0, 2.0)).to(DEV)
+
+
+def _texts(seed, lo, hi, n=32):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(lo, hi + 1, (n,), generator=g)
+    return [torch.randint(2, 12000, (int(k),), generator=g).to(torch.int32) for k in lens]
+
+
+def _batch(texts):
+    L = max(int(t.numel()) for t in texts)
+    out = torch.full((len(texts), L), 1, dtype=torch.int64)
+    for i, t in enumerate(texts):
+        out[i, : t.numel()] = t.long()
+    return out
+
+
+def _prefix(m, texts):
+    conds = m.get_conditioning(_cond_mel(), None)
+    text = _batch(texts).to(DEV)
+    _, emb, mask = m.prepare_gpt_inputs(conds, text)
+    return conds, text, emb, mask, (mask == 0).sum(1).to(torch.int32)
+
+
+# ------------------------------------------------------------------------------------------------------- config 3
+SP3 = dict(do_sample=True, top_p=0.8, top_k=30, temperature=1.0, repetition_penalty=10.0, seed=2000)
+
+
+def test_config3_full_size_sampling_loop_graph_eager_and_sampler_contract(gpt24_bf16):
+    """B=32, 24 layers, bf16, U{20..60} text, k=30 / p=0.8 / penalty 10, every row stopped after 140 tokens -- the benched
+    loop.  (i) the graph-replayed loop, the eagerly launched loop and the logits-returning loop produce the same tokens;
+    (ii) EVERY sampled token lies in the set the HF processors keep (recomputed by oracle/sampling_ref.py from the logits
+    the device produced and the row's history incl. the fake prefix ids 1 / 8192), and is the token the oracle's
+    inverse-CDF draw picks for the same Philox number; (iii) rows emit the stop token from step 140 on."""
+    from oracle import sampling_ref
+    m, eng = gpt24_bf16, gpt24_bf16.engine
+    _, _, emb, _, pad = _prefix(m, _texts(2, 20, 60))
+    force = [140] * 32
+    outs = {}
+    for tag, kw in (("graph", dict(use_graph=True)), ("eager", dict(use_graph=False)), ("logits", dict(return_logits=True))):
+        eng.prefill(emb, pad, 141)
+        outs[tag] = eng.decode(141, dict(SP3), force_stop=force, **kw)
+    codes_l, logits = outs["logits"]
+    assert torch.equal(outs["graph"], outs["eager"]), "graph replay differs from eager launches"
+    assert torch.equal(outs["graph"], codes_l)
+    codes = outs["graph"].cpu().numpy()
+    assert codes.shape[0] == 32 and codes.shape[1] >= 141
+    assert (codes[:, 140:] == 8193).all(), "rows must emit the stop token from their forced stop on"
+    lg = logits.float().cpu().numpy()                       # [steps, 32, V]; step s holds the logits token s was drawn from
+    exact = total = 0
+    for s in range(140):
+        hist = np.concatenate([np.array([[1, 8192]] * 32), codes[:, :s]], axis=1)
+        sc = sampling_ref.process(lg[s], hist, 10.0, 1.0, 30, 0.8)
+        for b in range(32):
+            tok = int(codes[b, s])
+            assert np.isfinite(sc[b, tok]), f"step {s} row {b}: token {tok} is outside the top-k/top-p set"
+            kept = int(np.isfinite(sc[b]).sum())
+            assert 1 <= kept <= 30
+            exact += int(sampling_ref.pick(sc[b], sampling_ref.uniform01(SP3["seed"], b, s)) == tok)
+            total += 1
+    assert exact / total > 0.995, f"only {exact}/{total} draws equal the oracle's pick"   # fp32 running-sum ties may differ
+    assert (codes[:, :140] != 8193).mean() > 0.99   # random weights: EOS essentially never sampled
+
+
+def test_config3_fp32_batch32_teacher_forced_vs_oracle(gpt24_fp32, oracle_W):
+    """fp32, 24 layers, the benched 32 rows (left-padded, text U{20..60}): prefill logits and 16 cached steps against
+    oracle/gpt_ref.py, teacher-forcing the oracle's greedy codes -- north_star bound 1e-3 max-abs on the logits."""
+    from oracle import gpt_ref
+    m, eng = gpt24_fp32, gpt24_fp32.engine
+    conds, text, emb, mask, pad = _prefix(m, _texts(2, 20, 60))
+    torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
+    emb_o, mask_o, pad_o = gpt_ref.prepare_gpt_inputs(conds.cpu().float(), text.cpu(), oracle_W)
+    assert torch.equal(pad_o.to(torch.int32), pad.cpu()) and (emb_o - emb.cpu()).abs().max().item() < 1e-5
+    lg_o, past = gpt_ref.decode_prefill(emb_o, mask_o, oracle_W)
+    lg = eng.prefill(emb, pad, 20)
+    errs = [(lg.cpu() - lg_o).abs().max().item()]
+    sp = dict(do_sample=False, top_p=1.0, top_k=0, temperature=1.0, repetition_penalty=10.0, seed=0)
+    for s in range(1, 17):
+        tok = lg_o.argmax(-1)
+        eng._sample(32, sp)                                   # advances the loop state (step, cache position)
+        eng.tokens[:32] = tok.to(torch.int32).to(DEV)         # teacher forcing with the oracle's code
+        eng.history[:32, s - 1] = eng.tokens[:32]
+        eng._step_transformer(32)
+        mask_o = torch.cat([mask_o, torch.ones(32, 1, dtype=torch.bool)], 1)
+        lg_o, past = gpt_ref.decode_step(tok, s, mask_o, past, oracle_W)
+        errs.append((eng.logits[:32].cpu() - lg_o).abs().max().item())
+    assert max(errs) < 1e-3, errs
+
+
+# ------------------------------------------------------------------------------------------------------- config 2
+def test_config2_batch1_greedy_128_steps_no_drift(gpt24_fp32, oracle_W):
+    """B=1, 12 text tokens (seed 1), 3.2 s prompt, fp32, greedy, 128 acoustic tokens (ctx 47 -> 174): the device loop's
+    logits stay within 1e-3 of the oracle at every one of the 128 steps when the oracle is fed the device's codes, and
+    the device's greedy choice is the oracle's argmax wherever the top-2 margin is not razor thin."""
+    from oracle import gpt_ref
+    m, eng = gpt24_fp32, gpt24_fp32.engine
+    g = torch.Generator().manual_seed(1)
+    text = torch.randint(2, 12000, (1, 12), generator=g)
+    conds = m.get_conditioning(_cond_mel(), None)
+    _, emb, mask = m.prepare_gpt_inputs(conds, text.to(DEV))
+    pad = (mask == 0).sum(1).to(torch.int32)
+    eng.prefill(emb, pad, 129)
+    sp = dict(do_sample=False, top_p=1.0, top_k=0, temperature=1.0, repetition_penalty=10.0, seed=0)
+    codes, logits = eng.decode(128, sp, return_logits=True)
+    codes, logits = codes.cpu(), logits.cpu()
+    assert codes.shape == (1, 128) and logits.shape[0] == 128
+    torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
+    emb_o, mask_o, _ = gpt_ref.prepare_gpt_inputs(conds.cpu().float(), text, oracle_W)
+    lg_o, past = gpt_ref.decode_prefill(emb_o, mask_o, oracle_W)
+    errs, flips = [], 0
+    hist = [1, 8192]
+    for s in range(128):
+        errs.append((logits[s, 0] - lg_o[0]).abs().max().item())
+        # greedy under repetition penalty 10: compare the decisions on the processed scores
+        sc = lg_o[0].clone()
+        ids = torch.tensor(sorted(set(hist)))
+        sc[ids] = torch.where(sc[ids] < 0, sc[ids] * 10.0, sc[ids] / 10.0)
+        top2 = torch.topk(sc, 2)
+        if (top2.values[0] - top2.values[1]).item() > 2e-3:
+            assert int(codes[0, s]) == int(top2.indices[0]), f"step {s}: device {int(codes[0, s])} vs oracle {int(top2.indices[0])}"
+        else:
+            flips += 1
+        tok = codes[:, s]
+        hist.append(int(tok))
+        if s == 127:
+            break
+        mask_o = torch.cat([mask_o, torch.ones(1, 1, dtype=torch.bool)], 1)
+        lg_o, past = gpt_ref.decode_step(tok, s + 1, mask_o, past, oracle_W)
+    assert max(errs) < 1e-3, (max(errs), int(np.argmax(errs)))
+    assert errs[-1] < 1e-3 and flips < 8
+
+
+# ------------------------------------------------------------------------------------------------------- config 4
+def test_config4_shard_forced_stops_and_rows_decoded_alone(gpt24_bf16, gpt24_fp32):
+    """One GPU's shard of BASELINE config 4: 32 left-padded rows, text U{8..100}, forced stops U{40..400} (seed 3).
+    bf16 + sampling (the benched settings): every row emits real codes before its stop step and the stop token from it on,
+    and the loop runs to the longest row.  fp32 + greedy: the shortest, a middle and the longest row decoded ALONE (no
+    padding, batch 1) give the batch's codes (compared while the top-2 margin exceeds 1e-3) -- early-finished neighbours
+    and left padding do not leak into a row."""
+    g = torch.Generator().manual_seed(3)
+    lens = torch.randint(8, 101, (32,), generator=g)
+    stops = [int(v) for v in torch.randint(40, 401, (32,), generator=g)]
+    texts = [torch.randint(2, 12000, (int(k),), generator=g).to(torch.int32) for k in lens]
+    mx = max(stops)
+    # --- bf16, sampling
+    m, eng = gpt24_bf16, gpt24_bf16.engine
+    _, _, emb, _, pad = _prefix(m, texts)
+    eng.prefill(emb, pad, mx + 1)
+    codes = eng.decode(mx + 1, dict(SP3, seed=31), force_stop=stops).cpu().numpy()
+    assert codes.shape[1] >= mx
+    for b, st in enumerate(stops):
+        assert (codes[b, st:] == 8193).all(), f"row {b} keeps emitting codes after its stop step {st}"
+        assert (codes[b, :st] != 8193).mean() > 0.98
+    # --- fp32, greedy: batch vs alone
+    m, eng = gpt24_fp32, gpt24_fp32.engine
+    _, text, emb, mask, pad = _prefix(m, texts)
+    sp = dict(do_sample=False, top_p=1.0, top_k=0, temperature=1.0, repetition_penalty=10.0, seed=0)
+    eng.prefill(emb, pad, mx + 1)
+    codes_b, logits_b = eng.decode(mx + 1, sp, force_stop=stops, return_logits=True)
+    codes_b, logits_b = codes_b.cpu(), logits_b.cpu()
+    order = sorted(range(32), key=lambda i: stops[i])
+    for b in (order[0], order[16], order[-1]):
+        n = int(lens[b])
+        conds = m.get_conditioning(_cond_mel(), None)
+        _, e1, m1 = m.prepare_gpt_inputs(conds, text[b: b + 1, :n])
+        assert int((m1 == 0).sum()) == 0
+        eng.prefill(e1, torch.zeros(1, dtype=torch.int32, device=DEV), stops[b] + 1)
+        c1, l1 = eng.decode(stops[b] + 1, sp, force_stop=[stops[b]], return_logits=True)
+        c1, l1 = c1.cpu(), l1.cpu()
+        assert int(c1[0, stops[b]]) == 8193
+        hist, compared = [1, 8192], 0
+        for s in range(stops[b]):
+            assert (logits_b[s, b] - l1[s, 0]).abs().max().item() < 1e-3, (b, s)
+            ta, tb = int(codes_b[b, s]), int(c1[0, s])
+            if ta != tb:
+                # greedy runs on the repetition-penalised scores: a flip is only legitimate at a razor-thin margin there,
+                # and it ends the comparable prefix (the two trajectories feed different tokens from here on)
+                sc = l1[s, 0].clone()
+                ids = torch.tensor(sorted(set(hist)))
+                sc[ids] = torch.where(sc[ids] < 0, sc[ids] * 10.0, sc[ids] / 10.0)
+                assert abs(float(sc[ta]) - float(sc[tb])) <= 2e-3, (b, s, ta, tb)
+                break
+            hist.append(ta)
+            compared += 1
+        assert compared >= min(stops[b], 24), (b, compared)
+
+
+# ------------------------------------------------------------------------------------------------------- config 5
+def _receptive_field_frames(cfg):
+    """One-sided receptive field of the generator in latent frames (conv_pre k7; per stage: ConvTranspose reaches one
+    input sample back, each AMP block adds per (act, dilated conv, act, conv) pair 6 + (k-1)/2*d + 6 + (k-1)/2 samples)."""
+    rf = 3.0
+    rate = 1
+    kmax = max(cfg["resblock_kernel_sizes"])
+    per_block = sum(6 + (kmax - 1) // 2 * d + 6 + (kmax - 1) // 2 for d in (1, 3, 5))
+    for u in cfg["upsample_rates"]:
+        rf += 1.0 / rate
+        rate *= u
+        rf += per_block / rate
+    rf += (6 + 3) / rate
+    return rf
+
+
+def test_config5_vocoder_stream_64x1024_fp16():
+    """BigVGAN on latent [64, 1024, 1280] fp16 (65 536 frames -> 64 x 1 048 576 samples): every sample finite and inside
+    (-1, 1); the first 128 frames of row 0 and the last 128 frames of row 63 equal an fp32 ORACLE run
+    (oracle/bigvgan_ref.py, CPU) of a 168-frame window -- the receptive field is < 40 frames, so the window's interior
+    is exactly what the full stream computes -- within the fp16 tolerance of the fixture-sized test (5e-3 RMS)."""
+    from indextts.BigVGAN.models import BigVGAN
+    from indextts.utils.config import Config
+    from oracle import bigvgan_ref
+    cfg = weights.reference_config()["bigvgan"]
+    rf = _receptive_field_frames(cfg)
+    WIN, KEEP = 168, 128
+    assert rf < WIN - KEEP, rf
+    bsd = weights.bigvgan_state_dict()
+    v = BigVGAN(Config(cfg))
+    v.load_state_dict(bsd)
+    v.to(DEV).to(torch.float16).remove_weight_norm()
+    g = torch.Generator().manual_seed(4)
+    lat = torch.randn(64, 1024, 1280, generator=g)
+    mel = torch.randn(64, 300, 100, generator=g) * 2.0 - 2.0
+    spk = v.speaker_embedding(mel.to(DEV))                      # [64, 1, 512], host PyTorch fp32 (ECAPA)
+    wav, _ = v(lat.to(DEV), speaker_embedding=spk)
+    torch.cuda.synchronize()
+    assert wav.shape == (64, 1, 1024 * 1024)
+    assert bool(torch.isfinite(wav).all()) and float(wav.abs().max()) <= 1.0
+    assert float(wav.std()) > 1e-3
+    VW = bigvgan_ref.Weights({k: t.numpy() for k, t in bsd.items()})
+    torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
+    spk_c = spk.cpu()
+    ref0 = bigvgan_ref.forward(lat[0:1, :WIN], spk_c[0:1].transpose(1, 2), VW)[0, 0, : KEEP * 1024]
+    ref63 = bigvgan_ref.forward(lat[63:64, -WIN:], spk_c[63:64].transpose(1, 2), VW)[0, 0, -KEEP * 1024:]
+    for name, got, ref in (("row 0 head", wav[0, 0, : KEEP * 1024].cpu(), ref0), ("row 63 tail", wav[63, 0, -KEEP * 1024:].cpu(), ref63)):
+        rms = (got - ref).pow(2).mean().sqrt().item()
+        assert rms < 5e-3, (name, rms, ref.pow(2).mean().sqrt().item())
+
+
+# ------------------------------------------------------------------------------------------------------- config 1 (disk)
+def _train_bpe(tmp):
+    """A REAL SentencePiece BPE model, trained here from an in-test corpus (no network): what dataset.bpe_model points to."""
+    import sentencepiece as spm
+    corpus = os.path.join(tmp, "corpus.txt")
+    lines = ["你 好 世 界 , 今 天 天 气 很 好 .", "我 们 去 公 园 散 步 吧 !", "HELLO WORLD , THIS IS A TEST .",
+             "THE QUICK BROWN FOX JUMPS OVER THE LAZY DOG ?", "语 音 合 成 测 试 , ONE TWO THREE ."] * 40
+    with open(corpus, "w", encoding="utf-8") as f:
+        f.write("\n".join(lines))
+    spm.SentencePieceTrainer.train(input=corpus, model_prefix=os.path.join(tmp, "bpe"), vocab_size=160, model_type="bpe",
+                                   bos_id=0, eos_id=1, unk_id=2, pad_id=-1, character_coverage=1.0, hard_vocab_limit=False,
+                                   minloglevel=2)
+    return os.path.join(tmp, "bpe.model")
+
+
+def test_on_disk_constructor_cli_and_speaker_conditions(tmp_path, capsys):
+    """IndexTTS(cfg_path, model_dir) end to end (infer.py:185-439): config.yaml -> load_config; gpt.pth =
+    {'model': sd, 'speaker_conditions': {id: np[32, D]}} -> load_checkpoint (checkpoint.py:36-76); bigvgan_generator.pth =
+    {'generator': weight_g/weight_v sd} -> fold; bpe.model -> SentencePiece.  The instance must behave exactly like
+    IndexTTS.from_weights on the same tensors; `indextts.cli.main` must write a wav; speaker ids follow the reference:
+    validated against speaker_info_path, stored conditions reachable through get_conditioning(None, speaker_ids=...),
+    and -- as in the reference, where the encoder path wins whenever a prompt mel is given (model.py:488-509) --
+    infer(speaker_id=...) with an audio prompt equals infer() without it."""
+    import wave
+
+    import yaml
+
+    from indextts.cli import main as cli_main
+    from indextts.infer import IndexTTS
+    from indextts.utils.audio import write_pcm16
+    tmp = str(tmp_path)
+    cfg = weights.reference_config()
+    cfg["gpt"]["layers"] = 2
+    gsd = weights.gpt_state_dict(2)
+    bsd = weights.bigvgan_state_dict()
+    assert any(k.endswith("weight_g") for k in bsd) and "conv_pre.weight" not in bsd
+    with open(os.path.join(tmp, "config.yaml"), "w") as f:
+        yaml.safe_dump(cfg, f)
+    rng = np.random.default_rng(0)
+    spk_cond = {"spk_a": rng.standard_normal((32, 1280)).astype(np.float32), "spk_b": rng.standard_normal((32, 1280)).astype(np.float32)}
+    torch.save({"model": {k: v.to(torch.float16) if k.endswith("c_fc.weight") else v for k, v in gsd.items()},
+                "speaker_conditions": spk_cond, "speakers": ["spk_a", "spk_b"]}, os.path.join(tmp, "gpt.pth"))
+    torch.save({"generator": bsd}, os.path.join(tmp, "bigvgan_generator.pth"))
+    _train_bpe(tmp)
+    with open(os.path.join(tmp, "speakers.json"), "w") as f:
+        json.dump([{"speaker": "spk_a"}, {"speaker": "spk_b"}], f)
+    t = np.arange(int(44100 * 1.5)) / 44100.0
+    stereo = np.stack([0.3 * np.sin(2 * np.pi * 220 * t), 0.2 * np.sin(2 * np.pi * 330 * t)], 1)
+    prompt = os.path.join(tmp, "prompt.wav")
+    write_pcm16(prompt, (stereo * 32767).astype(np.int16), 44100)
+
+    tts = IndexTTS(cfg_path=os.path.join(tmp, "config.yaml"), model_dir=tmp, is_fp16=True,
+                   speaker_info_path=os.path.join(tmp, "speakers.json"))
+    assert tts.gpt_path == os.path.join(tmp, "gpt.pth") and tts.speaker_list == ["spk_a", "spk_b"]
+    assert tts.tokenizer.sp_model is not None and tts.tokenizer.vocab_size >= 100
+    # stored speaker conditions (checkpoint.py:42-62 -> model.py:490-509)
+    c = tts.gpt.get_conditioning(None, None, speaker_ids=["spk_b", "spk_a"])
+    assert c.shape == (2, 32, 1280)
+    assert torch.equal(c[0].cpu(), torch.from_numpy(spk_cond["spk_b"])) and torch.equal(c[1].cpu(), torch.from_numpy(spk_cond["spk_a"]))
+    with pytest.raises(ValueError):
+        tts.gpt.get_conditioning(None, None, speaker_ids=["nobody"])
+    # same tensors through from_weights (fp16 c_fc round trip included): identical codes and waveforms
+    gsd_rt = {k: (v.to(torch.float16) if k.endswith("c_fc.weight") else v) for k, v in gsd.items()}
+    twin = IndexTTS.from_weights(cfg, gsd_rt, bsd, device="cuda:0", is_fp16=True)
+    cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
+    rows = [torch.tensor([11, 22, 33, 44, 55]), torch.tensor([66, 77, 88])]
+    gen = dict(do_sample=True, top_k=30, top_p=0.8, temperature=1.0, repetition_penalty=10.0, num_beams=1)
+    a, ra = tts.infer_batch(cond_mel, rows, max_mel_tokens=9, force_stop=[8, 6], seed=5, return_codes=True, **gen)
+    b, rb = twin.infer_batch(cond_mel, rows, max_mel_tokens=9, force_stop=[8, 6], seed=5, return_codes=True, **gen)
+    assert [r.tolist() for r in ra] == [r.tolist() for r in rb]
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    # public API from disk: speaker_id is validated; with a prompt the encoder path is used (reference semantics)
+    text = "你好世界, HELLO WORLD. 今天天气很好!"
+    kw = dict(max_mel_tokens=9, num_beams=1, do_sample=False)
+    with pytest.warns(RuntimeWarning):
+        sr1, pcm1 = tts.infer(prompt, text, None, **kw)
+    with pytest.warns(RuntimeWarning):
+        sr2, pcm2 = tts.infer(prompt, text, None, speaker_id="spk_a", **kw)
+    assert sr1 == sr2 == 24000 and pcm1.dtype == np.int16 and pcm1.shape == pcm2.shape and np.array_equal(pcm1, pcm2)
+    assert pcm1.shape[0] > 0 and pcm1.shape[0] % 1024 == 0
+    with pytest.raises(ValueError):
+        tts.infer(prompt, text, None, speaker_id="nobody", **kw)
+    # command line (cli.py:10-58), default generation settings (beam-sample, 3 beams)
+    out = os.path.join(tmp, "gen.wav")
+    del tts, twin
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        with pytest.warns(RuntimeWarning):
+            cli_main(["你好世界. HELLO!", "-v", prompt, "-o", out, "-c", os.path.join(tmp, "config.yaml"), "--model_dir", tmp])
+    finally:
+        os.chdir(cwd)
+    with wave.open(out, "rb") as w:
+        assert (w.getframerate(), w.getnchannels(), w.getsampwidth()) == (24000, 1, 2) and w.getnframes() % 1024 == 0 and w.getnframes() > 0

@@ -59,12 +59,19 @@ def test_gpt_decode_logits_and_latent_fp32(tag, layers, gpt_small_fp32):
         eng._step_transformer(3)
         errs.append((eng.logits[:3].cpu() - torch.from_numpy(g["logits"][s])).abs().max().item())
     assert max(errs) < 1e-3, errs
-    # greedy choices equal the reference's wherever the decision margin is not razor thin
+    # greedy choices equal the reference's wherever the decision margin (on the repetition-penalised scores the greedy
+    # rule sees: ids 1, 8192 and the row's earlier codes divided / multiplied by 10) exceeds twice the logit tolerance
+    decided = 0
     for s, c in enumerate(got_codes):
-        lg = g["logits"][s].copy()
-        ref_c = g["codes"][:, s]
-        agree = c == ref_c
-        assert agree.mean() >= 2 / 3, (s, c, ref_c)
+        for b in range(3):
+            sc = torch.from_numpy(g["logits"][s][b].copy())
+            ids = torch.tensor(sorted({1, 8192} | {int(v) for v in g["codes"][b, :s]}))
+            sc[ids] = torch.where(sc[ids] < 0, sc[ids] * 10.0, sc[ids] / 10.0)
+            top2 = torch.topk(sc, 2)
+            if (top2.values[0] - top2.values[1]).item() > 2e-3:
+                assert int(c[b]) == int(g["codes"][b, s]) == int(top2.indices[0]), (s, b, c, g["codes"][:, s])
+                decided += 1
+    assert decided >= 2 * len(got_codes), decided   # the margin rule must not make the check vacuous
     # latent pass (row 0)
     n = int(g["text_lens"][0])
     lat = m(cond_mel, text[0:1, :n], torch.tensor([n]), torch.from_numpy(g["codes"][0:1]).to(DEV),
@@ -90,7 +97,6 @@ def test_decode_loop_graph_equals_eager_and_pad_invariance(gpt_small_fp32):
     codes_b, logits_b = eng.decode(24, sp, use_graph=False, return_logits=True)
     assert torch.equal(codes_a, codes_b)
     assert torch.equal(logits_a, logits_b)
-    assert np.array_equal(codes_a[:, :8].cpu().numpy(), g["codes"]) or True  # informative only: ties can flip
     n2 = int(g["text_lens"][2])
     codes_1, logits_1 = m.inference_speech(cond_mel, text[2:3, :n2], return_logits=True, **kw)
     la, l1 = logits_a[:, 2].cpu(), logits_1[:, 0].cpu()
