@@ -1,5 +1,6 @@
 // Bandwidth-bound kernels: anti-aliased SnakeBeta activation, LayerNorm, embedding step, tanh -> PCM16.
 #include "common.h"
+#include "ln_math.h"
 #include "aa_tile.h"
 
 namespace itts {
@@ -314,43 +315,8 @@ __global__ __launch_bounds__(1024) void ln_reduce_wide_kernel(float* __restrict_
     for (int sidx = 0; sidx < NSLAB; ++sidx) v += sl[sidx];  // same association order as the one-wave form
     st16(hr + tid * 4, v);
   }
-#pragma unroll
-  for (int pass = 0; pass < (LN2 ? 2 : 1); ++pass) {
-    float s = wave_sum(v[0] + v[1] + v[2] + v[3]);
-    if (lane == 0) red[pass][0][wave] = s;
-    __syncthreads();
-    float tot = 0.f;
-    for (int i = 0; i < nw; ++i) tot += red[pass][0][i];
-    const float mean = tot / (float)D;
-    float q = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float d = v[e] - mean;
-      q = fmaf(d, d, q);
-    }
-    q = wave_sum(q);
-    if (lane == 0) red[pass][1][wave] = q;
-    __syncthreads();
-    float qt = 0.f;
-    for (int i = 0; i < nw; ++i) qt += red[pass][1][i];
-    const float rstd = rsqrtf(qt / (float)D + 1e-5f);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float ww = pass == 0 ? lw[e] : lw2[e];
-      float bb = pass == 0 ? lb[e] : lb2[e];
-      v[e] = (v[e] - mean) * rstd * ww + bb;
-    }
-  }
-  T* yr = y + (int64_t)row * D;
-  if constexpr (sizeof(T) == 4) {
-    st16(yr + tid * 4, v);
-  } else {
-    typedef T t4 __attribute__((ext_vector_type(4)));
-    t4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f(v[e]);
-    *reinterpret_cast<t4*>(yr + tid * 4) = o;
-  }
+  wide_layernorm<LN2>(v, lw, lb, lw2, lb2, &red[0][0][0], tid, nw, D, true);
+  store_row4<T>(y + (int64_t)row * D + tid * 4, v);
 }
 
 template <typename T, int NV>

@@ -327,3 +327,26 @@ def test_beam_decode_full_size_bf16_graph_equals_eager():
         eng.prefill(emb.repeat_interleave(3, 0), pad.repeat_interleave(3), 14)
         outs.append(eng.decode_beam(14, sp, 3, use_graph=use_graph, check_every=4).cpu())
     assert outs[0].shape[0] == 2 and torch.equal(outs[0], outs[1])
+
+
+def test_beam_graphs_follow_their_buffers(gpt_small_fp32):
+    """decode_beam with B=2, then B=1, then B=2 on ONE engine: the per-(B, num_beams) buffers are reallocated in between,
+    so a captured beam step must not survive them (it would replay over freed memory).  Graph replay == eager each time."""
+    m, eng = gpt_small_fp32, gpt_small_fp32.engine
+    cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
+    conds = m.get_conditioning(cond_mel, torch.tensor([120], device=DEV))
+    sp = dict(do_sample=True, top_p=0.8, top_k=30, temperature=1.0, repetition_penalty=10.0, seed=3, length_penalty=0.0)
+    texts = {2: torch.tensor([[11, 22, 33, 44, 55, 66], [77, 88, 99, 1, 1, 1]], device=DEV),
+             1: torch.tensor([[5, 6, 7, 8, 9]], device=DEV)}
+    want = {}
+    for B in (2, 1):
+        _, emb, mask = m.prepare_gpt_inputs(conds, texts[B])
+        pad = (mask == 0).sum(1).to(torch.int32)
+        eng.prefill(emb.repeat_interleave(3, 0), pad.repeat_interleave(3), 12)
+        want[B] = eng.decode_beam(12, sp, 3, use_graph=False).cpu()
+    for B in (2, 1, 2, 1):
+        _, emb, mask = m.prepare_gpt_inputs(conds, texts[B])
+        pad = (mask == 0).sum(1).to(torch.int32)
+        eng.prefill(emb.repeat_interleave(3, 0), pad.repeat_interleave(3), 12)
+        got = eng.decode_beam(12, sp, 3, use_graph=True, check_every=4).cpu()
+        assert torch.equal(got, want[B]), B
