@@ -48,14 +48,12 @@ extern "C" {
 #define ITTS_BF16 1
 #define ITTS_F16 2
 
-#define ITTS_ABI_VERSION 1
+#define ITTS_ABI_VERSION 2
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
-/* tuning/debug knob, not part of the product path: key 1 = column tiles per skinny-GEMM workgroup, key 2 = waves per
- * skinny-GEMM workgroup, key 3 = plain-GEMM kernel override (0 restores the built-in heuristic), key 4 = waves per
- * decode-attention workgroup (4 or 8; measured equal) */
-int itts_debug_set(int key, int value);
+/* The product library keeps no process-wide mutable state besides this thread-local error string and immutable tables:
+ * tuning overrides and in-kernel time stamps exist only in the diagnostic build (include/indextts_hip_diag.h). */
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Packed weight layout (shared by itts_gemm_skinny and itts_gemm_conv).  A logical matrix W[K][N] (K = reduction
@@ -81,10 +79,10 @@ int itts_aa_snake_fwd(const void* x, void* y, const float* alpha_log, const floa
                       const float* down_filter12, int B, int T, int C, int dtype, int layout, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
- * Skinny GEMM for the decode step: Y[M][N] = epi( X[M][K] @ W[K][N] + bias ), M <= 32 (bf16/f16) or <= 16 (f32)
- * rows per launch (larger M is processed in row chunks by the entry point).  One 16-column tile (x one K slice) per
- * workgroup, the K range split over the workgroup's waves and reduced deterministically through LDS; every global
- * load is issued before its first use (one memory round trip per launch).
+ * Skinny GEMM for the decode step: Y[M][N] = epi( X[M][K] @ W[K][N] + bias ), up to 96 rows (bf16/f16; 16 in fp32) per
+ * pass over the weights (larger M is processed in row chunks by the entry point).  1-3 16-column tiles (x one K slice)
+ * per workgroup, the K range split over the workgroup's waves and reduced deterministically through LDS; every global
+ * load is issued before its first use (one memory round trip per launch); 8/16-byte epilogue accesses.
  * ------------------------------------------------------------------------------------------------------------------ */
 #define ITTS_EPI_STORE 0      /* y (T [M][N]) = v */
 #define ITTS_EPI_GELU_STORE 1 /* y (T [M][N]) = gelu_new(v) */
@@ -92,14 +90,14 @@ int itts_aa_snake_fwd(const void* x, void* y, const float* alpha_log, const floa
 #define ITTS_EPI_QKV_CACHE 3  /* cols [0,D): y (T [M][D]) = v ; [D,2D): K cache ; [2D,3D): V cache, at position *pos */
 #define ITTS_EPI_STORE_F32 4  /* yf (fp32 [M][N]) = v               (logits) */
 #define ITTS_EPI_SLAB_F32 5   /* yf (fp32 [ksplit][M][N]): slice ks stores its partial product (bias added by slice 0);
-                                 the slabs are summed in order by itts_ln_reduce */
+                                 the slabs are summed in order by itts_ln_reduce, or by this launch's reducer tail */
 
 typedef struct itts_skinny_args {
   int dtype;
   int M, N, K;
   const void* wp;    /* packed W */
   const float* bias; /* [N] or NULL */
-  const void* x;     /* T [M][K]  (fp32 [M][K] when x_ln_f32 != 0) */
+  const void* x;     /* T [M][K] */
   int epi;
   void* y;
   float* yf;
@@ -108,23 +106,33 @@ typedef struct itts_skinny_args {
   const int32_t* pos; /* device scalar: cache row to write */
   int heads, smax;
   int ksplit; /* split-K over workgroups (grid.y); > 1 only with ITTS_EPI_SLAB_F32 */
-  int x_ln_f32; /* != 0: x is the fp32 residual stream and is normalised per row on the fly, (x - mean) * rstd with eps
-                   1e-5 (LayerNorm without its affine part, which the caller folds into W and bias); needs ksplit 1 */
-  /* Producer stage in the same launch (ln_h != NULL; needs ksplit 1, M <= 32, K % 256 == 0, K / 32 <= 40 k-steps):
-   * M extra workgroups first compute x[row] = LayerNorm(ln_h[row] + ln_bias + sum of ln_nslab split-K slabs; ln_w, ln_b)
-   * exactly as itts_ln_reduce does (ln_h is updated in place), publish the row (write-through stores, one agent-scope
-   * counter add per row) and exit; the GEMM workgroups request their weight blocks first, then wait for the counter to
-   * reach M, then read x.  ln_counter must be 0 at launch; ln_counter_prev (another launch's counter, or NULL) is zeroed. */
-  float* ln_h;
-  const float* ln_slab;
-  int ln_nslab;
-  const float* ln_bias;
-  const float* ln_w;
-  const float* ln_b;
-  int32_t* ln_counter;
-  int32_t* ln_counter_prev;
+  /* Reducer tail (tail_h != NULL; needs ITTS_EPI_SLAB_F32, ksplit <= 4, N % 4 == 0, N <= 2048, all M rows in ONE launch and
+   * M <= workgroups <= 256).  After a workgroup has stored its slab tile (write-through) it draws an arrival ticket from
+   * *tail_counter; the last M arrivals wait until every ticket of the launch is drawn, then arrival i reduces row i:
+   *     tail_h[row][:] += tail_bias[:] + slab[0][row][:] + ... + slab[ksplit-1][row][:]      (fixed order, in place)
+   *     tail_y[row][:]  = LN(tail_h[row]; tail_w, tail_b)   (then LN(.; tail_w2, tail_b2) if tail_w2 != NULL),  T [M][N]
+   * bit for bit what itts_ln_reduce computes in a launch of its own.  Counter protocol: *tail_counter is monotonic and is
+   * never reset by the kernel; a launch expects its tickets in [(e-1)*W, e*W) where e = *tail_epoch (a device word the
+   * caller advances once per use of this launch site, e.g. once per decode step) and W = workgroups of the launch; start
+   * from counter = 0, epoch = 1.  A reducer that waits too long, or tickets outside the window, set *tail_err (sticky,
+   * non-zero): the caller checks it when it next synchronises.  tail_acquire != 0 adds an agent-scope acquire fence after
+   * the wait (the slab bytes are read with L1-bypassing loads either way). */
+  float* tail_h;
+  const float* tail_bias;
+  const float* tail_w;
+  const float* tail_b;
+  const float* tail_w2;
+  const float* tail_b2;
+  void* tail_y;
+  int32_t* tail_counter;
+  const int32_t* tail_epoch;
+  int32_t* tail_err;
+  int tail_acquire;
 } itts_skinny_args;
 int itts_gemm_skinny(const itts_skinny_args* a, void* stream);
+/* launch geometry itts_gemm_skinny would use: out6 = {grid.x, grid.y, waves per workgroup, column tiles per workgroup,
+ * k-steps per wave, dynamic LDS bytes} (host-only, launches nothing) */
+int itts_skinny_plan(int dtype, int M, int N, int K, int ksplit, int* out6);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Tiled MFMA GEMM / 1-D convolution, channels-last.
@@ -167,9 +175,10 @@ int itts_layernorm(const float* h, const float* w, const float* b, const float* 
 int itts_ln_reduce(float* h, const float* slab, int nslab, const float* bias, const float* w, const float* b,
                    const float* w2, const float* b2, void* y, int M, int D, int dtype, void* stream);
 
-/* h[b][:] = table[tokens[b]][:] + pos_table[*step + pos_add][:]   (fp32 tables, fp32 h) */
+/* h[b][:] = table[tokens[b]][:] + pos_table[*step + pos_add][:]   (fp32 tables, fp32 h).  If epoch != NULL, *epoch is
+ * incremented once (the first launch of a decode step advances the epoch of that step's reducer tails). */
 int itts_embed_step(const int32_t* tokens, const float* table, const float* pos_table, const int32_t* step, int pos_add,
-                    float* h, int B, int D, void* stream);
+                    float* h, int B, int D, int32_t* epoch, void* stream);
 
 /* Single-query attention over the KV cache (decode).  q,out: T [B][H*64]; caches T [B][H][smax][64];
  * keys j in [pad[b], *pos] are visible (the key at *pos was just appended).  scale 1/8. */

@@ -286,7 +286,11 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const T* __restrict__
 
 using namespace itts;
 
-namespace itts { int g_attn_waves = 4; }  // itts_debug_set(4, 4|8): waves per decode-attention workgroup
+#if ITTS_DIAG
+namespace itts { int g_attn_waves = 4; }  // diagnostic build: itts_debug_set(4, 4|8) waves per decode-attention workgroup
+#else
+namespace itts { constexpr int g_attn_waves = 4; }  // measured equal to 8; the 8-wave instantiation folds away
+#endif
 
 extern "C" int itts_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, const int32_t* pad,
                                 const int32_t* pos, int B, int H, int smax, int dtype, void* stream) {

@@ -5,6 +5,15 @@
 
 #include "../../include/indextts_hip.h"
 
+// ITTS_DIAG = 1 builds libindextts_hip_diag.so (make diag): tuning overrides + in-kernel time stamps for the tools/
+// scripts.  The product library has neither: no process-wide mutable state besides immutable tables.
+#ifndef ITTS_DIAG
+#define ITTS_DIAG 0
+#endif
+#if ITTS_DIAG
+#include "../../include/indextts_hip_diag.h"
+#endif
+
 namespace itts {
 
 typedef __bf16 bf16_t;

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(1024) void ln_reduce_wide_kernel(float* __restrict_
                                                               const float* __restrict__ b, const float* __restrict__ w2,
                                                               const float* __restrict__ b2, T* __restrict__ y, int M, int D) {
   __shared__ float red[2][2][16];
-  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int row = blockIdx.x, tid = threadIdx.x, nw = blockDim.x >> 6;
   float* hr = h + (int64_t)row * D;
   f32x4 v = ld16<f32x4>(hr + tid * 4);
   const f32x4 lw = ld16<f32x4>(w + tid * 4), lb = ld16<f32x4>(b + tid * 4);
@@ -336,16 +336,12 @@ static int launch_ln_reduce(float* h, const float* slab, int nslab, const float*
     if (two) ITTS_LNR(4, true); else ITTS_LNR(4, false);
   } else if (nslab == 3) {
     if (two) ITTS_LNR(3, true); else ITTS_LNR(3, false);
-  } else if (nslab == 6) {
-    if (two) ITTS_LNR(6, true); else ITTS_LNR(6, false);
-  } else if (nslab == 8) {
-    if (two) ITTS_LNR(8, true); else ITTS_LNR(8, false);
   } else if (nslab == 2) {
     if (two) ITTS_LNR(2, true); else ITTS_LNR(2, false);
   } else if (nslab == 1) {
     if (two) ITTS_LNR(1, true); else ITTS_LNR(1, false);
   } else {
-    set_error("itts_ln_reduce: nslab must be 0..4, 6 or 8 (got %d)", nslab);
+    set_error("itts_ln_reduce: nslab must be 0..4 (got %d)", nslab);
     return ITTS_ERR_INVALID;
   }
 #undef ITTS_LNR
@@ -355,8 +351,9 @@ static int launch_ln_reduce(float* h, const float* slab, int nslab, const float*
 __global__ __launch_bounds__(256) void embed_step_kernel(const int32_t* __restrict__ tokens, const float* __restrict__ table,
                                                           const float* __restrict__ pos_table,
                                                           const int32_t* __restrict__ step, int pos_add,
-                                                          float* __restrict__ h, int D) {
+                                                          float* __restrict__ h, int D, int32_t* __restrict__ epoch) {
   int b = blockIdx.x;
+  if (epoch != nullptr && b == 0 && threadIdx.x == 0) epoch[0] = epoch[0] + 1;  // read by LATER launches of this step only
   int tok = tokens[b];
   int p = step[0] + pos_add;
   const float* e = table + (int64_t)tok * D;
@@ -476,29 +473,27 @@ extern "C" int itts_ln_reduce(float* h, const float* slab, int nslab, const floa
   ITTS_REQUIRE(h && w && b && y, "itts_ln_reduce: null pointer");
   ITTS_REQUIRE(nslab >= 0 && (nslab == 0 || slab != nullptr), "itts_ln_reduce: slab missing");
   ITTS_REQUIRE((w2 == nullptr) == (b2 == nullptr), "itts_ln_reduce: pass both or neither of w2/b2");
-  ITTS_REQUIRE(D % 4 == 0 && D <= 4 * 64 * 8 && D > 0, "itts_ln_reduce: unsupported D=%d (max 2048)", D);
+  // D % 256 == 0 (<= 4096): one float4 per thread, D/4 threads per row; any other D <= 1280: one wave per row
+  ITTS_REQUIRE(D % 4 == 0 && D > 0 && ((D % 256 == 0 && D <= 4096) || D <= 4 * 64 * 5),
+               "itts_ln_reduce: unsupported D=%d (a multiple of 256 up to 4096, or any multiple of 4 up to 1280)", D);
   if (M == 0) return ITTS_OK;
   hipStream_t s = (hipStream_t)stream;
-  const int nvl = (D / 4 + 63) / 64;  // float4 per lane
-#define ITTS_LNR_T(TT_)                                                                                         \
-  (nvl <= 5 ? launch_ln_reduce<TT_, 5>(h, slab, nslab, bias, w, b, w2, b2, (TT_*)y, M, D, s)                     \
-            : launch_ln_reduce<TT_, 8>(h, slab, nslab, bias, w, b, w2, b2, (TT_*)y, M, D, s))
   switch (dtype) {
     case ITTS_F32:
-      return ITTS_LNR_T(float);
+      return launch_ln_reduce<float, 5>(h, slab, nslab, bias, w, b, w2, b2, (float*)y, M, D, s);
     case ITTS_BF16:
-      return ITTS_LNR_T(bf16_t);
+      return launch_ln_reduce<bf16_t, 5>(h, slab, nslab, bias, w, b, w2, b2, (bf16_t*)y, M, D, s);
     case ITTS_F16:
-      return ITTS_LNR_T(f16_t);
+      return launch_ln_reduce<f16_t, 5>(h, slab, nslab, bias, w, b, w2, b2, (f16_t*)y, M, D, s);
   }
-#undef ITTS_LNR_T
   ITTS_REQUIRE(false, "itts_ln_reduce: unknown dtype %d", dtype);
 }
 
 extern "C" int itts_embed_step(const int32_t* tokens, const float* table, const float* pos_table, const int32_t* step,
-                               int pos_add, float* h, int B, int D, void* stream) {
+                               int pos_add, float* h, int B, int D, int32_t* epoch, void* stream) {
   ITTS_REQUIRE(tokens && table && pos_table && step && h && B > 0 && D > 0, "itts_embed_step: bad arguments");
-  hipLaunchKernelGGL(embed_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, tokens, table, pos_table, step, pos_add, h, D);
+  hipLaunchKernelGGL(embed_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, tokens, table, pos_table, step, pos_add, h, D,
+                     epoch);
   return check_launch("itts_embed_step");
 }
 

@@ -9,6 +9,8 @@
 // 144 B so the 16-row fragment reads (ds_read_b128) are bank-conflict free.  Packed weight blocks go straight from
 // L2 into B-fragment registers (they are shared only by workgroups, which L2 serves), double-buffered one step ahead;
 // the next chunk's activation rows are fetched into registers while the current chunk is being multiplied.
+#include <mutex>
+
 #include "common.h"
 #include <type_traits>
 
@@ -347,12 +349,11 @@ static int launch_conv(const ConvParams& p, hipStream_t s) {
     return ITTS_ERR_INVALID;
   }
   dim3 grid((unsigned)total);
-  static bool attr = false;
-  if (!attr && ldsb > 64 * 1024) {
+  static std::once_flag attr;   // one-shot per instantiation, safe under concurrent first calls (RequestPool threads)
+  std::call_once(attr, [] {
     (void)hipFuncSetAttribute((const void*)gemm_conv_kernel<T, WM, WN, TM, TN, CK, HALO>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        160 * 1024);
-    attr = true;
-  }
+                              160 * 1024);
+  });
   hipLaunchKernelGGL((gemm_conv_kernel<T, WM, WN, TM, TN, CK, HALO>), grid, dim3(WM * WN * 64), ldsb, s, q);
   return check_launch("itts_gemm_conv");
 }
@@ -502,11 +503,10 @@ static int launch_plain(const ConvParams& p, hipStream_t s) {
     set_error("itts_gemm_conv: too many tiles (%lld)", (long long)total);
     return ITTS_ERR_INVALID;
   }
-  static bool attr = false;
-  if (!attr) {
+  static std::once_flag attr;
+  std::call_once(attr, [] {
     (void)hipFuncSetAttribute((const void*)gemm_plain_kernel<T, WM, WN, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
+  });
   hipLaunchKernelGGL((gemm_plain_kernel<T, WM, WN, TM, TN>), dim3((unsigned)total), dim3(WM * WN * 64), ldsb, s, q);
   return check_launch("itts_gemm_conv");
 }
@@ -597,11 +597,10 @@ static int launch_narrow(const ConvParams& p, hipStream_t s) {
   per_cu = per_cu < 1 ? 1 : (per_cu > 6 ? 6 : per_cu);
   int64_t grid = 256 * (int64_t)per_cu;
   if (grid > tiles) grid = tiles;
-  static bool attr = false;
-  if (!attr) {
+  static std::once_flag attr;
+  std::call_once(attr, [] {
     (void)hipFuncSetAttribute((const void*)conv_narrow_kernel<T, KT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
+  });
   hipLaunchKernelGGL((conv_narrow_kernel<T, KT, NT>), dim3((unsigned)grid), dim3(256), ldsb, s, q);
   return check_launch("itts_gemm_conv");
 }
@@ -621,7 +620,11 @@ static int dispatch_narrow(const ConvParams& p, hipStream_t s, bool& handled) {
   return ITTS_OK;
 }
 
-int g_conv_cfg = 0;  // itts_debug_set(3, id): plain-GEMM kernel override for A/B measurements (0 = default)
+#if ITTS_DIAG
+int g_conv_cfg = 0;  // diagnostic build: itts_debug_set(3, id) kernel override for A/B measurements (0 = default)
+#else
+constexpr int g_conv_cfg = 0;  // product build: the heuristic below, no mutable state (the override branches fold away)
+#endif
 
 template <typename T>
 static int dispatch_conv(const ConvParams& p, hipStream_t s) {

@@ -1,19 +1,34 @@
-// Skinny (decode-step) GEMM: Y[M<=32][N] = epi( X[M][K] @ W[K][N] + bias ).
+// Skinny (decode-step) GEMM: Y[M<=96][N] = epi( X[M][K] @ W[K][N] + bias ).
 //
 // HBM-bound weight streaming, latency-first structure: every global load a wave needs (its 1-KiB packed weight blocks,
-// straight into MFMA B-fragment registers, and its A fragments of the T-typed activations) is issued BEFORE the first
-// use, so a launch costs one memory round trip plus the stream time.  A workgroup owns one 16-column tile and one slice
-// of K (grid.y = split-K factor); its waves split that slice and their fp32 partial tiles are summed through LDS in a
-// FIXED order.  With split-K > 1 each slice stores its partial tile into its own fp32 slab [ks][M][N]; the slabs are
-// summed, again in a fixed order, by the consumer (itts_ln_reduce), so the result is deterministic and needs no atomics
-// and no extra launch.  Replaces the per-step Conv1D/Linear calls of HF GPT2Block as driven by
+// straight into MFMA operand registers, and its fragments of the T-typed activations) is issued BEFORE the first use, so
+// a launch costs one memory round trip plus the stream time.  A workgroup owns 1-3 16-column tiles and one slice of K
+// (grid.y = split-K factor); its waves split that slice and their fp32 partial tiles are summed through LDS in a FIXED
+// order.  The MFMAs run with the WEIGHT fragment as the A operand: the accumulator tile comes out transposed, a lane
+// holds FOUR CONSECUTIVE OUTPUT COLUMNS of one batch row, and every epilogue access is 8 or 16 bytes wide.
+// Up to 96 rows (6 row tiles) share one pass over the weights: batch 32 x 3 beams (the infer() default) or several pooled
+// requests read the 966 MB of decoder weights ONCE per token.
+//
+// With split-K > 1 each slice stores its partial tile into its own fp32 slab [ks][M][N].  The slabs are then summed, in a
+// fixed order, either by the next launch (itts_ln_reduce), or -- "reducer tail", tail_h != NULL -- inside this launch: a
+// workgroup that has stored its slab takes an arrival ticket; the LAST M arrivals wait until all tickets are drawn and
+// then each turns one row into  h[row] += bias + slabs,  y[row] = LayerNorm(h[row])  with the arithmetic of
+// itts_ln_reduce (csrc/ln_math.h), so the consumer GEMM finds its normalised input ready at the kernel boundary and a
+// transformer block needs 5 launches instead of 7.  Hand-off rules (CDNA inter-workgroup visibility): slab tiles are
+// stored write-through (sc1), every storing wave drains (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, ONE lane
+// draws the ticket with an agent-scope atomic; a reducer's lane 0 polls the counter with sc1 loads, the workgroup meets
+// at a barrier, and every slab byte is read with an sc1 load (never served from this CU's L1).  Only M workgroups ever
+// wait and the others exit at once, so the wait cannot starve a workgroup that has not been dispatched yet.
+// Replaces the per-step Conv1D/Linear (+ residual + LayerNorm) calls of HF GPT2Block as driven by
 // indextts/gpt/model.py:163-193.
 #include "common.h"
+#include "ln_math.h"
 
-// Build-time A/B switch: non-temporal policy for the once-read weight blocks.  Measured neutral in the token loop
-// (1100.8 vs 1102 us per token; FC / FC2 -0.2..0.3 us, QKV / out-projection +0.2 us per launch), default policy kept.
 #ifndef ITTS_NT_WEIGHTS
-#define ITTS_NT_WEIGHTS 0
+#define ITTS_NT_WEIGHTS 0   // build-time A/B: non-temporal policy for the once-read weight blocks (measured neutral)
+#endif
+#ifndef ITTS_STAMPS
+#define ITTS_STAMPS 0       // diagnostic build only (make stamps): s_memtime stamps per workgroup, see tools/timeline_skinny.py
 #endif
 
 namespace itts {
@@ -38,116 +53,127 @@ struct SkinnyParams {
   int heads, smax;
   int ksplit;
   int slab_rows;
-  float* ln_h;            // fused LayerNorm producer stage (see itts_skinny_args)
-  const float* ln_slab;
-  int ln_nslab;
-  const float* ln_bias;
-  const float* ln_w;
-  const float* ln_b;
-  int32_t* ln_counter;
-  int32_t* ln_counter_prev;
-  int lnf;  // A operand is the fp32 residual stream, normalised per row (LayerNorm without affine) on the fly  // total rows of a slab (the caller's M), the stride between split-K slabs
+  // reducer tail
+  float* t_h;
+  const float* t_bias;
+  const float* t_w;
+  const float* t_b;
+  const float* t_w2;
+  const float* t_b2;
+  void* t_y;
+  uint32_t* t_counter;
+  const int32_t* t_epoch;
+  int32_t* t_err;
+  int t_acquire;
+#if ITTS_STAMPS
+  unsigned long long* stamps;
+#endif
 };
 
-// NTB = column tiles per workgroup.  More than one workgroup per CU does not overlap for this kernel (measured: 257
-// column tiles cost a full second round), so shapes with more than 256 tiles give each workgroup several tiles instead.
-// LNF: the A operand is fp32 [M][K] and is LayerNorm-normalised on the fly ((x - mean) * rstd, eps 1e-5; the affine part
-// is folded into the packed weights / bias by the caller).  Each wave computes exact two-pass statistics of its own K
-// slice, the slices are merged across the waves with Chan's parallel-variance formula through LDS (one barrier), and the
-// normalised values are rounded to T only then -- same numerics as LayerNorm in fp32 followed by a T-typed matmul.
-// Requires ksplit == 1 and the wave's whole K slice in one register chunk.
-// MAXT = threads per workgroup the register budget is sized for (512: up to 8 waves; 1024: up to 16 waves, which halves
-// the loads queued per lane at the price of a 128-register cap).
-// Producer stage of a fused launch: one row of x = LayerNorm(h + bias + slabs) per workgroup, numerics and association
-// order of ln_reduce_wide_kernel.  The row is published for the GEMM workgroups of the SAME launch with write-through
-// (sc1) stores, a drain of every storing wave, a workgroup barrier and one agent-scope counter add (the R1 recipe of the
-// CDNA hand-off rules); the residual stream itself is only read by later launches and is stored normally.
+#if ITTS_STAMPS
+unsigned long long* g_stamp_buf = nullptr;
+#define ITTS_STAMP(i)                                                                                  \
+  do {                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    if (p.stamps != nullptr && threadIdx.x == 0) {                                                     \
+      unsigned long long t_;                                                                           \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                        \
+      st_[i] = t_;                                                                                     \
+    }                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+  } while (0)
+#define ITTS_STAMP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define ITTS_STAMP(i) do { } while (0)
+#define ITTS_STAMP_DRAIN() do { } while (0)
+#endif
+
+constexpr int TAIL_SPIN_LIMIT = 1 << 22;  // ~seconds; a reducer that gives up sets *t_err (the host raises at its next sync)
+
+// 4 consecutive elements of a row; `nval` of them exist (N need not be a multiple of 4: the 8194-column head)
 template <typename T>
-__device__ __forceinline__ void fused_ln_row(const SkinnyParams& p, float* red) {
-  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  const int D = p.K;
-  const bool act = tid * 4 < D;
-  const int o = act ? tid * 4 : 0;
-  float* hr = p.ln_h + (int64_t)row * D;
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  f32x4 v = ld16<f32x4>(hr + o);
-  const f32x4 lw = ld16<f32x4>(p.ln_w + o), lb = ld16<f32x4>(p.ln_b + o);
-  {
-    // all loads unconditional (absent operands alias the row itself and are discarded): one round trip, no branches
-    const float* bsrc = p.ln_bias != nullptr ? p.ln_bias + o : hr + o;
-    f32x4 bs = ld16<f32x4>(bsrc);
-    f32x4 sl[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const float* ssrc = i < p.ln_nslab ? p.ln_slab + ((int64_t)i * p.slab_rows + row) * D + o : hr + o;
-      sl[i] = ld16<f32x4>(ssrc);
-    }
-    if (p.ln_nslab > 0) {
-      v += (p.ln_bias != nullptr) ? bs : zero;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) v += (i < p.ln_nslab) ? sl[i] : zero;
-      if (act) st16(hr + o, v);
-    }
-  }
-  if (!act) v = zero;
-  float s = wave_sum(v[0] + v[1] + v[2] + v[3]);
-  if (lane == 0) red[wave] = s;
-  __syncthreads();
-  float tot = 0.f;
-  for (int i = 0; i < nw; ++i) tot += red[i];
-  const float mean = tot / (float)D;
-  float q = 0.f;
-  if (act) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float d = v[e] - mean;
-      q = fmaf(d, d, q);
-    }
-  }
-  q = wave_sum(q);
-  if (lane == 0) red[32 + wave] = q;
-  __syncthreads();
-  float qt = 0.f;
-  for (int i = 0; i < nw; ++i) qt += red[32 + i];
-  const float rstd = rsqrtf(qt / (float)D + 1e-5f);
-  if (act) {
-    T* yr = (T*)const_cast<void*>(p.x) + (int64_t)row * D + o;
-    float r[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = (v[e] - mean) * rstd * lw[e] + lb[e];
+__device__ __forceinline__ void store4(T* dst, const f32x4& v, int nval) {
+  if (nval >= 4 && ((reinterpret_cast<uintptr_t>(dst) & (sizeof(T) * 4 - 1)) == 0)) {
     if constexpr (sizeof(T) == 4) {
-      uint64_t lo = ((uint64_t)__float_as_uint(r[1]) << 32) | __float_as_uint(r[0]);
-      uint64_t hi = ((uint64_t)__float_as_uint(r[3]) << 32) | __float_as_uint(r[2]);
-      __hip_atomic_store((uint64_t*)yr, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store((uint64_t*)yr + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      st16(dst, v);
     } else {
       typedef T t4 __attribute__((ext_vector_type(4)));
-      t4 ov = {Elem<T>::from_f(r[0]), Elem<T>::from_f(r[1]), Elem<T>::from_f(r[2]), Elem<T>::from_f(r[3])};
-      __hip_atomic_store((uint64_t*)yr, __builtin_bit_cast(uint64_t, ov), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f(v[e]);
+      *reinterpret_cast<t4*>(dst) = o;
     }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the workgroup signals
-  __syncthreads();
-  if (tid == 0) {
-    if (row == 0 && p.ln_counter_prev != nullptr) *p.ln_counter_prev = 0;  // that launch has completed (stream order)
-    __hip_atomic_fetch_add(p.ln_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (e < nval) dst[e] = Elem<T>::from_f(v[e]);
   }
 }
 
-template <typename T, int MT, int SPW, int NTB, bool LNF, int MAXT = 512, bool FUSE = false>
-__global__ __launch_bounds__(MAXT) void gemm_skinny_kernel(SkinnyParams p) {
+__device__ __forceinline__ f32x4 load4f(const float* src, int nval) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (nval >= 4 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) return ld16<f32x4>(src);
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (e < nval) v[e] = src[e];
+  return v;
+}
+
+// Reducer tail: row `row` of  h += bias + slabs ; y = LN(h)  (then LN2 when t_w2 != NULL) -- itts_ln_reduce's arithmetic.
+template <typename T>
+__device__ __forceinline__ void tail_reduce_row(const SkinnyParams& p, float* lds, int row) {
+  const int tid = threadIdx.x, nw = blockDim.x >> 6;
+  const int D = p.N;
+  const bool act = tid * 4 < D;
+  const int o = act ? tid * 4 : 0;
+  float* hr = p.t_h + (int64_t)row * D;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  // every load is issued before the first use: one round trip
+  f32x4 v = ld16<f32x4>(hr + o);
+  const f32x4 lw = ld16<f32x4>(p.t_w + o), lb = ld16<f32x4>(p.t_b + o);
+  const bool two = p.t_w2 != nullptr;
+  const f32x4 lw2 = ld16<f32x4>((two ? p.t_w2 : p.t_w) + o), lb2 = ld16<f32x4>((two ? p.t_b2 : p.t_b) + o);
+  const f32x4 bs = ld16<f32x4>((p.t_bias != nullptr ? p.t_bias : p.t_w) + o);
+  f32x4 sl[4];
+  {
+    // sc1 loads: the slab bytes were stored write-through by other CUs during THIS launch; they must not come from L1
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        p.yf, 0, (int)((int64_t)p.ksplit * p.slab_rows * D * 4), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned off = (i < p.ksplit && act) ? (unsigned)((((int64_t)i * p.slab_rows + row) * D + o) * 4) : 0xFFFFFFF0u;
+      sl[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
+    }
+  }
+  if (p.t_bias != nullptr) v += bs;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < p.ksplit) v += sl[i];   // same association order as itts_ln_reduce
+  if (act) st16(hr + o, v);
+  else v = zero;
+  if (two) wide_layernorm<true>(v, lw, lb, lw2, lb2, lds, tid, nw, D, act);
+  else wide_layernorm<false>(v, lw, lb, lw2, lb2, lds, tid, nw, D, act);
+  if (act) store_row4<T>((T*)p.t_y + (int64_t)row * D + o, v);
+}
+
+// NTB = column tiles per workgroup (grids stay within one round of the 256 CUs: a 257th workgroup costs a full second
+// round for this kernel), SPW = k-steps a wave keeps in registers per pass, MT = 16-row tiles (M <= 16*MT).
+template <typename T, int MT, int SPW, int NTB, bool TAIL>
+__global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
   typedef Elem<T> EL;
   typedef typename EL::frag frag;
   constexpr int E = EL::E, KS = EL::KS;
   extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][NTB][MT][64][4]
+#if ITTS_STAMPS
+  unsigned long long st_[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) st_[i] = 0;
+  unsigned long long rt0_ = 0;
+  if (p.stamps != nullptr && threadIdx.x == 0) rt0_ = __builtin_amdgcn_s_memrealtime();
+#endif
+  ITTS_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
-  if constexpr (FUSE) {
-    if ((int)blockIdx.x < p.M) {
-      fused_ln_row<T>(p, red);
-      return;
-    }
-  }
-  const int nt0 = (FUSE ? (int)blockIdx.x - p.M : (int)blockIdx.x) * NTB, ks = blockIdx.y;
+  const int nt0 = (int)blockIdx.x * NTB, ks = blockIdx.y;
   const int NTtot = (p.N + 15) / 16;
   const int g = lane >> 4, r = lane & 15;
   const int KT = p.K / KS;
@@ -160,14 +186,16 @@ __global__ __launch_bounds__(MAXT) void gemm_skinny_kernel(SkinnyParams p) {
   const char* bp = (const char*)p.wp + ((int64_t)nt0 * KT * 64 + lane) * 16;  // tile t of this workgroup: + t*KT*1024
   const T* X = (const T*)p.x;
 
-  // epilogue operands are requested now, so that their latency overlaps the weight stream
-  float bias_pre = 0.f;
+  // epilogue operands of the first output unit of this wave are requested now: their latency overlaps the weight stream
+  f32x4 bias_pre = {0.f, 0.f, 0.f, 0.f};
   int pos_pre = 0;
-  if (tid < NTB * MT * 256) {  // the element this thread handles first in the epilogue (e == tid)
-    int col = (nt0 + tid / (MT * 256)) * 16 + (tid & 15);
-    if (p.bias != nullptr && ks == 0 && col < p.N) bias_pre = p.bias[col];
+  unsigned epoch_pre = 0;
+  if (wave < NTB * MT) {
+    const int col0 = (nt0 + wave / MT) * 16 + g * 4;
+    if (p.bias != nullptr && ks == 0 && col0 < p.N) bias_pre = load4f(p.bias + col0, p.N - col0);
     if (p.epi == ITTS_EPI_QKV_CACHE) pos_pre = p.pos[0];
   }
+  if constexpr (TAIL) epoch_pre = (unsigned)p.t_epoch[0];
 
   f32x4 acc[NTB][MT];
 #pragma unroll
@@ -175,98 +203,8 @@ __global__ __launch_bounds__(MAXT) void gemm_skinny_kernel(SkinnyParams p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if constexpr (LNF) {
-    const float* H = (const float*)p.x;
-    float* stat = red + NW * NTB * MT * 256;  // [NW][MT*16][2] (mean, M2) of each wave's K slice
-    frag bf[NTB][SPW];
-    float xa[SPW][MT][E];
-#pragma unroll
-    for (int t = 0; t < NTB; ++t)
-#pragma unroll
-      for (int i = 0; i < SPW; ++i) {
-        int s = s_begin + i;
-        bf[t][i] = (s < s_end && nt0 + t < NTtot) ? ldw<frag>(bp + ((int64_t)t * KT + s) * 1024) : zero_frag<frag>();
-      }
-#pragma unroll
-    for (int i = 0; i < SPW; ++i) {
-      int s = s_begin + i;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        int row = mt * 16 + r;
-        bool ok = (s < s_end) && (row < p.M);
-        const float* src = H + (int64_t)row * p.K + s * KS + g * E;
-#pragma unroll
-        for (int e4 = 0; e4 < E / 4; ++e4) {
-          f32x4 v = ok ? ld16<f32x4>(src + e4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) xa[i][mt][e4 * 4 + e] = v[e];
-        }
-      }
-    }
-    const float n_w = (float)((s_end - s_begin) * KS);  // elements of a row in this wave's slice
-    float mean_w[MT], m2_w[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      float s1 = 0.f;
-#pragma unroll
-      for (int i = 0; i < SPW; ++i)
-#pragma unroll
-        for (int e = 0; e < E; ++e) s1 += xa[i][mt][e];  // slots past s_end hold zeros
-      s1 += __shfl_xor(s1, 16, 64);
-      s1 += __shfl_xor(s1, 32, 64);
-      mean_w[mt] = n_w > 0.f ? s1 / n_w : 0.f;
-      float s2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < SPW; ++i)
-        if (s_begin + i < s_end) {
-#pragma unroll
-          for (int e = 0; e < E; ++e) {
-            float d = xa[i][mt][e] - mean_w[mt];
-            s2 = fmaf(d, d, s2);
-          }
-        }
-      s2 += __shfl_xor(s2, 16, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      m2_w[mt] = s2;
-      if (g == 0) {
-        stat[(wave * (MT * 16) + mt * 16 + r) * 2 + 0] = mean_w[mt];
-        stat[(wave * (MT * 16) + mt * 16 + r) * 2 + 1] = s2;
-      }
-    }
-    __syncthreads();
-    // merge the NW slices (all slices but possibly the last have spw*KS elements)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      float tot = 0.f, msum = 0.f;
-      for (int w = 0; w < NW; ++w) {
-        int sb = b_begin + w * spw, se = min(b_end, sb + spw);
-        float nw = (float)(max(se - sb, 0) * KS);
-        msum += nw * stat[(w * (MT * 16) + mt * 16 + r) * 2];
-        tot += nw;
-      }
-      float mean = msum / tot, m2 = 0.f;
-      for (int w = 0; w < NW; ++w) {
-        int sb = b_begin + w * spw, se = min(b_end, sb + spw);
-        float nw = (float)(max(se - sb, 0) * KS);
-        float d = stat[(w * (MT * 16) + mt * 16 + r) * 2] - mean;
-        m2 += stat[(w * (MT * 16) + mt * 16 + r) * 2 + 1] + nw * d * d;
-      }
-      float rstd = rsqrtf(m2 / tot + 1e-5f);
-#pragma unroll
-      for (int i = 0; i < SPW; ++i) {
-        frag af;
-#pragma unroll
-        for (int e = 0; e < E; ++e) af[e] = EL::from_f((xa[i][mt][e] - mean) * rstd);
-        if (s_begin + i < s_end) {
-#pragma unroll
-          for (int t = 0; t < NTB; ++t) acc[t][mt] = EL::mma(af, bf[t][i], acc[t][mt]);
-        }
-      }
-    }
-  } else {
   for (int base = s_begin; base < s_end; base += SPW) {
     frag bf[NTB][SPW];
-    frag af[SPW][MT];
 #pragma unroll
     for (int t = 0; t < NTB; ++t)
 #pragma unroll
@@ -274,139 +212,239 @@ __global__ __launch_bounds__(MAXT) void gemm_skinny_kernel(SkinnyParams p) {
         int s = base + i;
         bf[t][i] = (s < s_end && nt0 + t < NTtot) ? ldw<frag>(bp + ((int64_t)t * KT + s) * 1024) : zero_frag<frag>();
       }
-    if constexpr (FUSE) {
-      // the weight blocks are in flight; now wait for the producer workgroups' rows: ONE lane polls the counter (relaxed),
-      // ONE agent-scope acquire drops this CU's stale lines, the barrier releases the other waves to plain loads
-      if (tid == 0) {
-        int spins = 0;
-        while (__hip_atomic_load(p.ln_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.M) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1 << 22)) break;  // never expected: the producers are the first workgroups of this launch
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __syncthreads();
-    }
+    if constexpr (MT <= 2) {
+      frag af[SPW][MT];
 #pragma unroll
-    for (int i = 0; i < SPW; ++i) {
-      int s = base + i;
+      for (int i = 0; i < SPW; ++i) {
+        int s = base + i;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          int row = mt * 16 + r;
+          af[i][mt] = (s < s_end && row < p.M) ? ld16<frag>(X + (int64_t)row * p.K + s * KS + g * E) : zero_frag<frag>();
+        }
+      }
+      ITTS_STAMP(1);
+#if ITTS_STAMPS
+      ITTS_STAMP_DRAIN();
+      ITTS_STAMP(2);
+#endif
+#pragma unroll
+      for (int i = 0; i < SPW; ++i) {
+#pragma unroll
+        for (int t = 0; t < NTB; ++t)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[t][mt] = EL::mma(bf[t][i], af[i][mt], acc[t][mt]);  // weights = A operand
+      }
+    } else {
+      // more than 32 rows: the activation fragments (L2-resident, shared by every workgroup) are fetched row tile by row
+      // tile behind the weight blocks; the unrolled loop lets the loads of tile mt+1 fly under the MFMAs of tile mt
+      ITTS_STAMP(1);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        int row = mt * 16 + r;
-        af[i][mt] = (s < s_end && row < p.M) ? ld16<frag>(X + (int64_t)row * p.K + s * KS + g * E) : zero_frag<frag>();
+        frag af[SPW];
+        const int row = mt * 16 + r;
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) {
+          int s = base + i;
+          af[i] = (s < s_end && row < p.M) ? ld16<frag>(X + (int64_t)row * p.K + s * KS + g * E) : zero_frag<frag>();
+        }
+#pragma unroll
+        for (int i = 0; i < SPW; ++i)
+#pragma unroll
+          for (int t = 0; t < NTB; ++t) acc[t][mt] = EL::mma(bf[t][i], af[i], acc[t][mt]);
       }
-    }
-#pragma unroll
-    for (int i = 0; i < SPW; ++i) {
-#pragma unroll
-      for (int t = 0; t < NTB; ++t)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[t][mt] = EL::mma(af[i][mt], bf[t][i], acc[t][mt]);
+      ITTS_STAMP(2);
     }
   }
-  }
+  ITTS_STAMP(3);
 
-  // ---- cross-wave reduction, fixed order
+  // ---- cross-wave reduction, fixed order.  Lane (g, r) of a tile holds Y[row = mt*16 + r][col = tile*16 + 4g .. 4g+3].
 #pragma unroll
   for (int t = 0; t < NTB; ++t)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) st16(red + (((wave * NTB + t) * MT + mt) * 64 + lane) * 4, acc[t][mt]);
   __syncthreads();
-  for (int e = tid; e < NTB * MT * 256; e += blockDim.x) {
-    int t = e / (MT * 256), e1 = e - t * (MT * 256);
-    int mt = e1 >> 8, rr = (e1 >> 4) & 15, c = e1 & 15;
-    int row = mt * 16 + rr, col = (nt0 + t) * 16 + c;
-    if (row >= p.M || col >= p.N) continue;
-    float bs = (e == tid) ? bias_pre : ((p.bias != nullptr && ks == 0) ? p.bias[col] : 0.f);
-    int src = ((rr >> 2) << 4) | c, j = rr & 3;
-    float v = 0.f;
-    for (int w = 0; w < NW; ++w) v += red[(((w * NTB + t) * MT + mt) * 64 + src) * 4 + j];
+  ITTS_STAMP(4);
+  const __amdgpu_buffer_rsrc_t rslab = __builtin_amdgcn_make_buffer_rsrc(
+      p.yf, 0, TAIL ? (int)((int64_t)p.ksplit * p.slab_rows * p.N * 4) : 0, 0x00020000);
+  for (int u = wave; u < NTB * MT; u += NW) {
+    const int t = u / MT, mt = u - t * MT;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int w = 0; w < NW; ++w) v += ld16<f32x4>(red + (((w * NTB + t) * MT + mt) * 64 + lane) * 4);
+    const int row = mt * 16 + r, col0 = (nt0 + t) * 16 + g * 4;
+    if (row >= p.M || col0 >= p.N) continue;
+    const int nval = min(4, p.N - col0);
+    f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+    if (u == wave) bs = bias_pre;
+    else if (p.bias != nullptr && ks == 0) bs = load4f(p.bias + col0, nval);
     v += bs;
     switch (p.epi) {
       case ITTS_EPI_STORE:
-        ((T*)p.y)[(int64_t)row * p.N + col] = EL::from_f(v);
+        store4<T>((T*)p.y + (int64_t)row * p.N + col0, v, nval);
         break;
-      case ITTS_EPI_GELU_STORE:
-        ((T*)p.y)[(int64_t)row * p.N + col] = EL::from_f(gelu_new(v));
-        break;
-      case ITTS_EPI_RESID_F32:
-        p.yf[(int64_t)row * p.N + col] += v;
-        break;
+      case ITTS_EPI_GELU_STORE: {
+        f32x4 gv = {gelu_new(v[0]), gelu_new(v[1]), gelu_new(v[2]), gelu_new(v[3])};
+        store4<T>((T*)p.y + (int64_t)row * p.N + col0, gv, nval);
+      } break;
+      case ITTS_EPI_RESID_F32: {
+        float* dst = p.yf + (int64_t)row * p.N + col0;
+        f32x4 old = load4f(dst, nval);
+        store4<float>(dst, old + v, nval);
+      } break;
       case ITTS_EPI_STORE_F32:
-        p.yf[(int64_t)row * p.N + col] = v;
+        store4<float>(p.yf + (int64_t)row * p.N + col0, v, nval);
         break;
-      case ITTS_EPI_SLAB_F32:
-        p.yf[((int64_t)ks * p.slab_rows + row) * p.N + col] = v;
-        break;
-      case ITTS_EPI_QKV_CACHE: {
-        int D = p.N / 3;
-        if (col < D) {
-          ((T*)p.y)[(int64_t)row * D + col] = EL::from_f(v);
+      case ITTS_EPI_SLAB_F32: {
+        const int64_t eoff = ((int64_t)ks * p.slab_rows + row) * p.N + col0;
+        if constexpr (TAIL) {
+          // write-through store (aux 16 = sc1) through a wave-uniform descriptor: the tile leaves this XCD's L2 at once,
+          // so no release fence is needed before the ticket (N % 4 == 0 is checked by the launcher)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rslab, (unsigned)(eoff * 4), 0, 16);
         } else {
-          int cc = col - D;
+          store4<float>(p.yf + eoff, v, nval);
+        }
+      } break;
+      case ITTS_EPI_QKV_CACHE: {
+        const int D = p.N / 3;   // a 4-column group never straddles q|k|v or a head (all multiples of 64)
+        if (col0 < D) {
+          store4<T>((T*)p.y + (int64_t)row * D + col0, v, nval);
+        } else {
+          int cc = col0 - D;
           T* cache = (T*)(cc < D ? p.kcache : p.vcache);
           if (cc >= D) cc -= D;
-          int hh = cc >> 6, dd = cc & 63;
-          int pos = (e == tid) ? pos_pre : p.pos[0];
-          cache[(((int64_t)row * p.heads + hh) * p.smax + pos) * 64 + dd] = EL::from_f(v);
+          const int hh = cc >> 6, dd = cc & 63;
+          const int pos = (u == wave) ? pos_pre : p.pos[0];
+          store4<T>(cache + (((int64_t)row * p.heads + hh) * p.smax + pos) * 64 + dd, v, nval);
         }
       } break;
     }
   }
+  ITTS_STAMP(5);
+
+  if constexpr (TAIL) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its write-through stores ...
+    __syncthreads();                                   // ... before the one lane that signals for all of them
+    ITTS_STAMP(6);
+    unsigned* slot = reinterpret_cast<unsigned*>(red);
+    const unsigned total = gridDim.x * gridDim.y;
+    const unsigned base_cnt = (epoch_pre - 1u) * total;   // tickets of this launch are base_cnt .. base_cnt + total - 1
+    if (tid == 0) slot[0] = __hip_atomic_fetch_add(p.t_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned rel = slot[0] - base_cnt;
+    ITTS_STAMP(7);
+    if (rel + (unsigned)p.M >= total && rel < total) {    // one of the last M arrivals: reducer of row rel - (total - M)
+      const int row = (int)(rel - (total - (unsigned)p.M));
+      __syncthreads();                                    // slot[0] has been read by everyone; LDS is reused below
+      if (tid == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(p.t_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base_cnt < total) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > TAIL_SPIN_LIMIT) {
+            atomicExch(p.t_err, 1);   // sticky: the host checks it at its next synchronisation and raises
+            break;
+          }
+        }
+        if (p.t_acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      ITTS_STAMP(8);
+      tail_reduce_row<T>(p, red, row);
+      ITTS_STAMP(9);
+    } else if (rel >= total && tid == 0) {
+      atomicExch(p.t_err, 2);   // counter / epoch out of step (a launch of this site was lost): results are invalid
+    }
+  }
+#if ITTS_STAMPS
+  if (p.stamps != nullptr && threadIdx.x == 0) {
+    ITTS_STAMP_DRAIN();
+    unsigned long long te_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te_)::"memory");
+    unsigned xcc_;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+    unsigned long long* o_ = p.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) o_[i] = st_[i];
+    o_[10] = te_;
+    o_[11] = rt0_;
+    o_[12] = __builtin_amdgcn_s_memrealtime();
+    o_[13] = xcc_ & 0xF;
+  }
+#endif
 }
 
-int g_tune_ntb = 0, g_tune_nw = 0;  // itts_debug_set(1|2, v): tuning overrides (0 = heuristic)
+// Launch geometry of one skinny GEMM (shared by the launcher and by tools through itts_skinny_plan)
+struct SkinnyPlan {
+  int NW, spw, ntb, gx, gy, SPWc;
+  size_t lds;
+};
+
+#if ITTS_DIAG
+int g_tune_ntb = 0, g_tune_nw = 0;  // diagnostic build: itts_debug_set(1|2, v) overrides (0 = heuristic)
+#endif
+
+template <typename T>
+static SkinnyPlan plan_skinny(int N, int K, int ksplit, int MT) {
+  constexpr int KS = Elem<T>::KS;
+  SkinnyPlan q;
+  const int KT = K / KS;
+  const int SB = (KT + ksplit - 1) / ksplit;
+  // waves per workgroup: 8 whenever the slice has 8 k-steps (measured: the split-K 3 out-projection, 14 k-steps, takes
+  // 3.8 us with 8 waves x 2 steps against 4.4 us with 3 waves x 5; more than 8 waves change nothing)
+  int NW = SB > 8 ? 8 : SB;
+  if (NW < 1) NW = 1;
+#if ITTS_DIAG
+  if (g_tune_nw > 0) NW = g_tune_nw > 8 ? 8 : g_tune_nw;
+#endif
+  const int spw = (SB + NW - 1) / NW;
+  const int NT = (N + 15) / 16;
+  int ntb = (NT * ksplit + 255) / 256;   // keep the grid within one round of the 256 CUs
+#if ITTS_DIAG
+  if (g_tune_ntb > 0) ntb = g_tune_ntb;
+#endif
+  if (ntb > 3) ntb = 3;
+  const int SPWc = spw <= 5 ? 5 : 10;     // register-chunk variant
+  if (SPWc == 10 && ntb > 2) ntb = 2;     // register budget of the 10-step variant
+  if (MT > 2 && SPWc == 10) ntb = 1;      // 4-6 row tiles with 10-step chunks: accumulators + weight fragments
+  q.NW = NW;
+  q.spw = spw;
+  q.ntb = ntb;
+  q.SPWc = SPWc;
+  q.gx = (NT + ntb - 1) / ntb;
+  q.gy = ksplit;
+  q.lds = (size_t)NW * ntb * MT * 256 * 4;
+  if (q.lds < 1024) q.lds = 1024;
+  return q;
+}
 
 template <typename T, int MT>
 static int launch_skinny(const SkinnyParams& p, hipStream_t s) {
-  constexpr int KS = Elem<T>::KS;
-  const int KT = p.K / KS;
-  const int SB = (KT + p.ksplit - 1) / p.ksplit;
-  // waves per workgroup: 8 whenever the slice has 8 k-steps (measured: the split-K 3 out-projection, 14 k-steps, takes
-  // 3.8 us with 8 waves x 2 steps against 4.4 us with 3 waves x 5; 10-16 waves change nothing for any of the four GEMMs);
-  // more than 5 steps per wave -> 10-step register chunks
-  int NW = SB;
-  if (NW > 8) NW = 8;
-  if (NW < 1) NW = 1;
-  if (g_tune_nw > 0 && !p.lnf) NW = g_tune_nw > 16 ? 16 : g_tune_nw;
-  if (NW > 8 && (SB + NW - 1) / NW > 5) NW = 8;  // the 16-wave build only exists for 5-step register chunks
-  const int spw = (SB + NW - 1) / NW;
-  const int NT = (p.N + 15) / 16;
-  // keep the grid within one round of the 256 CUs
-  int ntb = (NT * p.ksplit + 255) / 256;
-  if (g_tune_ntb > 0) ntb = g_tune_ntb;
-  if (ntb > 3) ntb = 3;
-  if (spw > 5 && ntb > 2) ntb = 2;  // register budget of the 10-step variant
-  size_t lds = (size_t)NW * ntb * MT * 256 * 4 + (p.lnf ? (size_t)NW * MT * 16 * 2 * 4 : 0);
-  dim3 grid((NT + ntb - 1) / ntb, p.ksplit), block(NW * 64);
-  if (p.ln_h != nullptr) {
-    // fused producer stage: M extra workgroups in front; one pass of the k-loop only (all weight blocks in flight at once)
-    if (p.ksplit != 1 || p.lnf || spw > 5 || NW != 8 || p.K % 256 != 0 || p.K / 4 > NW * 64 || p.ln_nslab < 0 || p.ln_nslab > 3) {
-      set_error("itts_gemm_skinny: the fused LayerNorm stage needs ksplit 1, K %% 256 == 0, K <= %d, <= 3 slabs", 8 * 5 * KS);
+  const SkinnyPlan q = plan_skinny<T>(p.N, p.K, p.ksplit, MT);
+  dim3 grid(q.gx, q.gy), block(q.NW * 64);
+  const bool tail = p.t_h != nullptr;
+  if (tail) {
+    if (p.epi != ITTS_EPI_SLAB_F32 || q.NW * 64 * 4 < p.N || p.N % 4 != 0 || p.ksplit > 4 || (int)(grid.x * grid.y) < p.M ||
+        grid.x * grid.y > 256) {
+      set_error("itts_gemm_skinny: the reducer tail needs the slab epilogue, N %% 4 == 0, N <= %d, ksplit <= 4 and M <= workgroups <= 256 "
+                "(N=%d, workgroups=%d, M=%d)", q.NW * 256, p.N, (int)(grid.x * grid.y), p.M);
       return ITTS_ERR_INVALID;
     }
-    grid.x += p.M;
-#define ITTS_SKF(NTB_) hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 5, NTB_, false, 512, true>), grid, block, lds, s, p)
-    if (ntb == 1) ITTS_SKF(1); else if (ntb == 2) ITTS_SKF(2); else ITTS_SKF(3);
-#undef ITTS_SKF
-    return check_launch("itts_gemm_skinny");
   }
-#define ITTS_SK(SPW_, NTB_, LNF_) hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, SPW_, NTB_, LNF_>), grid, block, lds, s, p)
-  if (p.lnf) {
-    if (spw > 5 || p.ksplit != 1) {
-      set_error("itts_gemm_skinny: the LayerNorm-fused A operand needs K <= %d and ksplit == 1", 8 * 5 * KS);
-      return ITTS_ERR_INVALID;
-    }
-    if (ntb == 1) ITTS_SK(5, 1, true); else if (ntb == 2) ITTS_SK(5, 2, true); else ITTS_SK(5, 3, true);
-  } else if (spw <= 5 && NW > 8) {
-#define ITTS_SK16(NTB_) hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 5, NTB_, false, 1024>), grid, block, lds, s, p)
-    if (ntb == 1) ITTS_SK16(1); else if (ntb == 2) ITTS_SK16(2); else ITTS_SK16(3);
-#undef ITTS_SK16
-  } else if (spw <= 5) {
-    if (ntb == 1) ITTS_SK(5, 1, false); else if (ntb == 2) ITTS_SK(5, 2, false); else ITTS_SK(5, 3, false);
+#define ITTS_SK(SPW_, NTB_)                                                                                            \
+  do {                                                                                                                 \
+    if (tail) hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, SPW_, NTB_, true>), grid, block, q.lds, s, p);              \
+    else hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, SPW_, NTB_, false>), grid, block, q.lds, s, p);                  \
+  } while (0)
+  if (q.SPWc == 5) {
+    if (q.ntb == 1) ITTS_SK(5, 1);
+    else if (q.ntb == 2) ITTS_SK(5, 2);
+    else ITTS_SK(5, 3);
   } else {
-    if (ntb == 1) ITTS_SK(10, 1, false); else ITTS_SK(10, 2, false);
+    if (q.ntb == 1) ITTS_SK(10, 1);
+    else {
+      if constexpr (MT <= 2) ITTS_SK(10, 2);
+      else ITTS_SK(10, 1);
+    }
   }
 #undef ITTS_SK
   return check_launch("itts_gemm_skinny");
@@ -432,13 +470,13 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
     ITTS_REQUIRE(a->yf, "itts_gemm_skinny: yf is null");
   else
     ITTS_REQUIRE((a->epi == ITTS_EPI_STORE || a->epi == ITTS_EPI_GELU_STORE) && a->y, "itts_gemm_skinny: bad epilogue %d", a->epi);
-  if (a->ln_h != nullptr)
-    ITTS_REQUIRE(a->ln_w && a->ln_b && a->ln_counter && (a->ln_nslab == 0 || a->ln_slab) && !a->x_ln_f32 &&
-                     a->M <= (a->dtype == ITTS_F32 ? 16 : 32),
-                 "itts_gemm_skinny: bad fused-LayerNorm arguments (needs M <= 32 rows, 16 in fp32)");
+  const int rows_per = (a->dtype == ITTS_F32) ? 16 : 96;
+  if (a->tail_h != nullptr)
+    ITTS_REQUIRE(a->tail_w && a->tail_b && a->tail_y && a->tail_counter && a->tail_epoch && a->tail_err &&
+                     (a->tail_w2 == nullptr) == (a->tail_b2 == nullptr) && a->M <= rows_per,
+                 "itts_gemm_skinny: bad reducer-tail arguments (needs M <= %d rows in one launch)", rows_per);
   if (a->M == 0) return ITTS_OK;
   hipStream_t s = (hipStream_t)stream;
-  const int rows_per = (a->dtype == ITTS_F32) ? 16 : 32;
   for (int r0 = 0; r0 < a->M; r0 += rows_per) {
     SkinnyParams p;
     p.M = a->M - r0 < rows_per ? a->M - r0 : rows_per;
@@ -446,8 +484,7 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
     p.K = a->K;
     p.wp = a->wp;
     p.bias = a->bias;
-    p.x = (const char*)a->x + (size_t)r0 * a->K * (a->x_ln_f32 ? 4 : esz);
-    p.lnf = a->x_ln_f32 ? 1 : 0;
+    p.x = (const char*)a->x + (size_t)r0 * a->K * esz;
     p.epi = a->epi;
     const size_t ycols = a->epi == ITTS_EPI_QKV_CACHE ? (size_t)a->N / 3 : (size_t)a->N;
     p.y = a->y ? (char*)a->y + (size_t)r0 * ycols * esz : nullptr;
@@ -460,21 +497,29 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
     p.smax = a->smax;
     p.ksplit = ksplit;
     p.slab_rows = a->M;
-    p.ln_h = a->ln_h;
-    p.ln_slab = a->ln_slab;
-    p.ln_nslab = a->ln_nslab;
-    p.ln_bias = a->ln_bias;
-    p.ln_w = a->ln_w;
-    p.ln_b = a->ln_b;
-    p.ln_counter = a->ln_counter;
-    p.ln_counter_prev = a->ln_counter_prev;
+    p.t_h = a->tail_h;
+    p.t_bias = a->tail_bias;
+    p.t_w = a->tail_w;
+    p.t_b = a->tail_b;
+    p.t_w2 = a->tail_w2;
+    p.t_b2 = a->tail_b2;
+    p.t_y = a->tail_y;
+    p.t_counter = (uint32_t*)a->tail_counter;
+    p.t_epoch = a->tail_epoch;
+    p.t_err = a->tail_err;
+    p.t_acquire = a->tail_acquire;
+#if ITTS_STAMPS
+    p.stamps = g_stamp_buf;
+#endif
     int rc;
     if (a->dtype == ITTS_F32) {
       rc = launch_skinny<float, 1>(p, s);
     } else if (a->dtype == ITTS_BF16) {
-      rc = p.M <= 16 ? launch_skinny<bf16_t, 1>(p, s) : launch_skinny<bf16_t, 2>(p, s);
+      rc = p.M <= 16 ? launch_skinny<bf16_t, 1>(p, s) : p.M <= 32 ? launch_skinny<bf16_t, 2>(p, s)
+           : p.M <= 64 ? launch_skinny<bf16_t, 4>(p, s) : launch_skinny<bf16_t, 6>(p, s);
     } else if (a->dtype == ITTS_F16) {
-      rc = p.M <= 16 ? launch_skinny<f16_t, 1>(p, s) : launch_skinny<f16_t, 2>(p, s);
+      rc = p.M <= 16 ? launch_skinny<f16_t, 1>(p, s) : p.M <= 32 ? launch_skinny<f16_t, 2>(p, s)
+           : p.M <= 64 ? launch_skinny<f16_t, 4>(p, s) : launch_skinny<f16_t, 6>(p, s);
     } else {
       ITTS_REQUIRE(false, "itts_gemm_skinny: unknown dtype %d", a->dtype);
     }
@@ -483,6 +528,16 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
   return ITTS_OK;
 }
 
+extern "C" int itts_skinny_plan(int dtype, int M, int N, int K, int ksplit, int* out6) {
+  ITTS_REQUIRE(out6 && N > 0 && K > 0 && ksplit > 0 && M > 0, "itts_skinny_plan: bad arguments");
+  const int MT = M <= 16 ? 1 : M <= 32 ? 2 : M <= 64 ? 4 : 6;
+  const SkinnyPlan q = dtype == ITTS_F32 ? plan_skinny<float>(N, K, ksplit, 1) : plan_skinny<bf16_t>(N, K, ksplit, MT);
+  out6[0] = q.gx; out6[1] = q.gy; out6[2] = q.NW; out6[3] = q.ntb; out6[4] = q.spw; out6[5] = (int)q.lds;
+  return ITTS_OK;
+}
+
+#if ITTS_DIAG
+// ---- diagnostic build only (libindextts_hip_diag.so, include/indextts_hip_diag.h); absent from the product library
 namespace itts { extern int g_conv_cfg; extern int g_attn_waves; }
 
 extern "C" int itts_debug_set(int key, int value) {
@@ -493,3 +548,15 @@ extern "C" int itts_debug_set(int key, int value) {
   else return ITTS_ERR_INVALID;
   return ITTS_OK;
 }
+
+// every later itts_gemm_skinny launch writes 16 u64 per workgroup to `buf` (NULL switches it off)
+extern "C" int itts_debug_stamps(void* buf) {
+#if ITTS_STAMPS
+  itts::g_stamp_buf = (unsigned long long*)buf;
+  return ITTS_OK;
+#else
+  (void)buf;
+  return ITTS_ERR_INVALID;
+#endif
+}
+#endif

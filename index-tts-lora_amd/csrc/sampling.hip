@@ -68,6 +68,13 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
   const float* lg = p.logits + (int64_t)b * p.ldl;
   const bool forced = p.finished[b] != 0 || (p.force_stop != nullptr && p.force_stop[b] >= 0 && p.force_stop[b] <= k);
 
+  // the row's logits are requested first (registers): their latency overlaps the bitmap construction
+  float lv[SM_MAXV / 256];
+#pragma unroll
+  for (int i = 0; i < SM_MAXV / 256; ++i) {
+    int idx = tid + i * 256;
+    lv[i] = idx < V ? lg[idx] : 0.f;
+  }
   // ---- repetition-penalty membership bitmap
   for (int i = tid; i < SM_MAXV / 32; i += 256) flag[i] = 0u;
   if (tid == 0) { sh_n = 0; sh_tok = p.stop_token; sh_keep = 0; }
@@ -85,11 +92,15 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
   }
   __syncthreads();
   const float inv_t = (p.do_sample && p.temperature != 1.0f) ? 1.0f / p.temperature : 1.0f;
-  for (int i = tid; i < V; i += 256) {
-    float v = lg[i];
-    if ((flag[i >> 5] >> (i & 31)) & 1u) v = v < 0.f ? v * p.rep_penalty : v / p.rep_penalty;
-    if (inv_t != 1.0f) v = v / p.temperature;
-    sv[i] = v;
+#pragma unroll
+  for (int i = 0; i < SM_MAXV / 256; ++i) {
+    int idx = tid + i * 256;
+    if (idx < V) {
+      float v = lv[i];
+      if ((flag[idx >> 5] >> (idx & 31)) & 1u) v = v < 0.f ? v * p.rep_penalty : v / p.rep_penalty;
+      if (inv_t != 1.0f) v = v / p.temperature;
+      sv[idx] = v;
+    }
   }
   __syncthreads();
 
@@ -120,29 +131,59 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
       for (int i = tid; i < V; i += 256) p.dbg_scores[(int64_t)b * V + i] = sv[i];
     __syncthreads();
   } else {
-    // ---- top-k threshold: the k-th largest order-preserving key, built bit by bit (32 counting rounds over the
-    //      register-resident keys; no LDS atomics -- random logits share their exponent bits, which serialises a radix
-    //      histogram on a handful of bins)
     int kk = p.top_k > 0 ? min(p.top_k, V) : min(V, SM_MAXC);
     if (kk > SM_MAXC) kk = SM_MAXC;
     uint32_t keys[SM_MAXV / 256];
+    uint32_t kmax = 0u;
 #pragma unroll
     for (int i = 0; i < SM_MAXV / 256; ++i) {
       int idx = tid + i * 256;
       keys[i] = idx < V ? fkey(sv[idx]) : 0u;  // key 0 is below every real float key
+      kmax = max(kmax, keys[i]);
     }
+    // ---- top-k threshold.  Fast path (k <= 256): the k-th largest of the 256 per-thread maxima is a LOWER bound of the
+    //      k-th largest score (k scores are at least that large), so the candidates are the few scores above it and the
+    //      exact k-th value falls out of their rank sort -- two barriers instead of 32 counting rounds.  If more than
+    //      SM_MAXC scores pass the bound (heavily tied logits), or k > 256, the exact bitwise bisection below decides.
     uint32_t thr = 0u;
-    for (int bit = 31; bit >= 0; --bit) {
-      const uint32_t cand = thr | (1u << bit);
-      // wave-wide count without cross-lane shuffles: one ballot + scalar popcount per key slot
+    bool exact = false;   // thr is the exact k-th largest key (bisection) rather than a lower bound
+    if (kk <= 256) {
+      uint32_t* tmax = reinterpret_cast<uint32_t*>(ss);   // ss is free until the rank sort
+      tmax[tid] = kmax;
+      __syncthreads();
+      int rank = 0;
+      for (int j = 0; j < 256; ++j) {
+        uint32_t o = tmax[j];
+        rank += (o > kmax || (o == kmax && j < tid)) ? 1 : 0;
+      }
+      if (rank == kk - 1) sh_prefix = kmax;
+      __syncthreads();
+      thr = sh_prefix;
       int cnt = 0;
 #pragma unroll
-      for (int i = 0; i < SM_MAXV / 256; ++i) cnt += __popcll(__ballot(keys[i] >= cand));
-      int* slot = &hist[(bit & 1) * 4];
-      if (lane == 0) slot[wave] = cnt;
+      for (int i = 0; i < SM_MAXV / 256; ++i) cnt += __popcll(__ballot(keys[i] >= thr));
+      if (lane == 0) hist[wave] = cnt;
       __syncthreads();
-      if (slot[0] + slot[1] + slot[2] + slot[3] >= kk) thr = cand;
+      if (hist[0] + hist[1] + hist[2] + hist[3] > SM_MAXC) thr = 0u;   // too many ties above the bound: bisect exactly
+      __syncthreads();
     }
+    if (thr == 0u) {
+      exact = true;
+      // the k-th largest order-preserving key, built bit by bit (32 counting rounds over the register-resident keys; no
+      // LDS atomics -- random logits share their exponent bits, which serialises a radix histogram on a handful of bins)
+      for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = thr | (1u << bit);
+        // wave-wide count without cross-lane shuffles: one ballot + scalar popcount per key slot
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < SM_MAXV / 256; ++i) cnt += __popcll(__ballot(keys[i] >= cand));
+        int* slot = &hist[(bit & 1) * 4];
+        if (lane == 0) slot[wave] = cnt;
+        __syncthreads();
+        if (slot[0] + slot[1] + slot[2] + slot[3] >= kk) thr = cand;
+      }
+    }
+    __syncthreads();
     if (tid == 0) sh_prefix = thr;
     __syncthreads();
     const uint32_t kth = sh_prefix;  // key of the k-th largest score; ties with it are kept (HF: scores < kth removed)
@@ -167,14 +208,32 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
       si[rank] = id;
     }
     __syncthreads();
-    if (tid == 0) {
-      // softmax numerators relative to the maximum; cs is reused for them
-      float total = 0.f;
-      for (int i = n - 1; i >= 0; --i) {
-        float e = expf(ss[i] - ss[0]);
-        cs[i] = e;
-        total += e;
+    if (!exact && n > kk) {
+      // candidates above the lower bound, sorted: keep the k best plus everything tied with the k-th (HF removes
+      // scores < k-th value only)
+      if (tid == 0) {
+        int keepk = kk;
+        const float kv = ss[kk - 1];
+        while (keepk < n && ss[keepk] == kv) ++keepk;
+        sh_n = keepk;
       }
+      __syncthreads();
+    }
+    const int n2 = min(sh_n, SM_MAXC);
+    // softmax numerators relative to the maximum, one per thread (cs is reused for them); the Philox draw is computed by
+    // another wave meanwhile; lane 0 then only runs the order-sensitive fp32 running sums
+    for (int i = tid; i < n2; i += 256) cs[i] = expf(ss[i] - ss[0]);
+    if (tid == 64) {
+      // key = launch argument + the 64-bit seed held in state[4..5] (lets a captured launch serve every seed)
+      const uint64_t key = (((uint64_t)p.seed_hi << 32) | p.seed_lo) + (((uint64_t)(uint32_t)p.state[5] << 32) | (uint32_t)p.state[4]);
+      uint32_t x = philox_first((uint32_t)b, (uint32_t)k, 0u, 0u, (uint32_t)key, (uint32_t)(key >> 32));
+      rv[0] = (float)(x >> 8) * (1.0f / 16777216.0f);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const int n = n2;
+      float total = 0.f;
+      for (int i = n - 1; i >= 0; --i) total += cs[i];
       int keep = n;
       if (p.top_p < 1.0f) {
         // HF TopPLogitsWarper: ascending cumulative probability <= 1 - top_p is removed, at least one token kept
@@ -186,17 +245,14 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
         }
       }
       sh_keep = keep;
-      // key = launch argument + the 64-bit seed held in state[4..5] (lets a captured launch serve every seed)
-      const uint64_t key = (((uint64_t)p.seed_hi << 32) | p.seed_lo) + (((uint64_t)(uint32_t)p.state[5] << 32) | (uint32_t)p.state[4]);
-      uint32_t x = philox_first((uint32_t)b, (uint32_t)k, 0u, 0u, (uint32_t)key, (uint32_t)(key >> 32));
-      float u = (float)(x >> 8) * (1.0f / 16777216.0f);
+      const float u = rv[0];
       float tot2 = 0.f;
       for (int i = 0; i < keep; ++i) tot2 += cs[i];
-      float thr = u * tot2, run = 0.f;
+      float dthr = u * tot2, run = 0.f;
       int pick = si[keep - 1];
       for (int i = 0; i < keep; ++i) {
         run += cs[i];
-        if (run > thr) { pick = si[i]; break; }
+        if (run > dthr) { pick = si[i]; break; }
       }
       sh_tok = pick;
     }

@@ -16,6 +16,8 @@ EPI_STORE, EPI_GELU_STORE, EPI_RESID_F32, EPI_QKV_CACHE, EPI_STORE_F32, EPI_SLAB
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libindextts_hip.so")
+# tools/ only: ITTS_HIP_LIB=<.../libindextts_hip_diag.so> loads the diagnostic build (tuning overrides, time stamps) instead
+_LIB_OVERRIDE = os.environ.get("ITTS_HIP_LIB")
 
 
 class NativeError(RuntimeError):
@@ -26,9 +28,10 @@ class SkinnyArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("wp", C.c_void_p),
                 ("bias", C.c_void_p), ("x", C.c_void_p), ("epi", C.c_int), ("y", C.c_void_p), ("yf", C.c_void_p),
                 ("kcache", C.c_void_p), ("vcache", C.c_void_p), ("pos", C.c_void_p), ("heads", C.c_int),
-                ("smax", C.c_int), ("ksplit", C.c_int), ("x_ln_f32", C.c_int), ("ln_h", C.c_void_p), ("ln_slab", C.c_void_p),
-                ("ln_nslab", C.c_int), ("ln_bias", C.c_void_p), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p),
-                ("ln_counter", C.c_void_p), ("ln_counter_prev", C.c_void_p)]
+                ("smax", C.c_int), ("ksplit", C.c_int), ("tail_h", C.c_void_p), ("tail_bias", C.c_void_p),
+                ("tail_w", C.c_void_p), ("tail_b", C.c_void_p), ("tail_w2", C.c_void_p), ("tail_b2", C.c_void_p),
+                ("tail_y", C.c_void_p), ("tail_counter", C.c_void_p), ("tail_epoch", C.c_void_p), ("tail_err", C.c_void_p),
+                ("tail_acquire", C.c_int)]
 
 
 class ConvArgs(C.Structure):
@@ -61,19 +64,19 @@ class BeamArgs(C.Structure):
 _SIGNATURES = {
     "itts_abi_version": (C.c_int, []),
     "itts_last_error": (C.c_char_p, []),
-    "itts_debug_set": (C.c_int, [C.c_int, C.c_int]),
     "itts_packed_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "itts_pack_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_aa_snake_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_gemm_skinny": (C.c_int, [C.POINTER(SkinnyArgs), C.c_void_p]),
+    "itts_skinny_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "itts_gemm_conv": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "itts_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_ln_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_embed_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
-                                  C.c_int, C.c_void_p]),
+                                  C.c_int, C.c_void_p, C.c_void_p]),
     "itts_attn_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_attn_prefill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -95,15 +98,16 @@ def lib():
     """Load (once) and return the shared library; raise NativeError if it is not built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise NativeError(f"{LIB_PATH} not found: build it with `make -C index-tts-lora_amd/csrc` "
+        path = _LIB_OVERRIDE or LIB_PATH
+        if not os.path.exists(path):
+            raise NativeError(f"{path} not found: build it with `make -C index-tts-lora_amd/csrc` "
                               f"(or python -c 'import __graft_entry__ as g; g.build()'). There is no fallback path.")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.itts_abi_version() != 1:
+        if L.itts_abi_version() != 2:
             raise NativeError("libindextts_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -116,6 +120,19 @@ def _check(rc, what):
 
 def dt(t: torch.dtype) -> int:
     return _DT[t]
+
+
+def debug_set(key: int, value: int):
+    """Tuning override of the DIAGNOSTIC build (tools/ only; include/indextts_hip_diag.h).  The product library has no
+    such entry point and no mutable knobs."""
+    L = lib()
+    try:
+        fn = L.itts_debug_set
+    except AttributeError:
+        raise NativeError("itts_debug_set exists only in libindextts_hip_diag.so: run the tool with "
+                          "ITTS_HIP_LIB=index-tts-lora_amd/indextts/_lib/libindextts_hip_diag.so (make -C index-tts-lora_amd/csrc diag)")
+    fn.restype, fn.argtypes = C.c_int, [C.c_int, C.c_int]
+    _check(fn(int(key), int(value)), "itts_debug_set")
 
 
 def _p(t):
@@ -171,20 +188,27 @@ def aa_snake(x, alpha_log, beta_log, up_f, down_f, layout=0, out=None):
 
 
 def gemm_skinny(dtype, M, N, K, wp, bias=None, x=None, epi=EPI_STORE, y=None, yf=None, kcache=None, vcache=None, pos=None,
-                heads=0, smax=0, ksplit=1, x_ln_f32=False, ln=None):
-    """ln = dict(h, w, b, counter[, slab, nslab, bias, prev]): fused producer stage, x = LN(h + bias + slabs) computed by the
-    first M workgroups of the same launch and written to `x` (see itts_skinny_args)."""
+                heads=0, smax=0, ksplit=1, tail=None):
+    """tail = dict(h, w, b, y, counter, epoch, err[, bias, w2, b2, acquire]): reducer tail of a split-K launch --
+    h += bias + slabs, y = LN(h) computed by the last M arriving workgroups of the same launch (see itts_skinny_args)."""
     a = SkinnyArgs()
-    if ln is not None:
-        a.ln_h, a.ln_w, a.ln_b, a.ln_counter = _p(ln["h"]), _p(ln["w"]), _p(ln["b"]), _p(ln["counter"])
-        a.ln_slab, a.ln_nslab, a.ln_bias = _p(ln.get("slab")), int(ln.get("nslab", 0)), _p(ln.get("bias"))
-        a.ln_counter_prev = _p(ln.get("prev"))
+    if tail is not None:
+        a.tail_h, a.tail_w, a.tail_b, a.tail_y = _p(tail["h"]), _p(tail["w"]), _p(tail["b"]), _p(tail["y"])
+        a.tail_bias, a.tail_w2, a.tail_b2 = _p(tail.get("bias")), _p(tail.get("w2")), _p(tail.get("b2"))
+        a.tail_counter, a.tail_epoch, a.tail_err = _p(tail["counter"]), _p(tail["epoch"]), _p(tail["err"])
+        a.tail_acquire = int(tail.get("acquire", 0))
     a.dtype, a.M, a.N, a.K = dt(dtype), M, N, K
     a.wp, a.bias, a.x = _p(wp), _p(bias), _p(x)
     a.epi, a.y, a.yf = epi, _p(y), _p(yf)
     a.kcache, a.vcache, a.pos, a.heads, a.smax, a.ksplit = _p(kcache), _p(vcache), _p(pos), heads, smax, ksplit
-    a.x_ln_f32 = int(bool(x_ln_f32))
     _check(lib().itts_gemm_skinny(C.byref(a), _stream()), "itts_gemm_skinny")
+
+
+def skinny_plan(dtype, M, N, K, ksplit=1) -> dict:
+    """Launch geometry itts_gemm_skinny would use (host-only)."""
+    out = (C.c_int * 6)()
+    _check(lib().itts_skinny_plan(dt(dtype), M, N, K, ksplit, out), "itts_skinny_plan")
+    return dict(grid=(out[0], out[1]), waves=out[2], tiles_per_wg=out[3], ksteps_per_wave=out[4], lds=out[5])
 
 
 def gemm_conv(dtype, B, Tin, Tout, Cin, N, wp, x, y, taps=1, off0=0, dil=1, x_bstride=None, bias=None, bias2=None,
@@ -221,9 +245,10 @@ def ln_reduce(h, w, b, out, slab=None, nslab=0, bias=None, w2=None, b2=None):
     return out
 
 
-def embed_step(tokens, table, pos_table, step, pos_add, h):
+def embed_step(tokens, table, pos_table, step, pos_add, h, epoch=None):
+    """epoch (int32 device word or None) is incremented once: the reducer tails of this decode step expect it."""
     B, D = h.shape
-    _check(lib().itts_embed_step(_p(tokens), _p(table), _p(pos_table), _p(step), pos_add, _p(h), B, D, _stream()),
+    _check(lib().itts_embed_step(_p(tokens), _p(table), _p(pos_table), _p(step), pos_add, _p(h), B, D, _p(epoch), _stream()),
            "itts_embed_step")
 
 

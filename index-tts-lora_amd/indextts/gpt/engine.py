@@ -36,25 +36,18 @@ class GPTEngine:
         def packed(w_kn):
             return nat.pack_weight(w_kn.detach().to(dev, dtype).contiguous())
 
-        # Decode-step structure (bf16/f16 only; the fp32 parity mode keeps separate LayerNorm launches):
-        #   mode 2: LayerNorm-2 is computed inside the FC GEMM (its affine part folded into the weights), the attention
-        #           out-projection updates the residual stream directly (no split-K)             -> 6 launches per block
-        #   mode 3: additionally LayerNorm-1 inside the QKV GEMM and an unsplit FC2               -> 5 launches per block
-        #   mode 1: every LayerNorm is its own [residual-reduce + LN] launch                      -> 7 launches per block
-        #   mode 4: the [residual-reduce + LN] rows are produced by 32 extra workgroups of the consumer GEMM's own launch
-        #           (in-launch hand-off: write-through rows, agent-scope counter, one acquire)    -> 5 launches per block
-        # Measured on MI355X (B=32, bf16): mode 1 1.29 ms/token, mode 2 1.32, mode 3 1.49 -- the unsplit N=1280 GEMMs
-        # (80 workgroups) and the heavier fused prologue cost more than the launches they save.  Mode 4 (after the wide
-        # ln_reduce brought mode 1 to 1.15 ms): 1.27 ms -- the hand-off (drain + counter + poll + acquire) costs ~2.4 us
-        # more per stage than the kernel boundary it removes, although the weight blocks are in flight meanwhile.  Mode 1
-        # stays the default.
-        self.decode_mode = int(os.environ.get("ITTS_DECODE_MODE", "1")) if dtype != torch.float32 else 1
-
-        def fold(ln_w, ln_b, w_kn, b_n):
-            """LN(x; g, b) @ W + c  ==  norm(x) @ (diag(g) W) + (b @ W + c)."""
-            wf = W[w_kn].detach().to(dev, torch.float32)
-            g, bb = W[ln_w].detach().to(dev, torch.float32), W[ln_b].detach().to(dev, torch.float32)
-            return packed(g[:, None] * wf), (bb @ wf + W[b_n].detach().to(dev, torch.float32)).contiguous()
+        # Decode-step structure:
+        #   "tail"   (default): the split-K out-projection / FC2 launches end with a reducer tail -- the last M arriving
+        #            workgroups fold the slabs into the residual stream and write LayerNorm(row) for the next GEMM --
+        #            5 launches per block (QKV, attention, out-proj+LN2, FC, FC2+LN1')
+        #   "launch": every [residual-reduce + LayerNorm] is a launch of its own -- 7 launches per block.  Same bits.
+        # Forms measured in round 1 and removed (profiles/README.md): LayerNorm inside the consumer GEMM's prologue (+3 % /
+        # +16 % per token), LN rows produced by extra workgroups of the CONSUMER's launch (+10 %).
+        self.decode_mode = os.environ.get("ITTS_DECODE_MODE", "tail")
+        if self.decode_mode not in ("tail", "launch"):
+            raise ValueError("ITTS_DECODE_MODE must be 'tail' or 'launch'")
+        self.tail_acquire = int(os.environ.get("ITTS_TAIL_ACQUIRE", "0"))
+        self.max_rows_per_launch = 16 if dtype == torch.float32 else 96   # rows one skinny-GEMM launch covers
 
         self.layers = []
         for i in range(layers):
@@ -67,11 +60,6 @@ class GPTEngine:
                 w_fc=packed(W[p + "mlp.c_fc.weight"]), b_fc=f32(p + "mlp.c_fc.bias"),
                 w_pr=packed(W[p + "mlp.c_proj.weight"]), b_pr=f32(p + "mlp.c_proj.bias"),
             )
-            if self.decode_mode in (2, 3):
-                d["w_fc_ln"], d["b_fc_ln"] = fold(p + "ln_2.weight", p + "ln_2.bias", p + "mlp.c_fc.weight", p + "mlp.c_fc.bias")
-            if self.decode_mode == 3:
-                d["w_qkv_ln"], d["b_qkv_ln"] = fold(p + "ln_1.weight", p + "ln_1.bias", p + "attn.c_attn.weight",
-                                                    p + "attn.c_attn.bias")
             self.layers.append(d)
         self.ln_f = (f32("gpt.ln_f.weight"), f32("gpt.ln_f.bias"))
         self.final_norm = (f32("final_norm.weight"), f32("final_norm.bias"))
@@ -89,7 +77,10 @@ class GPTEngine:
         self.force_eager = False  # measurement aid: launch every kernel eagerly
         self.steps_per_graph = int(os.environ.get("ITTS_STEPS_PER_GRAPH", "1"))  # decode tokens per CUDA-graph replay; measured 1 > 2 > 4 > 8 (1297 / 1319 / 1342 / 1368 us per token)
         self._sink = torch.zeros(4, dtype=torch.int32, device=dev)
-        self.ln_cnt = torch.zeros(2 * layers, dtype=torch.int32, device=dev)  # arrival counters of the fused LN stages (mode 4)
+        # arrival counters of the reducer tails: one per split-K launch site (2 per block), monotonic, never reset by the
+        # kernels; state[6] is the epoch the sites expect (advanced by embed_step once per decode step), state[7] the
+        # sticky error word of the tails
+        self.tail_cnt = torch.zeros((2 * layers + 3) // 4 * 4, dtype=torch.int32, device=dev)
         self.weight_bytes = sum(t.numel() * t.element_size() for l in self.layers for t in
                                 (l["w_qkv"], l["w_o"], l["w_fc"], l["w_pr"])) + self.w_head.numel()
 
@@ -102,7 +93,7 @@ class GPTEngine:
         e._graphs = {}
         e._beam_cap = (0, 0)
         e._sink = torch.zeros(4, dtype=torch.int32, device=self.device)
-        e.ln_cnt = torch.zeros_like(self.ln_cnt)
+        e.tail_cnt = torch.zeros_like(self.tail_cnt)
         return e
 
     # ------------------------------------------------------------------------------------------------ buffers
@@ -193,7 +184,8 @@ class GPTEngine:
         h = emb.view(B * S, D)[idx.to(dev)]
         h = self._blocks_full(h, B, S, None, True, row_off=row_off, cache_shift=self.pad[:B])
         self._head(h[last_rows].contiguous(), B)
-        self.state.zero_()
+        self.state.zero_()                 # step, cache position, finished rows, ..., tail epoch [6], tail error [7]
+        self.tail_cnt.zero_()              # the reducer tails count from (epoch - 1) * workgroups: both restart together
         self.state[1] = S - 1
         self.finished[:B] = 0
         self.history[:B].zero_()
@@ -234,60 +226,56 @@ class GPTEngine:
                    sp["repetition_penalty"], sp["temperature"], sp["top_k"], sp["top_p"], sp["do_sample"], sp["seed"],
                    self.stop_mel, dbg)
 
+    def _tail(self, site, h, xn, bias, ln, ln2=None):
+        t = dict(h=h, y=xn, bias=bias, w=ln[0], b=ln[1], counter=self.tail_cnt[site: site + 1], epoch=self.state[6:7],
+                 err=self.state[7:8], acquire=self.tail_acquire)
+        if ln2 is not None:
+            t.update(w2=ln2[0], b2=ln2[1])
+        return t
+
     def _step_transformer(self, B):
         """Transformer part of one cached decode step (model.py:163-193): embed token k at mel position k+1, 24 blocks,
-        head.  Seven launches per block: [residual-reduce + LN1] -> QKV (+K/V append) -> attention -> out-proj (split-K
-        slabs) -> [residual-reduce + LN2] -> FC + gelu -> FC2 (split-K slabs); the slabs of FC2 are folded into the next
-        block's LN1 launch (or the head's)."""
+        head.  "tail" form, 5 launches per block: QKV (+K/V append) -> attention -> out-proj (split-K slabs; tail: residual
+        update + LN2) -> FC + gelu -> FC2 (split-K slabs; tail: residual update + the NEXT block's LN1, or ln_f∘final_norm).
+        "launch" form, 7 per block: the two tails are itts_ln_reduce launches instead (same arithmetic, same bits)."""
         T, D, H, KS = self.dtype, self.D, self.H, self.KSPLIT
         step, pos = self.state[0:1], self.state[1:2]
         h, xn = self.h[:B], self.xn[:B]
         slab = self.slab.view(-1)[: KS * B * D].view(KS, B, D)  # [ks][B][D] on a contiguous prefix of the buffer
-        nat.embed_step(self.tokens, self.mel_emb, self.mel_pos, step, 1, h)
-        pending = None  # bias of an FC2 whose split-K slabs have not been folded into h yet
-        mode = self.decode_mode
-        if mode == 4 and B > 32:
-            mode = 1  # the fused producer stage handles one 32-row GEMM launch
+        tail = self.decode_mode == "tail" and B <= self.max_rows_per_launch
+        nat.embed_step(self.tokens, self.mel_emb, self.mel_pos, step, 1, h, epoch=self.state[6:7])
+        nat.ln_reduce(h, self.layers[0]["ln1"][0], self.layers[0]["ln1"][1], xn)
         for i, l in enumerate(self.layers):
-            # --- attention half
-            if mode == 4:
-                ln = dict(h=h, w=l["ln1"][0], b=l["ln1"][1], counter=self.ln_cnt[2 * i: 2 * i + 1],
-                          prev=self.ln_cnt[(2 * i - 1) % (2 * self.L):][:1])
-                if pending is not None:
-                    ln.update(slab=slab, nslab=KS, bias=pending)
-                nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv"], l["b_qkv"], x=xn, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
-                                vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s, ln=ln)
-            elif mode == 3:
-                nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv_ln"], l["b_qkv_ln"], x=h, x_ln_f32=True, epi=nat.EPI_QKV_CACHE, y=self.q,
-                                kcache=self.kc[i], vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s)
-            else:
-                if pending is None:
-                    nat.ln_reduce(h, l["ln1"][0], l["ln1"][1], xn)
-                else:
-                    nat.ln_reduce(h, l["ln1"][0], l["ln1"][1], xn, slab=slab, nslab=KS, bias=pending)
-                nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv"], l["b_qkv"], x=xn, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
-                                vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s)
+            nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv"], l["b_qkv"], x=xn, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
+                            vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s)
             nat.attn_decode(self.q, self.kc[i], self.vc[i], self.a, self.pad, pos, B, H, self._cap_s)
-            # --- MLP half
-            if mode == 4:
-                nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS)
-                ln = dict(h=h, w=l["ln2"][0], b=l["ln2"][1], counter=self.ln_cnt[2 * i + 1: 2 * i + 2],
-                          prev=self.ln_cnt[2 * i: 2 * i + 1], slab=slab, nslab=KS, bias=l["b_o"])
-                nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f, ln=ln)
-            elif mode >= 2:
-                nat.gemm_skinny(T, B, D, D, l["w_o"], l["b_o"], x=self.a, epi=nat.EPI_RESID_F32, yf=h)
-                nat.gemm_skinny(T, B, 4 * D, D, l["w_fc_ln"], l["b_fc_ln"], x=h, x_ln_f32=True, epi=nat.EPI_GELU_STORE, y=self.f)
+            last = i + 1 == self.L
+            nxt = self.ln_f if last else self.layers[i + 1]["ln1"]
+            nxt2 = self.final_norm if last else None
+            if tail:
+                nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS,
+                                tail=self._tail(2 * i, h, xn, l["b_o"], l["ln2"]))
+                nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f)
+                nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], None, x=self.f, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS,
+                                tail=self._tail(2 * i + 1, h, xn, l["b_pr"], nxt, nxt2))
             else:
                 nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS)
                 nat.ln_reduce(h, l["ln2"][0], l["ln2"][1], xn, slab=slab, nslab=KS, bias=l["b_o"])
                 nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f)
-            if mode == 3:
-                nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], l["b_pr"], x=self.f, epi=nat.EPI_RESID_F32, yf=h)
-                pending = None
-            else:
                 nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], None, x=self.f, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS)
-                pending = l["b_pr"]
-        self._head(h, B, pending=None if pending is None else (slab, KS, pending))
+                if last:
+                    nat.ln_reduce(h, nxt[0], nxt[1], xn, slab=slab, nslab=KS, bias=l["b_pr"], w2=nxt2[0], b2=nxt2[1])
+                else:
+                    nat.ln_reduce(h, nxt[0], nxt[1], xn, slab=slab, nslab=KS, bias=l["b_pr"])
+        nat.gemm_skinny(T, B, self.V, D, self.w_head, self.b_head, x=self.xn, epi=nat.EPI_STORE_F32, yf=self.logits)
+
+    def _poll(self):
+        """One host synchronisation of the token loop: (finished rows, raises if a reducer tail reported an error)."""
+        st = self.state.tolist()
+        if st[7] != 0:
+            raise nat.NativeError(f"decode step: reducer tail error {st[7]} (1 = a reducer waited too long for its launch's "
+                                  f"tickets, 2 = counter/epoch out of step); the generated tokens are invalid")
+        return st[2]
 
     def _step_kernels(self, B, sp):
         self._step_transformer(B)
@@ -295,20 +283,32 @@ class GPTEngine:
 
     def gemm_launches_of_step(self, B):
         """Measurement aid (bench.py): ONLY the skinny-GEMM launches of one decode step, with the step's real arguments
-        (97 launches: 4 per block + the head).  Returns (launch count, algorithmic bytes: weights once + activations)."""
+        (97 launches: 4 per block + the head; in "tail" mode the split-K ones carry their reducer tails, and one
+        embed_step launch in front advances the tails' epoch).  Returns (GEMM launch count, algorithmic bytes: weights
+        once + activations; the tails add the residual rows they read and write)."""
         T, D, H, KS = self.dtype, self.D, self.H, self.KSPLIT
         pos = self.state[1:2]
-        xn = self.xn[:B]
+        h, xn = self.h[:B], self.xn[:B]
         slab = self.slab.view(-1)[: KS * B * D].view(KS, B, D)
         es = 4 if T == torch.float32 else 2
+        tail = self.decode_mode == "tail" and B <= self.max_rows_per_launch
         nbytes, n = 0, 0
+        if tail:
+            nat.embed_step(self.tokens, self.mel_emb, self.mel_pos, self.state[0:1], 1, h, epoch=self.state[6:7])
         for i, l in enumerate(self.layers):
+            last = i + 1 == self.L
+            nxt = self.ln_f if last else self.layers[i + 1]["ln1"]
+            nxt2 = self.final_norm if last else None
             nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv"], l["b_qkv"], x=xn, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
                             vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s)
-            nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS)
+            nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS,
+                            tail=self._tail(2 * i, h, xn, l["b_o"], l["ln2"]) if tail else None)
             nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f)
-            nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], None, x=self.f, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS)
+            nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], None, x=self.f, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS,
+                            tail=self._tail(2 * i + 1, h, xn, l["b_pr"], nxt, nxt2) if tail else None)
             nbytes += 12 * D * D * es + B * D * es * (1 + 1 + 1 + 4) + B * es * (3 * D + 4 * D) + 2 * KS * B * D * 4
+            if tail:
+                nbytes += 2 * (KS * B * D * 4 + 2 * B * D * 4 + B * D * es)   # slabs read back, h read + written, xn written
             n += 4
         nat.gemm_skinny(T, B, self.V, D, self.w_head, self.b_head, x=self.xn, epi=nat.EPI_STORE_F32, yf=self.logits)
         nbytes += self.V * D * es + B * D * es + B * self.V * 4
@@ -340,8 +340,9 @@ class GPTEngine:
             n += k
             if return_logits:
                 logits_trace.append(self.logits[:B].clone())
-            if n // check_every != prev // check_every and int(self.state[2].item()) >= B:
+            if n // check_every != prev // check_every and self._poll() >= B:
                 break
+        self._poll()
         codes = self.history[:B, :n].to(torch.int64)
         return (codes, torch.stack(logits_trace, 0)) if return_logits else codes
 
@@ -411,8 +412,9 @@ class GPTEngine:
             else:
                 self._step_kernels_beam(B, nb, sp)
             n += 1
-            if n % check_every == 0 and int(self.state[2].item()) >= B:
+            if n % check_every == 0 and self._poll() >= B:
                 break
+        self._poll()
         return self._beam_finalize(B, nb, n, float(sp.get("length_penalty", 0.0)), max_new)
 
     def _beam_finalize(self, B, nb, n, length_penalty, max_new):

@@ -381,27 +381,6 @@ def test_tanh_pcm(nat):
     assert np.array_equal(pcm.cpu().numpy(), exp)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M,N", [(1, 3840), (13, 5120), (32, 5120), (32, 8194)])
-def test_gemm_skinny_layernorm_fused(nat, dtype, M, N):
-    """A operand = fp32 rows normalised on the fly; LayerNorm affine folded into W / bias by the caller."""
-    K = 1280
-    h = rnd(M, K, seed=120, scale=3.0) + 1.5          # non-zero mean on purpose
-    g, bb = 1 + 0.1 * rnd(K, seed=121), 0.1 * rnd(K, seed=122)
-    w = rnd(K, N, seed=123) * 0.03
-    c = rnd(N, seed=124)
-    wf = (g[:, None] * w).to(dtype)
-    bf = (bb @ w + c).contiguous()
-    wp = nat.pack_weight(wf)
-    xhat = F.layer_norm(h, (K,), None, None, 1e-5)
-    ref = xhat.to(dtype).float() @ wf.float() + bf      # what the kernel computes, in fp32
-    y = torch.empty(M, N, dtype=dtype, device=DEV)
-    nat.gemm_skinny(dtype, M, N, K, wp, bf, x=h, x_ln_f32=True, epi=nat.EPI_STORE, y=y)
-    assert (y.float() - ref).abs().max().item() < 3e-2
-    full = F.layer_norm(h, (K,), g, bb, 1e-5) @ w + c   # the un-folded fp32 computation
-    assert (y.float() - full).abs().max().item() < 6e-2
-
-
 @pytest.mark.parametrize("do_sample,lp", [(True, 0.0), (False, 0.0), (True, 1.0)])
 def test_beam_step_matches_oracle(nat, do_sample, lp):
     """itts_beam_step over several steps (EOS becomes likely half-way) against oracle/beam_ref.py: same tokens, same
@@ -467,35 +446,101 @@ def test_beam_reorder_kv(nat, dtype):
     assert torch.equal(kc[:, :, :, ctx:], k0[:, :, :, ctx:]) and torch.equal(vc[:, :, :, ctx:], v0[:, :, :, ctx:])
 
 
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])   # 16-bit only: fp32 needs two passes of the k-loop
-@pytest.mark.parametrize("nslab", [0, 3])
-def test_gemm_skinny_fused_layernorm_stage(nat, dtype, nslab):
-    """The fused launch (producer workgroups compute LN(h + bias + slabs), GEMM workgroups wait for them inside the same
-    launch) must reproduce the two-launch sequence itts_ln_reduce -> itts_gemm_skinny bit for bit, many times in a row
-    (the consumer CUs have the previous round's x lines in their caches), and leave h updated the same way."""
-    M, D, N = 32, 1280, 3840
-    w = (rnd(D, N, seed=70) * 0.03).to(dtype)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(33, 3840, 1280), (64, 5120, 1280), (96, 1280, 5120), (77, 8194, 1280), (96, 3840, 1280)])
+def test_gemm_skinny_many_rows_one_weight_pass(nat, dtype, M, N, K):
+    """33..96 rows (4 / 6 row tiles) in ONE launch: same results as the 32-row launches row block by row block, bit for
+    bit (a row's dot products do not depend on its neighbours), and close to the fp32 reference."""
+    x = rnd(M, K, seed=130).to(dtype)
+    w = (rnd(K, N, seed=131) * 0.05).to(dtype)
+    bias = rnd(N, seed=132)
     wp = nat.pack_weight(w)
-    bias = rnd(N, seed=71)
-    lw, lb = 1.0 + 0.1 * rnd(D, seed=72), 0.1 * rnd(D, seed=73)
-    ob = rnd(D, seed=74)
-    cnt = torch.zeros(2, dtype=torch.int32, device=DEV)
-    for it in range(6):
-        h0 = rnd(M, D, seed=80 + it)
-        slab = rnd(3, M, D, seed=90 + it) if nslab else None
-        h_ref, x_ref = h0.clone(), torch.empty(M, D, dtype=dtype, device=DEV)
-        nat.ln_reduce(h_ref, lw, lb, x_ref, slab=slab, nslab=nslab, bias=ob if nslab else None)
-        y_ref = torch.empty(M, N, dtype=dtype, device=DEV)
-        nat.gemm_skinny(dtype, M, N, D, wp, bias, x=x_ref, epi=nat.EPI_GELU_STORE, y=y_ref)
-        h, x, y = h0.clone(), torch.full((M, D), 7.0, dtype=dtype, device=DEV), torch.empty(M, N, dtype=dtype, device=DEV)
-        ln = dict(h=h, w=lw, b=lb, counter=cnt[it % 2: it % 2 + 1], prev=cnt[(it + 1) % 2: (it + 1) % 2 + 1])
-        if nslab:
-            ln.update(slab=slab, nslab=nslab, bias=ob)
-        nat.gemm_skinny(dtype, M, N, D, wp, bias, x=x, epi=nat.EPI_GELU_STORE, y=y, ln=ln)
+    y = torch.empty(M, N, dtype=dtype, device=DEV)
+    nat.gemm_skinny(dtype, M, N, K, wp, bias, x=x, epi=nat.EPI_GELU_STORE, y=y)
+    ref = gelu_new(x.float() @ w.float() + bias)
+    assert (y.float() - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item())
+    for r0 in range(0, M, 32):
+        m = min(32, M - r0)
+        yb = torch.empty(m, N, dtype=dtype, device=DEV)
+        nat.gemm_skinny(dtype, m, N, K, wp, bias, x=x[r0:r0 + m].contiguous(), epi=nat.EPI_GELU_STORE, y=yb)
+        assert torch.equal(y[r0:r0 + m], yb), r0
+    plan = nat.skinny_plan(dtype, M, N, K)
+    assert plan["grid"][0] * plan["grid"][1] <= 256
+
+
+def test_gemm_skinny_qkv_cache_epilogue_many_rows(nat):
+    """QKV epilogue at 96 rows (batch 32 x 3 beams): q rows, and k/v scattered into the cache at *pos, per head."""
+    dtype, M, H, smax, pos = torch.bfloat16, 96, 20, 64, 17
+    D = H * 64
+    x = rnd(M, D, seed=140).to(dtype)
+    w = (rnd(D, 3 * D, seed=141) * 0.03).to(dtype)
+    bias = rnd(3 * D, seed=142)
+    wp = nat.pack_weight(w)
+    q = torch.empty(M, D, dtype=dtype, device=DEV)
+    kc = torch.zeros(M, H, smax, 64, dtype=dtype, device=DEV)
+    vc = torch.zeros_like(kc)
+    posd = torch.tensor([pos], dtype=torch.int32, device=DEV)
+    nat.gemm_skinny(dtype, M, 3 * D, D, wp, bias, x=x, epi=nat.EPI_QKV_CACHE, y=q, kcache=kc, vcache=vc, pos=posd, heads=H, smax=smax)
+    ref = (x.float() @ w.float() + bias)
+    tol = 2e-2 * max(1.0, ref.abs().max().item())
+    assert (q.float() - ref[:, :D]).abs().max().item() < tol
+    assert (kc[:, :, pos].reshape(M, D).float() - ref[:, D:2 * D]).abs().max().item() < tol
+    assert (vc[:, :, pos].reshape(M, D).float() - ref[:, 2 * D:]).abs().max().item() < tol
+    kc[:, :, pos] = 0
+    vc[:, :, pos] = 0
+    assert kc.abs().max().item() == 0 and vc.abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype,M", [(torch.bfloat16, 32), (torch.bfloat16, 96), (torch.bfloat16, 5), (torch.float32, 16), (torch.float16, 48)])
+@pytest.mark.parametrize("K,two", [(1280, False), (5120, True)])
+def test_gemm_skinny_reducer_tail_equals_ln_reduce_launch(nat, dtype, M, K, two):
+    """Split-K launch with the reducer tail (slab tiles stored write-through, arrival tickets, the last M arrivals reduce
+    one row each) against the two-launch form itts_gemm_skinny(slabs) -> itts_ln_reduce: residual stream, normalised rows
+    and slabs must be IDENTICAL BITS, many rounds in a row on the same buffers (the reducers' caches hold the previous
+    round's slab lines: a stale read shows as a mismatch), with a streaming kernel queued in between to perturb arrival
+    order.  Counter protocol: monotonic counter, epoch advanced once per round."""
+    N, KS = 1280, 3
+    w = (rnd(K, N, seed=150) * 0.03).to(dtype)
+    wp = nat.pack_weight(w)
+    ob = rnd(N, seed=151)
+    lw, lb = 1.0 + 0.1 * rnd(N, seed=152), 0.1 * rnd(N, seed=153)
+    lw2, lb2 = (1.0 + 0.1 * rnd(N, seed=154), 0.1 * rnd(N, seed=155)) if two else (None, None)
+    cnt = torch.zeros(4, dtype=torch.int32, device=DEV)
+    st = torch.zeros(8, dtype=torch.int32, device=DEV)      # [6] epoch, [7] error
+    slab_a = torch.zeros(KS, M, N, device=DEV)
+    slab_b = torch.zeros(KS, M, N, device=DEV)
+    h_a, xn_a = torch.zeros(M, N, device=DEV), torch.zeros(M, N, dtype=dtype, device=DEV)
+    big = torch.zeros(64 << 20, device=DEV)
+    plan = nat.skinny_plan(dtype, M, N, K, KS)
+    W = plan["grid"][0] * plan["grid"][1]
+    assert M <= W <= 256
+    for it in range(12):
+        x = rnd(M, K, seed=160 + it).to(dtype)
+        h0 = rnd(M, N, seed=180 + it, scale=2.0) + 0.3
+        # launch form
+        h_b, xn_b = h0.clone(), torch.empty(M, N, dtype=dtype, device=DEV)
+        nat.gemm_skinny(dtype, M, N, K, wp, None, x=x, epi=nat.EPI_SLAB_F32, yf=slab_b, ksplit=KS)
+        nat.ln_reduce(h_b, lw, lb, xn_b, slab=slab_b, nslab=KS, bias=ob, w2=lw2, b2=lb2)
+        # tail form, same buffers every round
+        h_a.copy_(h0)
+        xn_a.fill_(7.0)
+        st[6] += 1
+        if it % 2:
+            big.add_(1.0)                                    # 256 MiB of streaming traffic right in front of the launch
+        tail = dict(h=h_a, y=xn_a, bias=ob, w=lw, b=lb, counter=cnt[0:1], epoch=st[6:7], err=st[7:8], acquire=it % 3 == 2)
+        if two:
+            tail.update(w2=lw2, b2=lb2)
+        nat.gemm_skinny(dtype, M, N, K, wp, None, x=x, epi=nat.EPI_SLAB_F32, yf=slab_a, ksplit=KS, tail=tail)
         torch.cuda.synchronize()
-        assert torch.equal(x, x_ref) and torch.equal(h, h_ref), f"round {it}"
-        assert torch.equal(y, y_ref), f"round {it}"
-        assert cnt[it % 2].item() == M and cnt[(it + 1) % 2].item() == 0
+        assert st[7].item() == 0
+        assert cnt[0].item() == (it + 1) * W
+        assert torch.equal(slab_a, slab_b), f"round {it}: slabs"
+        assert torch.equal(h_a, h_b), f"round {it}: residual stream"
+        assert torch.equal(xn_a, xn_b), f"round {it}: LayerNorm rows"
+    # a launch whose epoch was not advanced finds its tickets outside the window: flagged, not silently wrong
+    nat.gemm_skinny(dtype, M, N, K, wp, None, x=x, epi=nat.EPI_SLAB_F32, yf=slab_a, ksplit=KS, tail=tail)
+    torch.cuda.synchronize()
+    assert st[7].item() == 2
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

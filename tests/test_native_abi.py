@@ -25,8 +25,14 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/indextts_hip.h but not exported"
     assert set(syms) == set(_native.EXPORTED_SYMBOLS)
+    # the diagnostic entry points (include/indextts_hip_diag.h: tuning overrides, time stamps) are NOT in the product library
+    diag = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "indextts_hip_diag.h")).read(), flags=re.S)
+    dsyms = sorted(set(re.findall(r"\b(itts_[a-z0-9_]+)\s*\(", diag)))
+    assert dsyms == ["itts_debug_set", "itts_debug_stamps"]
+    for s in dsyms:
+        assert not hasattr(lib, s), f"{s} (diagnostic build only) is exported by the product library"
     lib.itts_abi_version.restype = ctypes.c_int
-    assert lib.itts_abi_version() == 1
+    assert lib.itts_abi_version() == 2
     lib.itts_packed_bytes.restype = ctypes.c_int64
     assert lib.itts_packed_bytes(1, 1280, 3840, 1) == 1280 * 3840 * 2
     assert lib.itts_packed_bytes(7, 24, 1, 0) == 7 * 1 * 2 * 1024

@@ -10,6 +10,8 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "index-tts-lora_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
+import os as _os
+_os.environ.setdefault("ITTS_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "index-tts-lora_amd", "indextts", "_lib", "libindextts_hip_diag.so"))  # tuning knobs live in the diagnostic build
 import torch  # noqa: E402
 
 from indextts import _native as nat  # noqa: E402
@@ -167,18 +169,18 @@ for name, K, ws, xin in (("proj", D, w_o, a), ("FC2", 4 * D, w_pr, f)):
                 for _ in range(R):
                     for i in range(L):
                         nat.gemm_skinny(T, B, D, K, ws[i], None, x=xin, epi=nat.EPI_SLAB_F32, yf=slab8, ksplit=ks)
-            nat.lib().itts_debug_set(1, ntb)
+            nat.debug_set(1, ntb)
             us = timed_graph(fn, R * L)
             log(f"{name} ksplit={ks} ntb={ntb}: {us:6.2f} us  (blocks {((80 + ntb - 1) // ntb) * ks})")
-nat.lib().itts_debug_set(1, 0)
+nat.debug_set(1, 0)
 for ntb in (1, 2, 3):
     for nw in (4, 8):
-        nat.lib().itts_debug_set(1, ntb)
-        nat.lib().itts_debug_set(2, nw)
+        nat.debug_set(1, ntb)
+        nat.debug_set(2, nw)
         us = timed_graph(exp_fc, R * L)
         log(f"FC ntb={ntb} nw={nw}: {us:6.2f} us")
-nat.lib().itts_debug_set(1, 0)
-nat.lib().itts_debug_set(2, 0)
+nat.debug_set(1, 0)
+nat.debug_set(2, 0)
 for ns in (3, 6, 8):
     def fn(ns=ns):
         for _ in range(R * L):

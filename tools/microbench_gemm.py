@@ -6,6 +6,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "index-tts-lora_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
+import os as _os
+_os.environ.setdefault("ITTS_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "index-tts-lora_amd", "indextts", "_lib", "libindextts_hip_diag.so"))  # tuning knobs live in the diagnostic build
 import torch  # noqa: E402
 
 from indextts import _native as nat  # noqa: E402
@@ -43,7 +45,7 @@ def bench(name, dtype, B, T, Cin, N, taps, dil, y_f32=False, resid=False, act=0)
 
 bf, fh = torch.bfloat16, torch.float16
 if os.environ.get("ITTS_CONV_CFG"):
-    nat.lib().itts_debug_set(3, int(os.environ["ITTS_CONV_CFG"]))
+    nat.debug_set(3, int(os.environ["ITTS_CONV_CFG"]))
     print("plain-GEMM tile cfg", os.environ["ITTS_CONV_CFG"])
 bench("prefill QKV  3008x3840x1280", bf, 1, 3008, 1280, 3840, 1, 1)
 bench("prefill proj 3008x1280x1280 +res", bf, 1, 3008, 1280, 1280, 1, 1, y_f32=True, resid=True)

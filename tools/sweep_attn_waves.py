@@ -6,6 +6,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "index-tts-lora_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
+import os as _os
+_os.environ.setdefault("ITTS_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "index-tts-lora_amd", "indextts", "_lib", "libindextts_hip_diag.so"))  # tuning knobs live in the diagnostic build
 import torch  # noqa: E402
 
 from indextts import _native as nat  # noqa: E402
@@ -21,7 +23,7 @@ state = torch.zeros(8, dtype=torch.int32, device=dev)
 for ctx in (100, 165, 236):
     state[1] = ctx - 1
     for nw in (4, 8):
-        nat.lib().itts_debug_set(4, nw)
+        nat.debug_set(4, nw)
 
         def fn():
             for _ in range(R):
@@ -42,4 +44,4 @@ for ctx in (100, 165, 236):
         torch.cuda.synchronize()
         us = 1e3 * e0.elapsed_time(e1) / (20 * R * L)
         print(f"ctx {ctx:3d} waves {nw}: {us:6.2f} us  ({B * ctx * 2 * D * 2 / us / 1e6:5.2f} TB/s)", flush=True)
-nat.lib().itts_debug_set(4, 4)
+nat.debug_set(4, 4)

@@ -6,6 +6,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "index-tts-lora_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
+import os as _os
+_os.environ.setdefault("ITTS_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "index-tts-lora_amd", "indextts", "_lib", "libindextts_hip_diag.so"))  # tuning knobs live in the diagnostic build
 import torch  # noqa: E402
 
 from indextts import _native as nat  # noqa: E402
@@ -60,11 +62,11 @@ exps = {
 }
 for name, one in exps.items():
     for nw in (0, 4, 6, 8, 10, 12, 16):
-        nat.lib().itts_debug_set(2, nw)
+        nat.debug_set(2, nw)
 
         def fn():
             for _ in range(R):
                 for i in range(L):
                     one(i)
         print(f"{name:10s} waves={nw or 'auto':>4}: {timed_graph(fn, R * L):6.2f} us", flush=True)
-nat.lib().itts_debug_set(2, 0)
+nat.debug_set(2, 0)
