@@ -107,16 +107,18 @@ typedef struct itts_skinny_args {
   int heads, smax;
   int ksplit; /* split-K over workgroups (grid.y); > 1 only with ITTS_EPI_SLAB_F32 */
   /* Reducer tail (tail_h != NULL; needs ITTS_EPI_SLAB_F32, ksplit <= 4, N % 4 == 0, N <= 2048, all M rows in ONE launch and
-   * M <= workgroups <= 256).  After a workgroup has stored its slab tile (write-through) it draws an arrival ticket from
-   * *tail_counter; the last M arrivals wait until every ticket of the launch is drawn, then arrival i reduces row i:
+   * M <= workgroups <= 256).  After a workgroup has stored its slab tile (write-through) it signals: one agent-scope add
+   * into shard (workgroup id % 8) of tail_counter[8].  Workgroups 0..M-1 then wait until every workgroup of the launch
+   * has signalled, and workgroup r reduces row r:
    *     tail_h[row][:] += tail_bias[:] + slab[0][row][:] + ... + slab[ksplit-1][row][:]      (fixed order, in place)
    *     tail_y[row][:]  = LN(tail_h[row]; tail_w, tail_b)   (then LN(.; tail_w2, tail_b2) if tail_w2 != NULL),  T [M][N]
-   * bit for bit what itts_ln_reduce computes in a launch of its own.  Counter protocol: *tail_counter is monotonic and is
-   * never reset by the kernel; a launch expects its tickets in [(e-1)*W, e*W) where e = *tail_epoch (a device word the
-   * caller advances once per use of this launch site, e.g. once per decode step) and W = workgroups of the launch; start
-   * from counter = 0, epoch = 1.  A reducer that waits too long, or tickets outside the window, set *tail_err (sticky,
-   * non-zero): the caller checks it when it next synchronises.  tail_acquire != 0 adds an agent-scope acquire fence after
-   * the wait (the slab bytes are read with L1-bypassing loads either way). */
+   * bit for bit what itts_ln_reduce computes in a launch of its own.  Counter protocol: the 8 shards are monotonic and
+   * never reset by the kernel; a launch waits until shard s holds e * W_s, where e = *tail_epoch (a device word the
+   * caller advances once per use of this launch site, e.g. once per decode step) and W_s = workgroups of the launch
+   * with id % 8 == s; start from counters = 0, epoch = 1.  A reducer that waits too long sets *tail_err = 1, shards
+   * beyond the expected value (a lost or repeated launch) set it to 2 (sticky): the caller checks it when it next
+   * synchronises.  tail_acquire != 0 adds an agent-scope acquire fence after the wait (the slab bytes are read with
+   * L1-bypassing loads either way). */
   float* tail_h;
   const float* tail_bias;
   const float* tail_w;
@@ -124,7 +126,7 @@ typedef struct itts_skinny_args {
   const float* tail_w2;
   const float* tail_b2;
   void* tail_y;
-  int32_t* tail_counter;
+  int32_t* tail_counter; /* [8] shards */
   const int32_t* tail_epoch;
   int32_t* tail_err;
   int tail_acquire;
@@ -168,12 +170,14 @@ int itts_gemm_conv(const itts_conv_args* a, void* stream);
 int itts_layernorm(const float* h, const float* w, const float* b, const float* w2, const float* b2, void* y, int y_f32,
                    int M, int D, int dtype, void* stream);
 
-/* Residual update + LayerNorm for the decode step, one wave per row:
+/* Residual update + LayerNorm for the decode step:
  *   if (nslab > 0)  h[m][:] += bias[:] + slab[0][m][:] + ... + slab[nslab-1][m][:]      (fixed order; h updated in place)
  *   y[m][:] = LN(h[m][:]; w, b)   (then LN(.; w2, b2) if w2 != NULL),  y is T [M][D].
- * slab is fp32 [nslab][M][D] as written by itts_gemm_skinny(ITTS_EPI_SLAB_F32). */
+ * slab is fp32 [nslab][M][D] as written by itts_gemm_skinny(ITTS_EPI_SLAB_F32).
+ * state_bump (int32[2] device words or NULL): both words are incremented once by this launch -- the decode loop's step
+ * counter and cache position, advanced here (a launch that reads neither) instead of by the sampling kernel. */
 int itts_ln_reduce(float* h, const float* slab, int nslab, const float* bias, const float* w, const float* b,
-                   const float* w2, const float* b2, void* y, int M, int D, int dtype, void* stream);
+                   const float* w2, const float* b2, void* y, int M, int D, int dtype, int32_t* state_bump, void* stream);
 
 /* h[b][:] = table[tokens[b]][:] + pos_table[*step + pos_add][:]   (fp32 tables, fp32 h).  If epoch != NULL, *epoch is
  * incremented once (the first launch of a decode step advances the epoch of that step's reducer tails). */
@@ -222,6 +226,9 @@ typedef struct itts_sample_args {
   uint64_t seed;     /* Philox key = seed + the 64-bit value in state[4..5] (lo, hi): a captured launch serves any seed */
   int stop_token;
   float* dbg_scores; /* optional [B][V] processed scores (-inf = removed), for parity tests; NULL in production */
+  int no_advance;    /* != 0: leave state[0] / state[1] alone -- the caller advances them in the next step's first
+                        itts_ln_reduce launch (state_bump), which removes a device-wide fence and a returning atomic
+                        per row from this kernel; itts_embed_step is then given pos_add + 1 */
 } itts_sample_args;
 int itts_sample(const itts_sample_args* a, void* stream);
 

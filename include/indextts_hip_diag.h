@@ -22,6 +22,11 @@ int itts_debug_set(int key, int value);
  * NULL switches the stamps off. */
 int itts_debug_stamps(void* buf);
 
+/* the same for itts_sample: 16 x u64 per batch row: s_memtime at 0 entry, 1 logits + bitmap done, 2 processed scores in LDS,
+ * 3 threshold known, 4 candidates compacted, 5 rank sort done, 6 token drawn, 7 bookkeeping done; [14] / [15] s_memrealtime
+ * at entry / exit */
+int itts_debug_stamps_sample(void* buf);
+
 #ifdef __cplusplus
 }
 #endif

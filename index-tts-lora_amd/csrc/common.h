@@ -13,6 +13,25 @@
 #if ITTS_DIAG
 #include "../../include/indextts_hip_diag.h"
 #endif
+#ifndef ITTS_STAMPS
+#define ITTS_STAMPS 0       // diagnostic build only (make diag): s_memtime stamps per workgroup, see tools/timeline_*.py
+#endif
+#if ITTS_STAMPS
+namespace itts { extern unsigned long long* g_stamp_buf; extern unsigned long long* g_stamp_buf_sample; }
+// one stamp: s_memtime of lane 0 of the workgroup into the local array st_[i] (declared by the kernel)
+#define ITTS_STAMP_IF(cond, i)                                                                         \
+  do {                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    if ((cond) && threadIdx.x == 0) {                                                                  \
+      unsigned long long t_;                                                                           \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                        \
+      st_[i] = t_;                                                                                     \
+    }                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+  } while (0)
+#else
+#define ITTS_STAMP_IF(cond, i) do { } while (0)
+#endif
 
 namespace itts {
 

@@ -206,8 +206,10 @@ template <typename T, int NV, int NSLAB, bool LN2>
 __global__ __launch_bounds__(64) void ln_reduce_kernel(float* __restrict__ h, const float* __restrict__ slab,
                                                         const float* __restrict__ bias, const float* __restrict__ w,
                                                         const float* __restrict__ b, const float* __restrict__ w2,
-                                                        const float* __restrict__ b2, T* __restrict__ y, int M, int D) {
+                                                        const float* __restrict__ b2, T* __restrict__ y, int M, int D,
+                                                        int32_t* __restrict__ bump) {
   const int row = blockIdx.x, lane = threadIdx.x;
+  if (bump != nullptr && row == 0 && lane == 0) { bump[0] += 1; bump[1] += 1; }
   float* hr = h + (int64_t)row * D;
   const int nv = D / 4;
   f32x4 v[NV], bs[NV], sl[NSLAB > 0 ? NSLAB : 1][NV], lw[NV], lb[NV], lw2[LN2 ? NV : 1], lb2[LN2 ? NV : 1];
@@ -293,9 +295,11 @@ template <typename T, int NSLAB, bool LN2>
 __global__ __launch_bounds__(1024) void ln_reduce_wide_kernel(float* __restrict__ h, const float* __restrict__ slab,
                                                               const float* __restrict__ bias, const float* __restrict__ w,
                                                               const float* __restrict__ b, const float* __restrict__ w2,
-                                                              const float* __restrict__ b2, T* __restrict__ y, int M, int D) {
+                                                              const float* __restrict__ b2, T* __restrict__ y, int M, int D,
+                                                              int32_t* __restrict__ bump) {
   __shared__ float red[2][2][16];
   const int row = blockIdx.x, tid = threadIdx.x, nw = blockDim.x >> 6;
+  if (bump != nullptr && row == 0 && tid == 0) { bump[0] += 1; bump[1] += 1; }   // nobody in this launch reads them
   float* hr = h + (int64_t)row * D;
   f32x4 v = ld16<f32x4>(hr + tid * 4);
   const f32x4 lw = ld16<f32x4>(w + tid * 4), lb = ld16<f32x4>(b + tid * 4);
@@ -321,14 +325,14 @@ __global__ __launch_bounds__(1024) void ln_reduce_wide_kernel(float* __restrict_
 
 template <typename T, int NV>
 static int launch_ln_reduce(float* h, const float* slab, int nslab, const float* bias, const float* w, const float* b,
-                            const float* w2, const float* b2, T* y, int M, int D, hipStream_t s) {
+                            const float* w2, const float* b2, T* y, int M, int D, int32_t* bump, hipStream_t s) {
   const bool wide = (D % 256 == 0) && D <= 4096;
   dim3 grid(M), block(wide ? D / 4 : 64);
   const bool two = w2 != nullptr;
 #define ITTS_LNR(NS, L2)                                                                                                   \
   do {                                                                                                                     \
-    if (wide) hipLaunchKernelGGL((ln_reduce_wide_kernel<T, NS, L2>), grid, block, 0, s, h, slab, bias, w, b, w2, b2, y, M, D); \
-    else hipLaunchKernelGGL((ln_reduce_kernel<T, NV, NS, L2>), grid, block, 0, s, h, slab, bias, w, b, w2, b2, y, M, D);     \
+    if (wide) hipLaunchKernelGGL((ln_reduce_wide_kernel<T, NS, L2>), grid, block, 0, s, h, slab, bias, w, b, w2, b2, y, M, D, bump); \
+    else hipLaunchKernelGGL((ln_reduce_kernel<T, NV, NS, L2>), grid, block, 0, s, h, slab, bias, w, b, w2, b2, y, M, D, bump);     \
   } while (0)
   if (nslab == 0) {
     if (two) ITTS_LNR(0, true); else ITTS_LNR(0, false);
@@ -469,7 +473,8 @@ extern "C" int itts_layernorm(const float* h, const float* w, const float* b, co
 }
 
 extern "C" int itts_ln_reduce(float* h, const float* slab, int nslab, const float* bias, const float* w, const float* b,
-                              const float* w2, const float* b2, void* y, int M, int D, int dtype, void* stream) {
+                              const float* w2, const float* b2, void* y, int M, int D, int dtype, int32_t* state_bump,
+                              void* stream) {
   ITTS_REQUIRE(h && w && b && y, "itts_ln_reduce: null pointer");
   ITTS_REQUIRE(nslab >= 0 && (nslab == 0 || slab != nullptr), "itts_ln_reduce: slab missing");
   ITTS_REQUIRE((w2 == nullptr) == (b2 == nullptr), "itts_ln_reduce: pass both or neither of w2/b2");
@@ -480,11 +485,11 @@ extern "C" int itts_ln_reduce(float* h, const float* slab, int nslab, const floa
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
     case ITTS_F32:
-      return launch_ln_reduce<float, 5>(h, slab, nslab, bias, w, b, w2, b2, (float*)y, M, D, s);
+      return launch_ln_reduce<float, 5>(h, slab, nslab, bias, w, b, w2, b2, (float*)y, M, D, state_bump, s);
     case ITTS_BF16:
-      return launch_ln_reduce<bf16_t, 5>(h, slab, nslab, bias, w, b, w2, b2, (bf16_t*)y, M, D, s);
+      return launch_ln_reduce<bf16_t, 5>(h, slab, nslab, bias, w, b, w2, b2, (bf16_t*)y, M, D, state_bump, s);
     case ITTS_F16:
-      return launch_ln_reduce<f16_t, 5>(h, slab, nslab, bias, w, b, w2, b2, (f16_t*)y, M, D, s);
+      return launch_ln_reduce<f16_t, 5>(h, slab, nslab, bias, w, b, w2, b2, (f16_t*)y, M, D, state_bump, s);
   }
   ITTS_REQUIRE(false, "itts_ln_reduce: unknown dtype %d", dtype);
 }

@@ -11,14 +11,15 @@
 //
 // With split-K > 1 each slice stores its partial tile into its own fp32 slab [ks][M][N].  The slabs are then summed, in a
 // fixed order, either by the next launch (itts_ln_reduce), or -- "reducer tail", tail_h != NULL -- inside this launch: a
-// workgroup that has stored its slab takes an arrival ticket; the LAST M arrivals wait until all tickets are drawn and
-// then each turns one row into  h[row] += bias + slabs,  y[row] = LayerNorm(h[row])  with the arithmetic of
-// itts_ln_reduce (csrc/ln_math.h), so the consumer GEMM finds its normalised input ready at the kernel boundary and a
-// transformer block needs 5 launches instead of 7.  Hand-off rules (CDNA inter-workgroup visibility): slab tiles are
-// stored write-through (sc1), every storing wave drains (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, ONE lane
-// draws the ticket with an agent-scope atomic; a reducer's lane 0 polls the counter with sc1 loads, the workgroup meets
-// at a barrier, and every slab byte is read with an sc1 load (never served from this CU's L1).  Only M workgroups ever
-// wait and the others exit at once, so the wait cannot starve a workgroup that has not been dispatched yet.
+// workgroup that has stored its slab signals (one add into a sharded arrival counter); workgroups 0..M-1 then wait until
+// every workgroup of the launch has signalled and each turns one row into  h[row] += bias + slabs,
+// y[row] = LayerNorm(h[row])  with the arithmetic of itts_ln_reduce (csrc/ln_math.h), so the consumer GEMM finds its
+// normalised input ready at the kernel boundary and a transformer block needs 5 launches instead of 7.  Hand-off rules
+// (CDNA inter-workgroup visibility): slab tiles are stored write-through (sc1), every storing wave drains (s_waitcnt
+// vmcnt(0)), the workgroup meets at a barrier, ONE lane signals with an agent-scope atomic; a reducer's first wave polls
+// the shards with sc1 loads, the workgroup meets at a barrier, and every slab byte is read with an sc1 load (never served
+// from this CU's L1).  Only M workgroups ever wait and the others exit at once, so the wait cannot starve a workgroup
+// that has not been dispatched yet (grids stay within one round of the CUs anyway).
 // Replaces the per-step Conv1D/Linear (+ residual + LayerNorm) calls of HF GPT2Block as driven by
 // indextts/gpt/model.py:163-193.
 #include "common.h"
@@ -26,9 +27,6 @@
 
 #ifndef ITTS_NT_WEIGHTS
 #define ITTS_NT_WEIGHTS 0   // build-time A/B: non-temporal policy for the once-read weight blocks (measured neutral)
-#endif
-#ifndef ITTS_STAMPS
-#define ITTS_STAMPS 0       // diagnostic build only (make stamps): s_memtime stamps per workgroup, see tools/timeline_skinny.py
 #endif
 
 namespace itts {
@@ -72,16 +70,8 @@ struct SkinnyParams {
 
 #if ITTS_STAMPS
 unsigned long long* g_stamp_buf = nullptr;
-#define ITTS_STAMP(i)                                                                                  \
-  do {                                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                                 \
-    if (p.stamps != nullptr && threadIdx.x == 0) {                                                     \
-      unsigned long long t_;                                                                           \
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                        \
-      st_[i] = t_;                                                                                     \
-    }                                                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                                 \
-  } while (0)
+unsigned long long* g_stamp_buf_sample = nullptr;
+#define ITTS_STAMP(i) ITTS_STAMP_IF(p.stamps != nullptr, i)
 #define ITTS_STAMP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #else
 #define ITTS_STAMP(i) do { } while (0)
@@ -120,20 +110,35 @@ __device__ __forceinline__ f32x4 load4f(const float* src, int nval) {
 }
 
 // Reducer tail: row `row` of  h += bias + slabs ; y = LN(h)  (then LN2 when t_w2 != NULL) -- itts_ln_reduce's arithmetic.
+// Two halves: the operands no other workgroup of this launch writes (residual row, bias, LayerNorm parameters) are
+// requested BEFORE the reducer polls for its launch's signals; the slab rows are read after.
+struct TailOps {
+  f32x4 v, lw, lb, lw2, lb2, bs;
+};
+
+__device__ __forceinline__ TailOps tail_issue(const SkinnyParams& p, int row) {
+  const int tid = threadIdx.x, D = p.N;
+  const int o = (tid * 4 < D) ? tid * 4 : 0;
+  const bool two = p.t_w2 != nullptr;
+  TailOps t;
+  t.v = ld16<f32x4>(p.t_h + (int64_t)row * D + o);
+  t.lw = ld16<f32x4>(p.t_w + o);
+  t.lb = ld16<f32x4>(p.t_b + o);
+  t.lw2 = ld16<f32x4>((two ? p.t_w2 : p.t_w) + o);
+  t.lb2 = ld16<f32x4>((two ? p.t_b2 : p.t_b) + o);
+  t.bs = ld16<f32x4>((p.t_bias != nullptr ? p.t_bias : p.t_w) + o);
+  return t;
+}
+
 template <typename T>
-__device__ __forceinline__ void tail_reduce_row(const SkinnyParams& p, float* lds, int row) {
+__device__ __forceinline__ void tail_finish(const SkinnyParams& p, float* lds, int row, const TailOps& t) {
   const int tid = threadIdx.x, nw = blockDim.x >> 6;
   const int D = p.N;
   const bool act = tid * 4 < D;
   const int o = act ? tid * 4 : 0;
   float* hr = p.t_h + (int64_t)row * D;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  // every load is issued before the first use: one round trip
-  f32x4 v = ld16<f32x4>(hr + o);
-  const f32x4 lw = ld16<f32x4>(p.t_w + o), lb = ld16<f32x4>(p.t_b + o);
-  const bool two = p.t_w2 != nullptr;
-  const f32x4 lw2 = ld16<f32x4>((two ? p.t_w2 : p.t_w) + o), lb2 = ld16<f32x4>((two ? p.t_b2 : p.t_b) + o);
-  const f32x4 bs = ld16<f32x4>((p.t_bias != nullptr ? p.t_bias : p.t_w) + o);
+  f32x4 v = t.v;
   f32x4 sl[4];
   {
     // sc1 loads: the slab bytes were stored write-through by other CUs during THIS launch; they must not come from L1
@@ -145,14 +150,14 @@ __device__ __forceinline__ void tail_reduce_row(const SkinnyParams& p, float* ld
       sl[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
     }
   }
-  if (p.t_bias != nullptr) v += bs;
+  if (p.t_bias != nullptr) v += t.bs;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
     if (i < p.ksplit) v += sl[i];   // same association order as itts_ln_reduce
   if (act) st16(hr + o, v);
   else v = zero;
-  if (two) wide_layernorm<true>(v, lw, lb, lw2, lb2, lds, tid, nw, D, act);
-  else wide_layernorm<false>(v, lw, lb, lw2, lb2, lds, tid, nw, D, act);
+  if (p.t_w2 != nullptr) wide_layernorm<true>(v, t.lw, t.lb, t.lw2, t.lb2, lds, tid, nw, D, act);
+  else wide_layernorm<false>(v, t.lw, t.lb, t.lw2, t.lb2, lds, tid, nw, D, act);
   if (act) store_row4<T>((T*)p.t_y + (int64_t)row * D + o, v);
 }
 
@@ -325,22 +330,29 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its write-through stores ...
     __syncthreads();                                   // ... before the one lane that signals for all of them
     ITTS_STAMP(6);
-    unsigned* slot = reinterpret_cast<unsigned*>(red);
-    const unsigned total = gridDim.x * gridDim.y;
-    const unsigned base_cnt = (epoch_pre - 1u) * total;   // tickets of this launch are base_cnt .. base_cnt + total - 1
-    if (tid == 0) slot[0] = __hip_atomic_fetch_add(p.t_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const unsigned rel = slot[0] - base_cnt;
+    // Signal: one fire-and-forget agent-scope add into one of 8 counter shards (240 returning adds on ONE word serialise
+    // at ~12 ns each at the memory side: 1.5 us median per workgroup, measured).  Reducers are STATIC: workgroup r < M owns
+    // row r, so nobody needs the value the add returns, and a reducer can request its row's other operands before it polls.
+    const unsigned total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    if (tid == 0) (void)__hip_atomic_fetch_add(p.t_counter + (lin & 7u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ITTS_STAMP(7);
-    if (rel + (unsigned)p.M >= total && rel < total) {    // one of the last M arrivals: reducer of row rel - (total - M)
-      const int row = (int)(rel - (total - (unsigned)p.M));
-      __syncthreads();                                    // slot[0] has been read by everyone; LDS is reused below
-      if (tid == 0) {
+    if (lin < (unsigned)p.M) {
+      const TailOps ops = tail_issue(p, (int)lin);   // requested now, consumed after the wait
+      __builtin_amdgcn_sched_barrier(0);
+      if (wave == 0) {
+        // lanes 0-7 each watch one shard: it must reach epoch * (workgroups of this launch that signal into it)
+        const unsigned sh = lane & 7u;
+        const unsigned want = epoch_pre * (total / 8u + (sh < (total & 7u) ? 1u : 0u));
         int spins = 0;
-        while (__hip_atomic_load(p.t_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base_cnt < total) {
+        for (;;) {
+          const unsigned got = __hip_atomic_load(p.t_counter + sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__all((int)(got - want) >= 0)) {
+            if (__any((int)(got - want) > 0) && lane == 0) atomicExch(p.t_err, 2);   // counter / epoch out of step
+            break;
+          }
           __builtin_amdgcn_s_sleep(1);
           if (++spins > TAIL_SPIN_LIMIT) {
-            atomicExch(p.t_err, 1);   // sticky: the host checks it at its next synchronisation and raises
+            if (lane == 0) atomicExch(p.t_err, 1);   // sticky: the host checks it at its next synchronisation and raises
             break;
           }
         }
@@ -349,10 +361,8 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
       }
       __syncthreads();
       ITTS_STAMP(8);
-      tail_reduce_row<T>(p, red, row);
+      tail_finish<T>(p, red, (int)lin, ops);
       ITTS_STAMP(9);
-    } else if (rel >= total && tid == 0) {
-      atomicExch(p.t_err, 2);   // counter / epoch out of step (a launch of this site was lost): results are invalid
     }
   }
 #if ITTS_STAMPS
@@ -553,6 +563,17 @@ extern "C" int itts_debug_set(int key, int value) {
 extern "C" int itts_debug_stamps(void* buf) {
 #if ITTS_STAMPS
   itts::g_stamp_buf = (unsigned long long*)buf;
+  return ITTS_OK;
+#else
+  (void)buf;
+  return ITTS_ERR_INVALID;
+#endif
+}
+
+// the same for itts_sample: 16 x u64 per batch row (see tools/timeline_sample.py for the stamp positions)
+extern "C" int itts_debug_stamps_sample(void* buf) {
+#if ITTS_STAMPS
+  itts::g_stamp_buf_sample = (unsigned long long*)buf;
   return ITTS_OK;
 #else
   (void)buf;

@@ -25,6 +25,10 @@ struct SampleParams {
   uint32_t seed_lo, seed_hi;
   int stop_token;
   float* dbg_scores;
+  int advance;
+#if ITTS_STAMPS
+  unsigned long long* stamps;
+#endif
 };
 
 __device__ __forceinline__ uint32_t fkey(float f) {
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
   __shared__ int hist[256];
   __shared__ float cs[SM_MAXC];
   __shared__ int ci[SM_MAXC];
-  __shared__ float ss[SM_MAXC];
+  __shared__ __attribute__((aligned(16))) float ss[SM_MAXC];
   __shared__ int si[SM_MAXC];
   __shared__ float rv[4];
   __shared__ int ri[4];
@@ -66,6 +70,17 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
   const int k = p.state[0];
   const int V = p.V;
   const float* lg = p.logits + (int64_t)b * p.ldl;
+#if ITTS_STAMPS
+  unsigned long long st_[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) st_[i] = 0;
+  unsigned long long* const sbuf_ = p.stamps;
+  if (sbuf_ != nullptr && threadIdx.x == 0) st_[14] = __builtin_amdgcn_s_memrealtime();
+#define SSTAMP(i) ITTS_STAMP_IF(sbuf_ != nullptr, i)
+#else
+#define SSTAMP(i) do { } while (0)
+#endif
+  SSTAMP(0);
   const bool forced = p.finished[b] != 0 || (p.force_stop != nullptr && p.force_stop[b] >= 0 && p.force_stop[b] <= k);
 
   // the row's logits are requested first (registers): their latency overlaps the bitmap construction
@@ -91,18 +106,30 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
     }
   }
   __syncthreads();
+  SSTAMP(1);
   const float inv_t = (p.do_sample && p.temperature != 1.0f) ? 1.0f / p.temperature : 1.0f;
+  {
+    // all bitmap words first (independent LDS reads in flight together), then the arithmetic
+    uint32_t fw[SM_MAXV / 256];
 #pragma unroll
-  for (int i = 0; i < SM_MAXV / 256; ++i) {
-    int idx = tid + i * 256;
-    if (idx < V) {
-      float v = lv[i];
-      if ((flag[idx >> 5] >> (idx & 31)) & 1u) v = v < 0.f ? v * p.rep_penalty : v / p.rep_penalty;
-      if (inv_t != 1.0f) v = v / p.temperature;
-      sv[idx] = v;
+    for (int i = 0; i < SM_MAXV / 256; ++i) {
+      int idx = tid + i * 256;
+      fw[i] = idx < V ? flag[idx >> 5] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < SM_MAXV / 256; ++i) {
+      int idx = tid + i * 256;
+      if (idx < V) {
+        float v = lv[i];
+        if ((fw[i] >> (idx & 31)) & 1u) v = v < 0.f ? v * p.rep_penalty : v / p.rep_penalty;
+        if (inv_t != 1.0f) v = v / p.temperature;
+        lv[i] = v;
+        sv[idx] = v;
+      }
     }
   }
   __syncthreads();
+  SSTAMP(2);
 
   if (!p.do_sample) {
     // ---- greedy: argmax, lowest id on ties
@@ -138,7 +165,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
 #pragma unroll
     for (int i = 0; i < SM_MAXV / 256; ++i) {
       int idx = tid + i * 256;
-      keys[i] = idx < V ? fkey(sv[idx]) : 0u;  // key 0 is below every real float key
+      keys[i] = idx < V ? fkey(lv[i]) : 0u;  // key 0 is below every real float key
       kmax = max(kmax, keys[i]);
     }
     // ---- top-k threshold.  Fast path (k <= 256): the k-th largest of the 256 per-thread maxima is a LOWER bound of the
@@ -152,9 +179,11 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
       tmax[tid] = kmax;
       __syncthreads();
       int rank = 0;
-      for (int j = 0; j < 256; ++j) {
-        uint32_t o = tmax[j];
-        rank += (o > kmax || (o == kmax && j < tid)) ? 1 : 0;
+#pragma unroll 8
+      for (int j4 = 0; j4 < 64; ++j4) {   // broadcast 16-byte reads, eight in flight
+        const u32x4 o4 = *reinterpret_cast<const u32x4*>(tmax + j4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rank += (o4[e] > kmax || (o4[e] == kmax && j4 * 4 + e < tid)) ? 1 : 0;
       }
       if (rank == kk - 1) sh_prefix = kmax;
       __syncthreads();
@@ -186,14 +215,17 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
     __syncthreads();
     if (tid == 0) sh_prefix = thr;
     __syncthreads();
+    SSTAMP(3);
     const uint32_t kth = sh_prefix;  // key of the k-th largest score; ties with it are kept (HF: scores < kth removed)
-    for (int i = tid; i < V; i += 256) {
-      if (fkey(sv[i]) >= kth) {
+#pragma unroll
+    for (int i = 0; i < SM_MAXV / 256; ++i) {   // the keys are still in registers: only the hits touch LDS
+      if (keys[i] >= kth && tid + i * 256 < V) {
         int slot = atomicAdd(&sh_n, 1);
-        if (slot < SM_MAXC) { cs[slot] = sv[i]; ci[slot] = i; }
+        if (slot < SM_MAXC) { cs[slot] = lv[i]; ci[slot] = tid + i * 256; }
       }
     }
     __syncthreads();
+    SSTAMP(4);
     const int n = min(sh_n, SM_MAXC);
     // ---- rank sort: descending score, ascending id
     for (int i = tid; i < n; i += 256) {
@@ -219,6 +251,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
       }
       __syncthreads();
     }
+    SSTAMP(5);
     const int n2 = min(sh_n, SM_MAXC);
     // softmax numerators relative to the maximum, one per thread (cs is reused for them); the Philox draw is computed by
     // another wave meanwhile; lane 0 then only runs the order-sensitive fp32 running sums
@@ -230,31 +263,60 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
       rv[0] = (float)(x >> 8) * (1.0f / 16777216.0f);
     }
     __syncthreads();
-    if (tid == 0) {
-      const int n = n2;
-      float total = 0.f;
-      for (int i = n - 1; i >= 0; --i) total += cs[i];
-      int keep = n;
-      if (p.top_p < 1.0f) {
-        // HF TopPLogitsWarper: ascending cumulative probability <= 1 - top_p is removed, at least one token kept
-        float cum = 0.f;
-        const float lim = 1.0f - p.top_p;
-        for (int i = n - 1; i >= 1; --i) {
-          cum += cs[i] / total;
-          if (cum <= lim) keep = i; else break;
-        }
-      }
-      sh_keep = keep;
+    if (wave == 0) {
+      const int n = __builtin_amdgcn_readfirstlane(n2);
       const float u = rv[0];
-      float tot2 = 0.f;
-      for (int i = 0; i < keep; ++i) tot2 += cs[i];
-      float dthr = u * tot2, run = 0.f;
-      int pick = si[keep - 1];
-      for (int i = 0; i < keep; ++i) {
-        run += cs[i];
-        if (run > dthr) { pick = si[i]; break; }
+      const float lim = 1.0f - p.top_p;
+      if (n <= 64) {
+        // the order-sensitive fp32 running sums of the reference, with the numerators in registers (lane i holds
+        // candidate i) and v_readlane instead of one dependent LDS read per term; every lane computes the same scalars
+        const int e_bits = __float_as_int(lane < n ? cs[lane] : 0.f);
+        const int id = lane < n ? si[lane] : 0;
+        auto term = [&](int i) { return __int_as_float(__builtin_amdgcn_readlane(e_bits, i)); };
+        float total = 0.f;
+        for (int i = n - 1; i >= 0; --i) total += term(i);
+        int keep = n;
+        if (p.top_p < 1.0f) {
+          // HF TopPLogitsWarper: ascending cumulative probability <= 1 - top_p is removed, at least one token kept
+          float cum = 0.f;
+          for (int i = n - 1; i >= 1; --i) {
+            cum += term(i) / total;
+            if (cum <= lim) keep = i; else break;
+          }
+        }
+        float tot2 = 0.f;
+        for (int i = 0; i < keep; ++i) tot2 += term(i);
+        const float dthr = u * tot2;
+        float run = 0.f;
+        int pick_i = keep - 1;
+        for (int i = 0; i < keep; ++i) {
+          run += term(i);
+          if (run > dthr) { pick_i = i; break; }
+        }
+        const int pick = __builtin_amdgcn_readlane(id, pick_i);
+        if (lane == 0) { sh_keep = keep; sh_tok = pick; }
+      } else if (lane == 0) {
+        float total = 0.f;
+        for (int i = n - 1; i >= 0; --i) total += cs[i];
+        int keep = n;
+        if (p.top_p < 1.0f) {
+          float cum = 0.f;
+          for (int i = n - 1; i >= 1; --i) {
+            cum += cs[i] / total;
+            if (cum <= lim) keep = i; else break;
+          }
+        }
+        sh_keep = keep;
+        float tot2 = 0.f;
+        for (int i = 0; i < keep; ++i) tot2 += cs[i];
+        float dthr = u * tot2, run = 0.f;
+        int pick = si[keep - 1];
+        for (int i = 0; i < keep; ++i) {
+          run += cs[i];
+          if (run > dthr) { pick = si[i]; break; }
+        }
+        sh_tok = pick;
       }
-      sh_tok = pick;
     }
     __syncthreads();
     if (p.dbg_scores) {
@@ -264,6 +326,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
     }
   }
 
+  SSTAMP(6);
   // ---- bookkeeping
   if (tid == 0) {
     int tok = forced ? p.stop_token : sh_tok;
@@ -273,14 +336,26 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
       p.finished[b] = 1;
       atomicAdd(&p.state[2], 1);
     }
-    __threadfence();
-    int done = atomicAdd(&p.state[3], 1);
-    if (done == p.B - 1) {  // last row of this launch: every workgroup has already read state[0]
-      p.state[3] = 0;
-      p.state[0] = k + 1;
-      p.state[1] = p.state[1] + 1;
+    if (p.advance) {
+      // legacy protocol (advance != 0): the last row of the launch advances the loop state after every workgroup has read
+      // state[0] -- one device-wide fence and one returning atomic per row
+      __threadfence();
+      int done = atomicAdd(&p.state[3], 1);
+      if (done == p.B - 1) {
+        p.state[3] = 0;
+        p.state[0] = k + 1;
+        p.state[1] = p.state[1] + 1;
+      }
     }
   }
+#if ITTS_STAMPS
+  SSTAMP(7);
+  if (sbuf_ != nullptr && threadIdx.x == 0) {
+    st_[15] = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sbuf_[(size_t)blockIdx.x * 16 + i] = st_[i];
+  }
+#endif
 }
 
 }  // namespace itts
@@ -317,6 +392,10 @@ extern "C" int itts_sample(const itts_sample_args* a, void* stream) {
   p.seed_hi = (uint32_t)(a->seed >> 32);
   p.stop_token = a->stop_token;
   p.dbg_scores = a->dbg_scores;
+  p.advance = a->no_advance ? 0 : 1;
+#if ITTS_STAMPS
+  p.stamps = itts::g_stamp_buf_sample;
+#endif
   hipLaunchKernelGGL(sample_kernel, dim3(a->B), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("itts_sample");
 }

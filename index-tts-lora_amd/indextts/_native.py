@@ -48,7 +48,8 @@ class SampleArgs(C.Structure):
                 ("history", C.c_void_p), ("hist_cap", C.c_int), ("finished", C.c_void_p), ("state", C.c_void_p),
                 ("extra_ids", C.c_void_p), ("n_extra", C.c_int), ("force_stop", C.c_void_p),
                 ("rep_penalty", C.c_float), ("temperature", C.c_float), ("top_p", C.c_float), ("top_k", C.c_int),
-                ("do_sample", C.c_int), ("seed", C.c_uint64), ("stop_token", C.c_int), ("dbg_scores", C.c_void_p)]
+                ("do_sample", C.c_int), ("seed", C.c_uint64), ("stop_token", C.c_int), ("dbg_scores", C.c_void_p),
+                ("no_advance", C.c_int)]
 
 
 class BeamArgs(C.Structure):
@@ -74,7 +75,7 @@ _SIGNATURES = {
     "itts_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_ln_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                 C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                                 C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "itts_embed_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                   C.c_int, C.c_void_p, C.c_void_p]),
     "itts_attn_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -237,11 +238,12 @@ def layernorm(h, w, b, out, w2=None, b2=None):
     return out
 
 
-def ln_reduce(h, w, b, out, slab=None, nslab=0, bias=None, w2=None, b2=None):
-    """h fp32 [M,D] (updated in place when nslab > 0) -> out T [M,D] = LN(h + bias + sum(slabs))."""
+def ln_reduce(h, w, b, out, slab=None, nslab=0, bias=None, w2=None, b2=None, state_bump=None):
+    """h fp32 [M,D] (updated in place when nslab > 0) -> out T [M,D] = LN(h + bias + sum(slabs)).
+    state_bump: int32[2] device words incremented once by the launch (decode loop: step counter and cache position)."""
     M, D = h.shape
     _check(lib().itts_ln_reduce(_p(h), _p(slab), nslab, _p(bias), _p(w), _p(b), _p(w2), _p(b2), _p(out), M, D,
-                                dt(out.dtype), _stream()), "itts_ln_reduce")
+                                dt(out.dtype), _p(state_bump), _stream()), "itts_ln_reduce")
     return out
 
 
@@ -269,7 +271,7 @@ def attn_prefill_packed(qkv, out, kcache, vcache, row_off, cache_shift, B, Smax,
 
 
 def sample(logits, tokens, history, finished, state, extra_ids, force_stop, rep_penalty, temperature, top_k, top_p,
-           do_sample, seed, stop_token, dbg_scores=None):
+           do_sample, seed, stop_token, dbg_scores=None, no_advance=False):
     a = SampleArgs()
     B, V = logits.shape
     a.logits, a.B, a.V, a.ldl = _p(logits), B, V, logits.stride(0)
@@ -280,6 +282,7 @@ def sample(logits, tokens, history, finished, state, extra_ids, force_stop, rep_
     a.rep_penalty, a.temperature, a.top_p = float(rep_penalty), float(temperature), float(top_p)
     a.top_k, a.do_sample, a.seed, a.stop_token = int(top_k), int(bool(do_sample)), int(seed), int(stop_token)
     a.dbg_scores = _p(dbg_scores)
+    a.no_advance = int(bool(no_advance))
     _check(lib().itts_sample(C.byref(a), _stream()), "itts_sample")
 
 

@@ -37,13 +37,15 @@ class GPTEngine:
             return nat.pack_weight(w_kn.detach().to(dev, dtype).contiguous())
 
         # Decode-step structure:
-        #   "tail"   (default): the split-K out-projection / FC2 launches end with a reducer tail -- the last M arriving
-        #            workgroups fold the slabs into the residual stream and write LayerNorm(row) for the next GEMM --
-        #            5 launches per block (QKV, attention, out-proj+LN2, FC, FC2+LN1')
-        #   "launch": every [residual-reduce + LayerNorm] is a launch of its own -- 7 launches per block.  Same bits.
-        # Forms measured in round 1 and removed (profiles/README.md): LayerNorm inside the consumer GEMM's prologue (+3 % /
-        # +16 % per token), LN rows produced by extra workgroups of the CONSUMER's launch (+10 %).
-        self.decode_mode = os.environ.get("ITTS_DECODE_MODE", "tail")
+        #   "launch" (default): every [residual-reduce + LayerNorm] is a launch of its own -- 7 launches per block
+        #   "tail":  the split-K out-projection / FC2 launches end with a reducer tail -- workgroups 0..M-1 wait for the
+        #            launch's arrival signals, fold the slabs into the residual stream and write LayerNorm(row) for the next
+        #            GEMM -- 5 launches per block.  Same bits as "launch" (tests/test_kernels_gpu.py).
+        # Measured on MI355X (B=32, bf16, profiles/README.md round 2): launch 1.09 ms/token, tail 1.18 ms: the in-launch
+        # hand-off (store drain, signal, poll, slab read-back: ~5.4 us on the split-K launches) costs more than the
+        # ~3.5 us the removed launch took.  Forms removed in round 1: LayerNorm in the consumer GEMM's prologue, LN rows
+        # produced by extra workgroups of the CONSUMER's launch.
+        self.decode_mode = os.environ.get("ITTS_DECODE_MODE", "launch")
         if self.decode_mode not in ("tail", "launch"):
             raise ValueError("ITTS_DECODE_MODE must be 'tail' or 'launch'")
         self.tail_acquire = int(os.environ.get("ITTS_TAIL_ACQUIRE", "0"))
@@ -80,7 +82,7 @@ class GPTEngine:
         # arrival counters of the reducer tails: one per split-K launch site (2 per block), monotonic, never reset by the
         # kernels; state[6] is the epoch the sites expect (advanced by embed_step once per decode step), state[7] the
         # sticky error word of the tails
-        self.tail_cnt = torch.zeros((2 * layers + 3) // 4 * 4, dtype=torch.int32, device=dev)
+        self.tail_cnt = torch.zeros(2 * layers, 8, dtype=torch.int32, device=dev)   # 8 shards per site
         self.weight_bytes = sum(t.numel() * t.element_size() for l in self.layers for t in
                                 (l["w_qkv"], l["w_o"], l["w_fc"], l["w_pr"])) + self.w_head.numel()
 
@@ -187,6 +189,7 @@ class GPTEngine:
         self.state.zero_()                 # step, cache position, finished rows, ..., tail epoch [6], tail error [7]
         self.tail_cnt.zero_()              # the reducer tails count from (epoch - 1) * workgroups: both restart together
         self.state[1] = S - 1
+        self._pending_bump = False
         self.finished[:B] = 0
         self.history[:B].zero_()
         self._B, self._S = B, S
@@ -222,19 +225,25 @@ class GPTEngine:
 
     # ------------------------------------------------------------------------------------------------ decode loop
     def _sample(self, B, sp, dbg=None):
+        """Token selection for all rows.  The loop state (step counter, cache position) is NOT advanced here: the next
+        transformer step does it in its first LayerNorm launch (a launch that reads neither word), which takes a
+        device-wide fence and a returning atomic per row out of the sampling kernel."""
         nat.sample(self.logits[:B], self.tokens, self.history, self.finished, self.state, self.extra_ids, self.force_stop,
                    sp["repetition_penalty"], sp["temperature"], sp["top_k"], sp["top_p"], sp["do_sample"], sp["seed"],
-                   self.stop_mel, dbg)
+                   self.stop_mel, dbg, no_advance=True)
+        self._pending_bump = True
 
     def _tail(self, site, h, xn, bias, ln, ln2=None):
-        t = dict(h=h, y=xn, bias=bias, w=ln[0], b=ln[1], counter=self.tail_cnt[site: site + 1], epoch=self.state[6:7],
+        t = dict(h=h, y=xn, bias=bias, w=ln[0], b=ln[1], counter=self.tail_cnt[site], epoch=self.state[6:7],
                  err=self.state[7:8], acquire=self.tail_acquire)
         if ln2 is not None:
             t.update(w2=ln2[0], b2=ln2[1])
         return t
 
-    def _step_transformer(self, B):
-        """Transformer part of one cached decode step (model.py:163-193): embed token k at mel position k+1, 24 blocks,
+    def _step_transformer(self, B, bump=None):
+        """(bump: advance step counter / cache position in this step's first LayerNorm launch; None = "a _sample call is
+        waiting for it", which is what the token loop wants; the beam step kernel advances the state itself.)
+        Transformer part of one cached decode step (model.py:163-193): embed token k at mel position k+1, 24 blocks,
         head.  "tail" form, 5 launches per block: QKV (+K/V append) -> attention -> out-proj (split-K slabs; tail: residual
         update + LN2) -> FC + gelu -> FC2 (split-K slabs; tail: residual update + the NEXT block's LN1, or ln_f∘final_norm).
         "launch" form, 7 per block: the two tails are itts_ln_reduce launches instead (same arithmetic, same bits)."""
@@ -243,8 +252,12 @@ class GPTEngine:
         h, xn = self.h[:B], self.xn[:B]
         slab = self.slab.view(-1)[: KS * B * D].view(KS, B, D)  # [ks][B][D] on a contiguous prefix of the buffer
         tail = self.decode_mode == "tail" and B <= self.max_rows_per_launch
-        nat.embed_step(self.tokens, self.mel_emb, self.mel_pos, step, 1, h, epoch=self.state[6:7])
-        nat.ln_reduce(h, self.layers[0]["ln1"][0], self.layers[0]["ln1"][1], xn)
+        if bump is None:
+            bump = getattr(self, "_pending_bump", False)
+        self._pending_bump = False
+        # mel position of token k is k + 1 (model.py:163-167); with a pending bump state[0] still holds k - 1
+        nat.embed_step(self.tokens, self.mel_emb, self.mel_pos, step, 2 if bump else 1, h, epoch=self.state[6:7])
+        nat.ln_reduce(h, self.layers[0]["ln1"][0], self.layers[0]["ln1"][1], xn, state_bump=self.state[0:2] if bump else None)
         for i, l in enumerate(self.layers):
             nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv"], l["b_qkv"], x=xn, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
                             vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s)
@@ -369,6 +382,7 @@ class GPTEngine:
 
     def _beam_select(self, B, nb, sp):
         R = B * nb
+        self._pending_bump = False   # the beam step kernel advances step counter and cache position itself
         nat.beam_step(self.logits[:R], nb, self.tokens, self.b_src, self.b_scores, self.b_hist, self.b_hyp_score, self.b_hyp_len,
                       self.b_hyp_tok, self.b_n_hyp, self.b_worst, self.b_done, self.state, self.extra_ids,
                       sp["repetition_penalty"], sp["temperature"], sp["top_k"], sp["top_p"], sp["do_sample"],
