@@ -79,6 +79,15 @@ int itts_aa_snake_fwd(const void* x, void* y, const float* alpha_log, const floa
                       const float* down_filter12, int B, int T, int C, int dtype, int layout, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Packed activation layout of the decode step (optional, per operand).  A T-typed activation matrix X[M][K] that a skinny
+ * GEMM consumes can be stored in MFMA-fragment order, 1 KiB per (k-step, 16-row tile):
+ *     element (m, k) at  ((k / KS * MTP + m / 16) * 64 + (k % KS) / E * 16 + m % 16) * E + k % E,   MTP = ceil(M / 16),
+ *     KS = 32, E = 8 (bf16/f16) or KS = 16, E = 4 (f32); the buffer holds K/KS * MTP KiB (rows up to 16*MTP exist).
+ * The GEMM then reads a fragment as one contiguous 1-KiB wave-load instead of 16 rows x 64 bytes.  Producers that can
+ * write it: itts_ln_reduce (y_packed), itts_attn_decode (out_packed), itts_gemm_skinny (y_packed, tail_y_packed).
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Skinny GEMM for the decode step: Y[M][N] = epi( X[M][K] @ W[K][N] + bias ), up to 96 rows (bf16/f16; 16 in fp32) per
  * pass over the weights (larger M is processed in row chunks by the entry point).  1-3 16-column tiles (x one K slice)
  * per workgroup, the K range split over the workgroup's waves and reduced deterministically through LDS; every global
@@ -130,6 +139,9 @@ typedef struct itts_skinny_args {
   const int32_t* tail_epoch;
   int32_t* tail_err;
   int tail_acquire;
+  /* Packed-activation layout (see "Packed activation layout" above): x_packed -- x is packed [K/KS][ceil(M/16)][64][E];
+   * y_packed -- y (ITTS_EPI_STORE / ITTS_EPI_GELU_STORE, N % KS == 0) is written packed; tail_y_packed -- the tail's y. */
+  int x_packed, y_packed, tail_y_packed;
 } itts_skinny_args;
 int itts_gemm_skinny(const itts_skinny_args* a, void* stream);
 /* launch geometry itts_gemm_skinny would use: out6 = {grid.x, grid.y, waves per workgroup, column tiles per workgroup,
@@ -174,10 +186,12 @@ int itts_layernorm(const float* h, const float* w, const float* b, const float* 
  *   if (nslab > 0)  h[m][:] += bias[:] + slab[0][m][:] + ... + slab[nslab-1][m][:]      (fixed order; h updated in place)
  *   y[m][:] = LN(h[m][:]; w, b)   (then LN(.; w2, b2) if w2 != NULL),  y is T [M][D].
  * slab is fp32 [nslab][M][D] as written by itts_gemm_skinny(ITTS_EPI_SLAB_F32).
+ * y_packed != 0 (needs D % 256 == 0): y is written in the packed activation layout.
  * state_bump (int32[2] device words or NULL): both words are incremented once by this launch -- the decode loop's step
  * counter and cache position, advanced here (a launch that reads neither) instead of by the sampling kernel. */
 int itts_ln_reduce(float* h, const float* slab, int nslab, const float* bias, const float* w, const float* b,
-                   const float* w2, const float* b2, void* y, int M, int D, int dtype, int32_t* state_bump, void* stream);
+                   const float* w2, const float* b2, void* y, int M, int D, int dtype, int y_packed, int32_t* state_bump,
+                   void* stream);
 
 /* h[b][:] = table[tokens[b]][:] + pos_table[*step + pos_add][:]   (fp32 tables, fp32 h).  If epoch != NULL, *epoch is
  * incremented once (the first launch of a decode step advances the epoch of that step's reducer tails). */
@@ -185,9 +199,10 @@ int itts_embed_step(const int32_t* tokens, const float* table, const float* pos_
                     float* h, int B, int D, int32_t* epoch, void* stream);
 
 /* Single-query attention over the KV cache (decode).  q,out: T [B][H*64]; caches T [B][H][smax][64];
- * keys j in [pad[b], *pos] are visible (the key at *pos was just appended).  scale 1/8. */
+ * keys j in [pad[b], *pos] are visible (the key at *pos was just appended).  scale 1/8.  out_packed != 0: out is written in
+ * the packed activation layout (M = B, K = H*64). */
 int itts_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, const int32_t* pad,
-                     const int32_t* pos, int B, int H, int smax, int dtype, void* stream);
+                     const int32_t* pos, int B, int H, int smax, int dtype, int out_packed, void* stream);
 
 /* Causal self-attention over a whole (left-padded) sequence.  qkv: T [B][S][3*H*64] (q|k|v); out: T [B][S][H*64];
  * query i sees key j iff pad[b] <= j <= i; rows with no visible key produce zeros.  If kcache/vcache are non-NULL the

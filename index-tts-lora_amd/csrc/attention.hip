@@ -31,7 +31,7 @@ template <typename T, int NWV>
 __global__ __launch_bounds__(NWV * 64) void attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ kc,
                                                            const T* __restrict__ vc, T* __restrict__ out,
                                                            const int32_t* __restrict__ pad, const int32_t* __restrict__ pos,
-                                                           int H, int smax) {
+                                                           int H, int smax, int out_mtp) {
   typedef Elem<T> EL;
   typedef typename EL::frag frag;
   constexpr int E = EL::E;
@@ -128,7 +128,9 @@ __global__ __launch_bounds__(NWV * 64) void attn_decode_kernel(const T* __restri
       L += w_l[w] * sw;
       acc += w_o[w][tid] * sw;
     }
-    out[((int64_t)b * H + h) * HD + tid] = EL::from_f(L > 0.f ? acc / L : 0.f);
+    // out_mtp > 0: packed-activation layout (the out-projection GEMM's operand), else row-major [B][H*64]
+    const int64_t o = out_mtp > 0 ? pa_off<T>(b, h * HD + tid, out_mtp) : ((int64_t)b * H + h) * HD + tid;
+    out[o] = EL::from_f(L > 0.f ? acc / L : 0.f);
   }
 }
 
@@ -293,7 +295,8 @@ namespace itts { constexpr int g_attn_waves = 4; }  // measured equal to 8; the 
 #endif
 
 extern "C" int itts_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, const int32_t* pad,
-                                const int32_t* pos, int B, int H, int smax, int dtype, void* stream) {
+                                const int32_t* pos, int B, int H, int smax, int dtype, int out_packed, void* stream) {
+  const int out_mtp = out_packed ? (B + 15) / 16 : 0;
   ITTS_REQUIRE(q && kcache && vcache && out && pad && pos, "itts_attn_decode: null pointer");
   ITTS_REQUIRE(B > 0 && H > 0 && smax > 0 && smax <= AD_MAXCTX, "itts_attn_decode: bad shape B=%d H=%d smax=%d (max %d)", B, H,
                smax, AD_MAXCTX);
@@ -302,13 +305,13 @@ extern "C" int itts_attn_decode(const void* q, const void* kcache, const void* v
   if (g_attn_waves == 8) {
     switch (dtype) {
       case ITTS_F32:
-        hipLaunchKernelGGL((attn_decode_kernel<float, 8>), grid, block, 0, s, (const float*)q, (const float*)kcache, (const float*)vcache, (float*)out, pad, pos, H, smax);
+        hipLaunchKernelGGL((attn_decode_kernel<float, 8>), grid, block, 0, s, (const float*)q, (const float*)kcache, (const float*)vcache, (float*)out, pad, pos, H, smax, out_mtp);
         break;
       case ITTS_BF16:
-        hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 8>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)kcache, (const bf16_t*)vcache, (bf16_t*)out, pad, pos, H, smax);
+        hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 8>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)kcache, (const bf16_t*)vcache, (bf16_t*)out, pad, pos, H, smax, out_mtp);
         break;
       case ITTS_F16:
-        hipLaunchKernelGGL((attn_decode_kernel<f16_t, 8>), grid, block, 0, s, (const f16_t*)q, (const f16_t*)kcache, (const f16_t*)vcache, (f16_t*)out, pad, pos, H, smax);
+        hipLaunchKernelGGL((attn_decode_kernel<f16_t, 8>), grid, block, 0, s, (const f16_t*)q, (const f16_t*)kcache, (const f16_t*)vcache, (f16_t*)out, pad, pos, H, smax, out_mtp);
         break;
       default:
         ITTS_REQUIRE(false, "itts_attn_decode: unknown dtype %d", dtype);
@@ -317,13 +320,13 @@ extern "C" int itts_attn_decode(const void* q, const void* kcache, const void* v
   }
   switch (dtype) {
     case ITTS_F32:
-      hipLaunchKernelGGL((attn_decode_kernel<float, 4>), grid, block, 0, s, (const float*)q, (const float*)kcache, (const float*)vcache, (float*)out, pad, pos, H, smax);
+      hipLaunchKernelGGL((attn_decode_kernel<float, 4>), grid, block, 0, s, (const float*)q, (const float*)kcache, (const float*)vcache, (float*)out, pad, pos, H, smax, out_mtp);
       break;
     case ITTS_BF16:
-      hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 4>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)kcache, (const bf16_t*)vcache, (bf16_t*)out, pad, pos, H, smax);
+      hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 4>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)kcache, (const bf16_t*)vcache, (bf16_t*)out, pad, pos, H, smax, out_mtp);
       break;
     case ITTS_F16:
-      hipLaunchKernelGGL((attn_decode_kernel<f16_t, 4>), grid, block, 0, s, (const f16_t*)q, (const f16_t*)kcache, (const f16_t*)vcache, (f16_t*)out, pad, pos, H, smax);
+      hipLaunchKernelGGL((attn_decode_kernel<f16_t, 4>), grid, block, 0, s, (const f16_t*)q, (const f16_t*)kcache, (const f16_t*)vcache, (f16_t*)out, pad, pos, H, smax, out_mtp);
       break;
     default:
       ITTS_REQUIRE(false, "itts_attn_decode: unknown dtype %d", dtype);

@@ -128,6 +128,17 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Packed activation layout ("PA") of the decode step: X[M][K] of T stored as MFMA operand fragments, 1 KiB per (k-step,
+// 16-row tile), so that the skinny GEMM reads an activation fragment as ONE contiguous 1-KiB wave-load (8 cache lines)
+// instead of 16 rows x 64 bytes (16 half-used lines): the activations, re-read by every workgroup, are two thirds of a
+// CU's load traffic in these GEMMs.   element (m, k) -> ((k / KS * MTP + m / 16) * 64 + (k % KS) / E * 16 + m % 16) * E
+// + k % E,   MTP = ceil(M / 16) row tiles; rows up to 16 * MTP exist (padding rows are never stored by consumers).
+template <typename T>
+__device__ __forceinline__ int64_t pa_off(int m, int k, int mtp) {
+  constexpr int E = Elem<T>::E, KS = Elem<T>::KS;
+  return ((((int64_t)(k / KS) * mtp + (m >> 4)) * 64 + ((k % KS) / E) * 16 + (m & 15)) * E) + (k % E);
+}
+
 // transformers NewGELUActivation (gelu_new): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
 __device__ __forceinline__ float gelu_new(float x) {
   const float k = 0.7978845608028654f;

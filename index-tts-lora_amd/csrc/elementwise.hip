@@ -296,7 +296,7 @@ __global__ __launch_bounds__(1024) void ln_reduce_wide_kernel(float* __restrict_
                                                               const float* __restrict__ bias, const float* __restrict__ w,
                                                               const float* __restrict__ b, const float* __restrict__ w2,
                                                               const float* __restrict__ b2, T* __restrict__ y, int M, int D,
-                                                              int32_t* __restrict__ bump) {
+                                                              int32_t* __restrict__ bump, int y_pa) {
   __shared__ float red[2][2][16];
   const int row = blockIdx.x, tid = threadIdx.x, nw = blockDim.x >> 6;
   if (bump != nullptr && row == 0 && tid == 0) { bump[0] += 1; bump[1] += 1; }   // nobody in this launch reads them
@@ -320,18 +320,22 @@ __global__ __launch_bounds__(1024) void ln_reduce_wide_kernel(float* __restrict_
     st16(hr + tid * 4, v);
   }
   wide_layernorm<LN2>(v, lw, lb, lw2, lb2, &red[0][0][0], tid, nw, D, true);
-  store_row4<T>(y + (int64_t)row * D + tid * 4, v);
+  store_row4<T>(y + (y_pa ? pa_off<T>(row, tid * 4, (M + 15) >> 4) : (int64_t)row * D + tid * 4), v);
 }
 
 template <typename T, int NV>
 static int launch_ln_reduce(float* h, const float* slab, int nslab, const float* bias, const float* w, const float* b,
-                            const float* w2, const float* b2, T* y, int M, int D, int32_t* bump, hipStream_t s) {
+                            const float* w2, const float* b2, T* y, int M, int D, int32_t* bump, int y_pa, hipStream_t s) {
   const bool wide = (D % 256 == 0) && D <= 4096;
+  if (y_pa && !wide) {
+    set_error("itts_ln_reduce: a packed y needs D %% 256 == 0 (D=%d)", D);
+    return ITTS_ERR_INVALID;
+  }
   dim3 grid(M), block(wide ? D / 4 : 64);
   const bool two = w2 != nullptr;
 #define ITTS_LNR(NS, L2)                                                                                                   \
   do {                                                                                                                     \
-    if (wide) hipLaunchKernelGGL((ln_reduce_wide_kernel<T, NS, L2>), grid, block, 0, s, h, slab, bias, w, b, w2, b2, y, M, D, bump); \
+    if (wide) hipLaunchKernelGGL((ln_reduce_wide_kernel<T, NS, L2>), grid, block, 0, s, h, slab, bias, w, b, w2, b2, y, M, D, bump, y_pa); \
     else hipLaunchKernelGGL((ln_reduce_kernel<T, NV, NS, L2>), grid, block, 0, s, h, slab, bias, w, b, w2, b2, y, M, D, bump);     \
   } while (0)
   if (nslab == 0) {
@@ -473,8 +477,8 @@ extern "C" int itts_layernorm(const float* h, const float* w, const float* b, co
 }
 
 extern "C" int itts_ln_reduce(float* h, const float* slab, int nslab, const float* bias, const float* w, const float* b,
-                              const float* w2, const float* b2, void* y, int M, int D, int dtype, int32_t* state_bump,
-                              void* stream) {
+                              const float* w2, const float* b2, void* y, int M, int D, int dtype, int y_packed,
+                              int32_t* state_bump, void* stream) {
   ITTS_REQUIRE(h && w && b && y, "itts_ln_reduce: null pointer");
   ITTS_REQUIRE(nslab >= 0 && (nslab == 0 || slab != nullptr), "itts_ln_reduce: slab missing");
   ITTS_REQUIRE((w2 == nullptr) == (b2 == nullptr), "itts_ln_reduce: pass both or neither of w2/b2");
@@ -485,11 +489,11 @@ extern "C" int itts_ln_reduce(float* h, const float* slab, int nslab, const floa
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
     case ITTS_F32:
-      return launch_ln_reduce<float, 5>(h, slab, nslab, bias, w, b, w2, b2, (float*)y, M, D, state_bump, s);
+      return launch_ln_reduce<float, 5>(h, slab, nslab, bias, w, b, w2, b2, (float*)y, M, D, state_bump, y_packed, s);
     case ITTS_BF16:
-      return launch_ln_reduce<bf16_t, 5>(h, slab, nslab, bias, w, b, w2, b2, (bf16_t*)y, M, D, state_bump, s);
+      return launch_ln_reduce<bf16_t, 5>(h, slab, nslab, bias, w, b, w2, b2, (bf16_t*)y, M, D, state_bump, y_packed, s);
     case ITTS_F16:
-      return launch_ln_reduce<f16_t, 5>(h, slab, nslab, bias, w, b, w2, b2, (f16_t*)y, M, D, state_bump, s);
+      return launch_ln_reduce<f16_t, 5>(h, slab, nslab, bias, w, b, w2, b2, (f16_t*)y, M, D, state_bump, y_packed, s);
   }
   ITTS_REQUIRE(false, "itts_ln_reduce: unknown dtype %d", dtype);
 }

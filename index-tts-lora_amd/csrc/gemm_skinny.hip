@@ -63,6 +63,8 @@ struct SkinnyParams {
   const int32_t* t_epoch;
   int32_t* t_err;
   int t_acquire;
+  int x_pa, y_pa, t_y_pa;  // packed-activation layout for x / y (STORE, GELU_STORE) / the tail's y
+  int mtp, row0;           // row tiles of the WHOLE operand, first row of this launch (a multiple of 16)
 #if ITTS_STAMPS
   unsigned long long* stamps;
 #endif
@@ -158,7 +160,7 @@ __device__ __forceinline__ void tail_finish(const SkinnyParams& p, float* lds, i
   else v = zero;
   if (p.t_w2 != nullptr) wide_layernorm<true>(v, t.lw, t.lb, t.lw2, t.lb2, lds, tid, nw, D, act);
   else wide_layernorm<false>(v, t.lw, t.lb, t.lw2, t.lb2, lds, tid, nw, D, act);
-  if (act) store_row4<T>((T*)p.t_y + (int64_t)row * D + o, v);
+  if (act) store_row4<T>((T*)p.t_y + (p.t_y_pa ? pa_off<T>(row, o, p.mtp) : (int64_t)row * D + o), v);
 }
 
 // NTB = column tiles per workgroup (grids stay within one round of the 256 CUs: a 257th workgroup costs a full second
@@ -225,7 +227,10 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           int row = mt * 16 + r;
-          af[i][mt] = (s < s_end && row < p.M) ? ld16<frag>(X + (int64_t)row * p.K + s * KS + g * E) : zero_frag<frag>();
+          if (p.x_pa)   // one contiguous 1-KiB block per (k-step, row tile); padding rows exist and are never stored
+            af[i][mt] = (s < s_end) ? ld16<frag>(X + (((int64_t)s * p.mtp + (p.row0 >> 4) + mt) * 64 + lane) * E) : zero_frag<frag>();
+          else
+            af[i][mt] = (s < s_end && row < p.M) ? ld16<frag>(X + (int64_t)row * p.K + s * KS + g * E) : zero_frag<frag>();
         }
       }
       ITTS_STAMP(1);
@@ -251,7 +256,10 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
 #pragma unroll
         for (int i = 0; i < SPW; ++i) {
           int s = base + i;
-          af[i] = (s < s_end && row < p.M) ? ld16<frag>(X + (int64_t)row * p.K + s * KS + g * E) : zero_frag<frag>();
+          if (p.x_pa)
+            af[i] = (s < s_end) ? ld16<frag>(X + (((int64_t)s * p.mtp + (p.row0 >> 4) + mt) * 64 + lane) * E) : zero_frag<frag>();
+          else
+            af[i] = (s < s_end && row < p.M) ? ld16<frag>(X + (int64_t)row * p.K + s * KS + g * E) : zero_frag<frag>();
         }
 #pragma unroll
         for (int i = 0; i < SPW; ++i)
@@ -285,11 +293,11 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
     v += bs;
     switch (p.epi) {
       case ITTS_EPI_STORE:
-        store4<T>((T*)p.y + (int64_t)row * p.N + col0, v, nval);
+        store4<T>((T*)p.y + (p.y_pa ? pa_off<T>(p.row0 + row, col0, p.mtp) : (int64_t)row * p.N + col0), v, nval);
         break;
       case ITTS_EPI_GELU_STORE: {
         f32x4 gv = {gelu_new(v[0]), gelu_new(v[1]), gelu_new(v[2]), gelu_new(v[3])};
-        store4<T>((T*)p.y + (int64_t)row * p.N + col0, gv, nval);
+        store4<T>((T*)p.y + (p.y_pa ? pa_off<T>(p.row0 + row, col0, p.mtp) : (int64_t)row * p.N + col0), gv, nval);
       } break;
       case ITTS_EPI_RESID_F32: {
         float* dst = p.yf + (int64_t)row * p.N + col0;
@@ -485,6 +493,10 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
     ITTS_REQUIRE(a->tail_w && a->tail_b && a->tail_y && a->tail_counter && a->tail_epoch && a->tail_err &&
                      (a->tail_w2 == nullptr) == (a->tail_b2 == nullptr) && a->M <= rows_per,
                  "itts_gemm_skinny: bad reducer-tail arguments (needs M <= %d rows in one launch)", rows_per);
+  if (a->y_packed)
+    ITTS_REQUIRE((a->epi == ITTS_EPI_STORE || a->epi == ITTS_EPI_GELU_STORE) && a->N % ks == 0,
+                 "itts_gemm_skinny: a packed y needs the STORE / GELU_STORE epilogue and N %% %d == 0", ks);
+  if (a->tail_y_packed) ITTS_REQUIRE(a->tail_h && a->N % ks == 0, "itts_gemm_skinny: packed tail_y needs a tail and N %% %d == 0", ks);
   if (a->M == 0) return ITTS_OK;
   hipStream_t s = (hipStream_t)stream;
   for (int r0 = 0; r0 < a->M; r0 += rows_per) {
@@ -494,10 +506,15 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
     p.K = a->K;
     p.wp = a->wp;
     p.bias = a->bias;
-    p.x = (const char*)a->x + (size_t)r0 * a->K * esz;
+    p.x = a->x_packed ? (const char*)a->x : (const char*)a->x + (size_t)r0 * a->K * esz;
+    p.x_pa = a->x_packed ? 1 : 0;
+    p.y_pa = a->y_packed ? 1 : 0;
+    p.t_y_pa = a->tail_y_packed ? 1 : 0;
+    p.mtp = (a->M + 15) / 16;
+    p.row0 = r0;
     p.epi = a->epi;
     const size_t ycols = a->epi == ITTS_EPI_QKV_CACHE ? (size_t)a->N / 3 : (size_t)a->N;
-    p.y = a->y ? (char*)a->y + (size_t)r0 * ycols * esz : nullptr;
+    p.y = a->y ? (a->y_packed ? (char*)a->y : (char*)a->y + (size_t)r0 * ycols * esz) : nullptr;
     p.yf = a->yf ? a->yf + (size_t)r0 * a->N : nullptr;
     const size_t crow = (size_t)a->heads * a->smax * 64 * esz;
     p.kcache = a->kcache ? (char*)a->kcache + (size_t)r0 * crow : nullptr;

@@ -31,7 +31,7 @@ class SkinnyArgs(C.Structure):
                 ("smax", C.c_int), ("ksplit", C.c_int), ("tail_h", C.c_void_p), ("tail_bias", C.c_void_p),
                 ("tail_w", C.c_void_p), ("tail_b", C.c_void_p), ("tail_w2", C.c_void_p), ("tail_b2", C.c_void_p),
                 ("tail_y", C.c_void_p), ("tail_counter", C.c_void_p), ("tail_epoch", C.c_void_p), ("tail_err", C.c_void_p),
-                ("tail_acquire", C.c_int)]
+                ("tail_acquire", C.c_int), ("x_packed", C.c_int), ("y_packed", C.c_int), ("tail_y_packed", C.c_int)]
 
 
 class ConvArgs(C.Structure):
@@ -75,11 +75,11 @@ _SIGNATURES = {
     "itts_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_ln_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                 C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+                                 C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "itts_embed_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                   C.c_int, C.c_void_p, C.c_void_p]),
     "itts_attn_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                   C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_attn_prefill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_attn_prefill_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -189,7 +189,7 @@ def aa_snake(x, alpha_log, beta_log, up_f, down_f, layout=0, out=None):
 
 
 def gemm_skinny(dtype, M, N, K, wp, bias=None, x=None, epi=EPI_STORE, y=None, yf=None, kcache=None, vcache=None, pos=None,
-                heads=0, smax=0, ksplit=1, tail=None):
+                heads=0, smax=0, ksplit=1, tail=None, x_packed=False, y_packed=False):
     """tail = dict(h, w, b, y, counter, epoch, err[, bias, w2, b2, acquire]): reducer tail of a split-K launch --
     h += bias + slabs, y = LN(h) computed by the last M arriving workgroups of the same launch (see itts_skinny_args)."""
     a = SkinnyArgs()
@@ -198,11 +198,39 @@ def gemm_skinny(dtype, M, N, K, wp, bias=None, x=None, epi=EPI_STORE, y=None, yf
         a.tail_bias, a.tail_w2, a.tail_b2 = _p(tail.get("bias")), _p(tail.get("w2")), _p(tail.get("b2"))
         a.tail_counter, a.tail_epoch, a.tail_err = _p(tail["counter"]), _p(tail["epoch"]), _p(tail["err"])
         a.tail_acquire = int(tail.get("acquire", 0))
+        a.tail_y_packed = int(bool(tail.get("y_packed", False)))
     a.dtype, a.M, a.N, a.K = dt(dtype), M, N, K
     a.wp, a.bias, a.x = _p(wp), _p(bias), _p(x)
     a.epi, a.y, a.yf = epi, _p(y), _p(yf)
     a.kcache, a.vcache, a.pos, a.heads, a.smax, a.ksplit = _p(kcache), _p(vcache), _p(pos), heads, smax, ksplit
+    a.x_packed, a.y_packed = int(bool(x_packed)), int(bool(y_packed))
     _check(lib().itts_gemm_skinny(C.byref(a), _stream()), "itts_gemm_skinny")
+
+
+def packed_rows(M: int) -> int:
+    """Rows a packed-activation buffer must provide for M logical rows (16-row tiles)."""
+    return (M + 15) // 16 * 16
+
+
+def pack_activation(x: torch.Tensor) -> torch.Tensor:
+    """Row-major [M, K] -> the packed activation layout (include/indextts_hip.h), as a flat tensor of packed_rows(M)*K
+    elements.  Host-side torch restatement for tests and tools; the kernels write this layout themselves."""
+    M, K = x.shape
+    E = 4 if x.dtype == torch.float32 else 8
+    KS = 4 * E
+    mtp = (M + 15) // 16
+    xp = torch.zeros(mtp * 16, K, dtype=x.dtype, device=x.device)
+    xp[:M] = x
+    v = xp.view(mtp, 16, K // KS, 4, E).permute(2, 0, 3, 1, 4).contiguous()   # [ks][mt][g][c][e]
+    return v.view(-1)
+
+
+def unpack_activation(xp: torch.Tensor, M: int, K: int) -> torch.Tensor:
+    E = 4 if xp.dtype == torch.float32 else 8
+    KS = 4 * E
+    mtp = (M + 15) // 16
+    v = xp.view(K // KS, mtp, 4, 16, E).permute(1, 3, 0, 2, 4).contiguous().view(mtp * 16, K)
+    return v[:M]
 
 
 def skinny_plan(dtype, M, N, K, ksplit=1) -> dict:
@@ -238,12 +266,12 @@ def layernorm(h, w, b, out, w2=None, b2=None):
     return out
 
 
-def ln_reduce(h, w, b, out, slab=None, nslab=0, bias=None, w2=None, b2=None, state_bump=None):
+def ln_reduce(h, w, b, out, slab=None, nslab=0, bias=None, w2=None, b2=None, state_bump=None, y_packed=False):
     """h fp32 [M,D] (updated in place when nslab > 0) -> out T [M,D] = LN(h + bias + sum(slabs)).
     state_bump: int32[2] device words incremented once by the launch (decode loop: step counter and cache position)."""
     M, D = h.shape
     _check(lib().itts_ln_reduce(_p(h), _p(slab), nslab, _p(bias), _p(w), _p(b), _p(w2), _p(b2), _p(out), M, D,
-                                dt(out.dtype), _p(state_bump), _stream()), "itts_ln_reduce")
+                                dt(out.dtype), int(bool(y_packed)), _p(state_bump), _stream()), "itts_ln_reduce")
     return out
 
 
@@ -254,9 +282,9 @@ def embed_step(tokens, table, pos_table, step, pos_add, h, epoch=None):
            "itts_embed_step")
 
 
-def attn_decode(q, kcache, vcache, out, pad, pos, B, H, smax):
+def attn_decode(q, kcache, vcache, out, pad, pos, B, H, smax, out_packed=False):
     _check(lib().itts_attn_decode(_p(q), _p(kcache), _p(vcache), _p(out), _p(pad), _p(pos), B, H, smax, dt(q.dtype),
-                                  _stream()), "itts_attn_decode")
+                                  int(bool(out_packed)), _stream()), "itts_attn_decode")
 
 
 def attn_prefill(qkv, out, kcache, vcache, pad, B, S, H, smax):

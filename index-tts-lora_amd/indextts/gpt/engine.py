@@ -49,6 +49,9 @@ class GPTEngine:
         if self.decode_mode not in ("tail", "launch"):
             raise ValueError("ITTS_DECODE_MODE must be 'tail' or 'launch'")
         self.tail_acquire = int(os.environ.get("ITTS_TAIL_ACQUIRE", "0"))
+        # T-typed activations of the decode step (xn, attention output, MLP hidden) live in the packed fragment layout
+        # (include/indextts_hip.h): the GEMMs read them as contiguous 1-KiB blocks.  ITTS_PACKED_ACT=0: row-major (same bits).
+        self.pa = os.environ.get("ITTS_PACKED_ACT", "1") == "1"
         self.max_rows_per_launch = 16 if dtype == torch.float32 else 96   # rows one skinny-GEMM launch covers
 
         self.layers = []
@@ -111,10 +114,11 @@ class GPTEngine:
         self.kc = torch.zeros(self.L, B, self.H, smax, 64, dtype=T, device=dev)
         self.vc = torch.zeros(self.L, B, self.H, smax, 64, dtype=T, device=dev)
         self.h = torch.zeros(B, self.D, dtype=torch.float32, device=dev)
+        Bp = nat.packed_rows(B)   # the packed layout works in 16-row tiles
         self.q = torch.zeros(B, self.D, dtype=T, device=dev)
-        self.a = torch.zeros(B, self.D, dtype=T, device=dev)
-        self.f = torch.zeros(B, 4 * self.D, dtype=T, device=dev)
-        self.xn = torch.zeros(B, self.D, dtype=T, device=dev)
+        self.a = torch.zeros(Bp, self.D, dtype=T, device=dev)
+        self.f = torch.zeros(Bp, 4 * self.D, dtype=T, device=dev)
+        self.xn = torch.zeros(Bp, self.D, dtype=T, device=dev)
         self.slab = torch.zeros(self.KSPLIT, B, self.D, dtype=torch.float32, device=dev)
         self.logits = torch.zeros(B, self.V, dtype=torch.float32, device=dev)
         self.tokens = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -152,15 +156,11 @@ class GPTEngine:
             nat.gemm_conv(T, 1, M, M, 4 * D, D, l["w_pr"], ff, h, bias=l["b_pr"], y_f32=True, resid=h)
         return h
 
-    def _head(self, h_rows, B, pending=None):
-        """ln_f -> final_norm -> mel_head on fp32 rows.  `pending` = (slab, nslab, bias): a residual update still to apply."""
-        if pending is None:
-            nat.ln_reduce(h_rows, self.ln_f[0], self.ln_f[1], self.xn[:B], w2=self.final_norm[0], b2=self.final_norm[1])
-        else:
-            nat.ln_reduce(h_rows, self.ln_f[0], self.ln_f[1], self.xn[:B], slab=pending[0], nslab=pending[1], bias=pending[2],
-                          w2=self.final_norm[0], b2=self.final_norm[1])
+    def _head(self, h_rows, B):
+        """ln_f -> final_norm -> mel_head on fp32 rows."""
+        nat.ln_reduce(h_rows, self.ln_f[0], self.ln_f[1], self.xn, w2=self.final_norm[0], b2=self.final_norm[1], y_packed=self.pa)
         nat.gemm_skinny(self.dtype, B, self.V, self.D, self.w_head, self.b_head, x=self.xn, epi=nat.EPI_STORE_F32,
-                        yf=self.logits)
+                        yf=self.logits, x_packed=self.pa)
 
     def prefill(self, prefix_emb: torch.Tensor, pad: torch.Tensor, max_new: int):
         """prefix_emb fp32 [B,P,D] (left-padded with zeros), pad int [B].  Runs prefix + start token (mel position 0,
@@ -235,7 +235,7 @@ class GPTEngine:
 
     def _tail(self, site, h, xn, bias, ln, ln2=None):
         t = dict(h=h, y=xn, bias=bias, w=ln[0], b=ln[1], counter=self.tail_cnt[site], epoch=self.state[6:7],
-                 err=self.state[7:8], acquire=self.tail_acquire)
+                 err=self.state[7:8], acquire=self.tail_acquire, y_packed=self.pa)
         if ln2 is not None:
             t.update(w2=ln2[0], b2=ln2[1])
         return t
@@ -249,7 +249,7 @@ class GPTEngine:
         "launch" form, 7 per block: the two tails are itts_ln_reduce launches instead (same arithmetic, same bits)."""
         T, D, H, KS = self.dtype, self.D, self.H, self.KSPLIT
         step, pos = self.state[0:1], self.state[1:2]
-        h, xn = self.h[:B], self.xn[:B]
+        h, xn, pa = self.h[:B], self.xn, self.pa   # xn / a / f: whole buffers (packed layout is addressed from the base)
         slab = self.slab.view(-1)[: KS * B * D].view(KS, B, D)  # [ks][B][D] on a contiguous prefix of the buffer
         tail = self.decode_mode == "tail" and B <= self.max_rows_per_launch
         if bump is None:
@@ -257,30 +257,31 @@ class GPTEngine:
         self._pending_bump = False
         # mel position of token k is k + 1 (model.py:163-167); with a pending bump state[0] still holds k - 1
         nat.embed_step(self.tokens, self.mel_emb, self.mel_pos, step, 2 if bump else 1, h, epoch=self.state[6:7])
-        nat.ln_reduce(h, self.layers[0]["ln1"][0], self.layers[0]["ln1"][1], xn, state_bump=self.state[0:2] if bump else None)
+        nat.ln_reduce(h, self.layers[0]["ln1"][0], self.layers[0]["ln1"][1], xn, state_bump=self.state[0:2] if bump else None,
+                      y_packed=pa)
         for i, l in enumerate(self.layers):
             nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv"], l["b_qkv"], x=xn, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
-                            vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s)
-            nat.attn_decode(self.q, self.kc[i], self.vc[i], self.a, self.pad, pos, B, H, self._cap_s)
+                            vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s, x_packed=pa)
+            nat.attn_decode(self.q, self.kc[i], self.vc[i], self.a, self.pad, pos, B, H, self._cap_s, out_packed=pa)
             last = i + 1 == self.L
             nxt = self.ln_f if last else self.layers[i + 1]["ln1"]
             nxt2 = self.final_norm if last else None
             if tail:
-                nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS,
+                nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS, x_packed=pa,
                                 tail=self._tail(2 * i, h, xn, l["b_o"], l["ln2"]))
-                nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f)
-                nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], None, x=self.f, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS,
+                nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f, x_packed=pa, y_packed=pa)
+                nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], None, x=self.f, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS, x_packed=pa,
                                 tail=self._tail(2 * i + 1, h, xn, l["b_pr"], nxt, nxt2))
             else:
-                nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS)
-                nat.ln_reduce(h, l["ln2"][0], l["ln2"][1], xn, slab=slab, nslab=KS, bias=l["b_o"])
-                nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f)
-                nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], None, x=self.f, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS)
+                nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS, x_packed=pa)
+                nat.ln_reduce(h, l["ln2"][0], l["ln2"][1], xn, slab=slab, nslab=KS, bias=l["b_o"], y_packed=pa)
+                nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f, x_packed=pa, y_packed=pa)
+                nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], None, x=self.f, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS, x_packed=pa)
                 if last:
-                    nat.ln_reduce(h, nxt[0], nxt[1], xn, slab=slab, nslab=KS, bias=l["b_pr"], w2=nxt2[0], b2=nxt2[1])
+                    nat.ln_reduce(h, nxt[0], nxt[1], xn, slab=slab, nslab=KS, bias=l["b_pr"], w2=nxt2[0], b2=nxt2[1], y_packed=pa)
                 else:
-                    nat.ln_reduce(h, nxt[0], nxt[1], xn, slab=slab, nslab=KS, bias=l["b_pr"])
-        nat.gemm_skinny(T, B, self.V, D, self.w_head, self.b_head, x=self.xn, epi=nat.EPI_STORE_F32, yf=self.logits)
+                    nat.ln_reduce(h, nxt[0], nxt[1], xn, slab=slab, nslab=KS, bias=l["b_pr"], y_packed=pa)
+        nat.gemm_skinny(T, B, self.V, D, self.w_head, self.b_head, x=self.xn, epi=nat.EPI_STORE_F32, yf=self.logits, x_packed=pa)
 
     def _poll(self):
         """One host synchronisation of the token loop: (finished rows, raises if a reducer tail reported an error)."""
@@ -301,7 +302,7 @@ class GPTEngine:
         once + activations; the tails add the residual rows they read and write)."""
         T, D, H, KS = self.dtype, self.D, self.H, self.KSPLIT
         pos = self.state[1:2]
-        h, xn = self.h[:B], self.xn[:B]
+        h, xn, pa = self.h[:B], self.xn, self.pa
         slab = self.slab.view(-1)[: KS * B * D].view(KS, B, D)
         es = 4 if T == torch.float32 else 2
         tail = self.decode_mode == "tail" and B <= self.max_rows_per_launch
@@ -313,17 +314,17 @@ class GPTEngine:
             nxt = self.ln_f if last else self.layers[i + 1]["ln1"]
             nxt2 = self.final_norm if last else None
             nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv"], l["b_qkv"], x=xn, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
-                            vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s)
-            nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS,
+                            vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s, x_packed=pa)
+            nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS, x_packed=pa,
                             tail=self._tail(2 * i, h, xn, l["b_o"], l["ln2"]) if tail else None)
-            nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f)
-            nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], None, x=self.f, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS,
+            nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f, x_packed=pa, y_packed=pa)
+            nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], None, x=self.f, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS, x_packed=pa,
                             tail=self._tail(2 * i + 1, h, xn, l["b_pr"], nxt, nxt2) if tail else None)
             nbytes += 12 * D * D * es + B * D * es * (1 + 1 + 1 + 4) + B * es * (3 * D + 4 * D) + 2 * KS * B * D * 4
             if tail:
                 nbytes += 2 * (KS * B * D * 4 + 2 * B * D * 4 + B * D * es)   # slabs read back, h read + written, xn written
             n += 4
-        nat.gemm_skinny(T, B, self.V, D, self.w_head, self.b_head, x=self.xn, epi=nat.EPI_STORE_F32, yf=self.logits)
+        nat.gemm_skinny(T, B, self.V, D, self.w_head, self.b_head, x=self.xn, epi=nat.EPI_STORE_F32, yf=self.logits, x_packed=pa)
         nbytes += self.V * D * es + B * D * es + B * self.V * 4
         return n + 1, nbytes
 

@@ -350,3 +350,26 @@ def test_beam_graphs_follow_their_buffers(gpt_small_fp32):
         eng.prefill(emb.repeat_interleave(3, 0), pad.repeat_interleave(3), 12)
         got = eng.decode_beam(12, sp, 3, use_graph=True, check_every=4).cpu()
         assert torch.equal(got, want[B]), B
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_packed_activations_and_tail_mode_give_the_same_bits(dtype):
+    """The decode loop's variants -- packed vs row-major activations, [reduce + LayerNorm] as launches vs as reducer tails
+    of the split-K GEMMs -- are re-arrangements of the same arithmetic: identical logits and codes, step for step."""
+    m = make_gpt(2, dtype)
+    eng = m.engine
+    g = np.load(os.path.join(G, "gpt_small.npz"))
+    cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
+    text = torch.from_numpy(g["text"]).to(DEV)
+    conds = m.get_conditioning(cond_mel, None)
+    _, emb, mask = m.prepare_gpt_inputs(conds, text)
+    pad = (mask == 0).sum(1).to(torch.int32)
+    sp = dict(do_sample=True, top_p=0.8, top_k=30, temperature=1.0, repetition_penalty=10.0, seed=9)
+    outs = []
+    for pa, mode in ((True, "launch"), (False, "launch"), (True, "tail"), (False, "tail")):
+        eng.pa, eng.decode_mode = pa, mode
+        eng._graphs.clear()
+        eng.prefill(emb, pad, 20)
+        outs.append(eng.decode(20, sp, return_logits=True))
+    for codes, logits in outs[1:]:
+        assert torch.equal(codes, outs[0][0]) and torch.equal(logits, outs[0][1])

@@ -482,6 +482,71 @@ def test_gemm_skinny_many_rows_one_weight_pass(nat, dtype, M, N, K):
     assert plan["grid"][0] * plan["grid"][1] <= 256
 
 
+@pytest.mark.parametrize("dtype,M", [(torch.bfloat16, 32), (torch.bfloat16, 13), (torch.bfloat16, 96), (torch.float32, 32), (torch.float16, 40)])
+def test_packed_activation_layout_end_to_end(nat, dtype, M):
+    """The packed activation layout (include/indextts_hip.h) through its producers and its consumer: itts_ln_reduce
+    (y_packed), itts_attn_decode (out_packed), itts_gemm_skinny (x_packed, y_packed with gelu, tail_y_packed) give the SAME
+    BITS as the row-major forms, and the packing matches the documented index formula (nat.pack_activation)."""
+    D, H = 1280, 20
+    # the layout itself: element (m, k) where the header says
+    E = 4 if dtype == torch.float32 else 8
+    KS, mtp = 4 * E, (M + 15) // 16
+    x = rnd(M, D, seed=200).to(dtype)
+    xp = nat.pack_activation(x)
+    assert xp.numel() == mtp * 16 * D
+    for (m, k) in ((0, 0), (M - 1, D - 1), (M // 2, 333), (min(17, M - 1), 64)):
+        off = ((k // KS * mtp + m // 16) * 64 + (k % KS) // E * 16 + m % 16) * E + k % E
+        assert xp[off].item() == x[m, k].item()
+    assert torch.equal(nat.unpack_activation(xp, M, D), x)
+    # LayerNorm producer
+    h = rnd(M, D, seed=201, scale=2.0)
+    lw, lb = 1.0 + 0.1 * rnd(D, seed=202), 0.1 * rnd(D, seed=203)
+    y_rm = torch.empty(M, D, dtype=dtype, device=DEV)
+    y_pk = torch.zeros(mtp * 16 * D, dtype=dtype, device=DEV)
+    nat.ln_reduce(h.clone(), lw, lb, y_rm)
+    nat.ln_reduce(h.clone(), lw, lb, y_pk, y_packed=True)
+    assert torch.equal(nat.unpack_activation(y_pk, M, D), y_rm)
+    # GEMM consumer + gelu producer
+    w = (rnd(D, 4 * D, seed=204) * 0.03).to(dtype)
+    wp = nat.pack_weight(w)
+    bias = rnd(4 * D, seed=205)
+    f_rm = torch.empty(M, 4 * D, dtype=dtype, device=DEV)
+    f_pk = torch.zeros(mtp * 16 * 4 * D, dtype=dtype, device=DEV)
+    nat.gemm_skinny(dtype, M, 4 * D, D, wp, bias, x=y_rm, epi=nat.EPI_GELU_STORE, y=f_rm)
+    nat.gemm_skinny(dtype, M, 4 * D, D, wp, bias, x=y_pk, epi=nat.EPI_GELU_STORE, y=f_pk, x_packed=True, y_packed=True)
+    assert torch.equal(nat.unpack_activation(f_pk, M, 4 * D), f_rm)
+    # split-K slabs from a packed operand, and the reducer tail writing a packed y
+    w2 = (rnd(4 * D, D, seed=206) * 0.03).to(dtype)
+    wp2 = nat.pack_weight(w2)
+    KSP = 3
+    slab_rm, slab_pk = torch.zeros(KSP, M, D, device=DEV), torch.zeros(KSP, M, D, device=DEV)
+    nat.gemm_skinny(dtype, M, D, 4 * D, wp2, None, x=f_rm, epi=nat.EPI_SLAB_F32, yf=slab_rm, ksplit=KSP)
+    nat.gemm_skinny(dtype, M, D, 4 * D, wp2, None, x=f_pk, epi=nat.EPI_SLAB_F32, yf=slab_pk, ksplit=KSP, x_packed=True)
+    assert torch.equal(slab_pk, slab_rm)
+    if M <= (16 if dtype == torch.float32 else 96):
+        h_ref, xn_ref = h.clone(), torch.empty(M, D, dtype=dtype, device=DEV)
+        nat.ln_reduce(h_ref, lw, lb, xn_ref, slab=slab_rm, nslab=KSP, bias=bias[:D].contiguous())
+        cnt, st = torch.zeros(8, dtype=torch.int32, device=DEV), torch.zeros(8, dtype=torch.int32, device=DEV)
+        st[6] = 1
+        h_t, xn_t = h.clone(), torch.zeros(mtp * 16 * D, dtype=dtype, device=DEV)
+        nat.gemm_skinny(dtype, M, D, 4 * D, wp2, None, x=f_pk, epi=nat.EPI_SLAB_F32, yf=slab_pk, ksplit=KSP, x_packed=True,
+                        tail=dict(h=h_t, y=xn_t, bias=bias[:D].contiguous(), w=lw, b=lb, counter=cnt, epoch=st[6:7], err=st[7:8], y_packed=True))
+        torch.cuda.synchronize()
+        assert st[7].item() == 0 and torch.equal(h_t, h_ref) and torch.equal(nat.unpack_activation(xn_t, M, D), xn_ref)
+    # decode attention producer
+    smax, ctx = 64, 41
+    q = rnd(M, D, seed=207).to(dtype)
+    kc, vc = rnd(M, H, smax, 64, seed=208).to(dtype), rnd(M, H, smax, 64, seed=209).to(dtype)
+    pad = torch.zeros(M, dtype=torch.int32, device=DEV)
+    pad[M // 2] = 7
+    pos = torch.tensor([ctx - 1], dtype=torch.int32, device=DEV)
+    a_rm = torch.empty(M, D, dtype=dtype, device=DEV)
+    a_pk = torch.zeros(mtp * 16 * D, dtype=dtype, device=DEV)
+    nat.attn_decode(q, kc, vc, a_rm, pad, pos, M, H, smax)
+    nat.attn_decode(q, kc, vc, a_pk, pad, pos, M, H, smax, out_packed=True)
+    assert torch.equal(nat.unpack_activation(a_pk, M, D), a_rm)
+
+
 def test_gemm_skinny_qkv_cache_epilogue_many_rows(nat):
     """QKV epilogue at 96 rows (batch 32 x 3 beams): q rows, and k/v scattered into the cache at *pos, per head."""
     dtype, M, H, smax, pos = torch.bfloat16, 96, 20, 64, 17
