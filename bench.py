@@ -304,6 +304,7 @@ def main():
                          "U{40..400}, text U{8..100}), 32 per GPU sharded longest-first from one global list (256 at 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-beam", action="store_true", help="skip the extra beam-sample (32 x 3 rows) token-time measurement")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight for --schedule concurrent")
     ap.add_argument("--no-concurrency", action="store_true",
                     help="skip the extra (reported, never `value`) measurement with two batch-32 requests in flight")
@@ -559,6 +560,23 @@ def main():
                                                  "overlap; `value` above is one request at a time"}
         pl.close()
         log(f"[bench] {len(pl.instances)} requests in flight: {result['concurrent_requests']['value']} audio-s/s")
+
+    if rank == 0 and world == 1 and args.config == 3 and not args.no_beam:
+        # The reference's DEFAULT generation settings (infer.py:807-814): beam-sample with 3 beams -> 96 rows share each
+        # pass over the weights (skinny GEMM with 6 row tiles) and KV rows follow their beams through a row table.
+        # Reported beside `value` (which stays num_beams = 1, BASELINE config 3): token time of the 32 x 3 loop.
+        genb = dict(gen, num_beams=3, length_penalty=0.0)
+        tts.infer_batch(cond_mel, texts, max_mel_tokens=MEL_TOKENS + 1, seed=77, **genb)   # warm-up + graph capture
+        peb = {}
+        tts.infer_batch(cond_mel, texts, max_mel_tokens=MEL_TOKENS + 1, seed=78, phase_events=peb, **genb)
+        torch.cuda.synchronize()
+        beam_us = 1e3 * peb["prefilled"].elapsed_time(peb["decoded"]) / (MEL_TOKENS + 1)
+        result["beam_sample"] = {"num_beams": 3, "rows": 3 * BATCH, "us_per_token": round(beam_us, 1),
+                                 "ratio_to_num_beams_1": round(beam_us / step_us, 3), "kv": eng.beam_kv,
+                                 "whole_step_ms": round(peb["start"].elapsed_time(peb["vocoded"]), 2),
+                                 "note": "batch 32 x 3 beams, 141 tokens, top-k/top-p beam-sample on device; one weight pass per "
+                                         "token for all 96 rows"}
+        log(f"[bench] beam-sample 32x3: {beam_us:.1f} us/token ({beam_us / step_us:.2f}x the num_beams=1 token)")
 
     if rank == 0 and not args.no_roofline:
         # one more identical step with per-launch HIP events (eager launches instead of graph replay)

@@ -200,9 +200,12 @@ int itts_embed_step(const int32_t* tokens, const float* table, const float* pos_
 
 /* Single-query attention over the KV cache (decode).  q,out: T [B][H*64]; caches T [B][H][smax][64];
  * keys j in [pad[b], *pos] are visible (the key at *pos was just appended).  scale 1/8.  out_packed != 0: out is written in
- * the packed activation layout (M = B, K = H*64). */
+ * the packed activation layout (M = B, K = H*64).
+ * kv_rows / kv_step (both or neither): beam search without cache copies -- position j of logical row b is read from
+ * physical cache row kv_rows[(*kv_step & 1)][b][j] (int32 [2][B][smax], maintained by itts_beam_step). */
 int itts_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, const int32_t* pad,
-                     const int32_t* pos, int B, int H, int smax, int dtype, int out_packed, void* stream);
+                     const int32_t* pos, int B, int H, int smax, int dtype, int out_packed, const int32_t* kv_rows,
+                     const int32_t* kv_step, void* stream);
 
 /* Causal self-attention over a whole (left-padded) sequence.  qkv: T [B][S][3*H*64] (q|k|v); out: T [B][S][H*64];
  * query i sees key j iff pad[b] <= j <= i; rows with no visible key produce zeros.  If kcache/vcache are non-NULL the
@@ -280,7 +283,15 @@ typedef struct itts_beam_args {
 } itts_beam_args;
 int itts_beam_step(const itts_beam_args* a, void* stream);
 
-/* KV cache rows follow their beams (GPT2InferenceModel._reorder_cache, model.py:207-218): row r <- row src[r] for cache
+/* KV rows follow their beams as a TABLE (GPT2InferenceModel._reorder_cache, model.py:207-218, without moving cache bytes):
+ * kv_rows int32 [2][rows][smax], ping-pong by step parity; entry [r][j] = physical cache row that holds position j of
+ * logical row r (rows = B*num_beams).  Call right after itts_beam_step (state[0] = k+1, state[1] = P): table (k+1)&1 is
+ * written from table k&1 -- [r][j] = old[src[r]][j] for j < P, and [r][P] = r (where the next step appends).  Start from
+ * table 0 = identity.  itts_attn_decode reads the table through its kv_rows / kv_step arguments. */
+int itts_beam_kv_rows(int32_t* kv_rows, const int32_t* src, const int32_t* state, int rows, int smax, void* stream);
+
+/* The same by COPYING cache rows (kept as the reference form; the decode loop uses the table):
+ * KV cache rows follow their beams (GPT2InferenceModel._reorder_cache, model.py:207-218): row r <- row src[r] for cache
  * positions [0, state[1]), every layer, K and V; batch elements whose rows map to themselves are skipped.
  * Cache layout [layers][rows][heads][smax][64]; layer_stride in elements. */
 int itts_beam_reorder_kv(void* kcache, void* vcache, const int32_t* src, const int32_t* state, int layers, int B, int num_beams,

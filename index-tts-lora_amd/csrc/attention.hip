@@ -27,11 +27,14 @@ __device__ __forceinline__ void softmax_merge(float& m, float& l, float m2, floa
   m = M;
 }
 
-template <typename T, int NWV>
+// IND: beam search -- key/value position j of logical row b lives in physical cache row kv_rows[parity][b][j] (a table
+// that itts_beam_step permutes instead of copying cache rows); parity = *kv_step & 1.
+template <typename T, int NWV, bool IND>
 __global__ __launch_bounds__(NWV * 64) void attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ kc,
                                                            const T* __restrict__ vc, T* __restrict__ out,
                                                            const int32_t* __restrict__ pad, const int32_t* __restrict__ pos,
-                                                           int H, int smax, int out_mtp) {
+                                                           int H, int smax, int out_mtp, const int32_t* __restrict__ kv_rows,
+                                                           const int32_t* __restrict__ kv_step, int rows_total) {
   typedef Elem<T> EL;
   typedef typename EL::frag frag;
   constexpr int E = EL::E;
@@ -47,6 +50,8 @@ __global__ __launch_bounds__(NWV * 64) void attn_decode_kernel(const T* __restri
   const int ctx = pos[0] + 1;  // keys [j0, ctx)
   const T* kb = kc + ((int64_t)b * H + h) * smax * HD + part * E;
   const T* vb = vc + ((int64_t)b * H + h) * smax * HD + part * E;
+  const int32_t* tab = nullptr;
+  if constexpr (IND) tab = kv_rows + ((int64_t)(kv_step[0] & 1) * rows_total + b) * smax;
 
   float qf[E];
   {
@@ -60,12 +65,22 @@ __global__ __launch_bounds__(NWV * 64) void attn_decode_kernel(const T* __restri
 
   for (int base = j0; base < ctx; base += 4 * RPW * AD_CH) {
     frag kf[CH], vf[CH];
+    int prow[CH];
+    if constexpr (IND) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {   // the rows of this chunk's keys, all requested before the first K/V load
+        int j = base + (i * NWV + wave) * RPW + rg;
+        prow[i] = j < ctx ? tab[j] : b;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       int j = base + (i * NWV + wave) * RPW + rg;
       bool ok = j < ctx;
-      kf[i] = ok ? ld16<frag>(kb + (int64_t)j * HD) : zero_frag<frag>();
-      vf[i] = ok ? ld16<frag>(vb + (int64_t)j * HD) : zero_frag<frag>();
+      int64_t ro = (int64_t)j * HD;
+      if constexpr (IND) ro += (int64_t)(prow[i] - b) * H * smax * HD;   // same head, same position, another row
+      kf[i] = ok ? ld16<frag>(kb + ro) : zero_frag<frag>();
+      vf[i] = ok ? ld16<frag>(vb + ro) : zero_frag<frag>();
     }
     float sc[CH];
     float cmax = -INFINITY;
@@ -295,42 +310,39 @@ namespace itts { constexpr int g_attn_waves = 4; }  // measured equal to 8; the 
 #endif
 
 extern "C" int itts_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, const int32_t* pad,
-                                const int32_t* pos, int B, int H, int smax, int dtype, int out_packed, void* stream) {
+                                const int32_t* pos, int B, int H, int smax, int dtype, int out_packed, const int32_t* kv_rows,
+                                const int32_t* kv_step, void* stream) {
   const int out_mtp = out_packed ? (B + 15) / 16 : 0;
   ITTS_REQUIRE(q && kcache && vcache && out && pad && pos, "itts_attn_decode: null pointer");
   ITTS_REQUIRE(B > 0 && H > 0 && smax > 0 && smax <= AD_MAXCTX, "itts_attn_decode: bad shape B=%d H=%d smax=%d (max %d)", B, H,
                smax, AD_MAXCTX);
+  ITTS_REQUIRE((kv_rows == nullptr) == (kv_step == nullptr), "itts_attn_decode: pass both or neither of kv_rows / kv_step");
   dim3 grid(H, B), block(g_attn_waves * 64);
   hipStream_t s = (hipStream_t)stream;
-  if (g_attn_waves == 8) {
-    switch (dtype) {
-      case ITTS_F32:
-        hipLaunchKernelGGL((attn_decode_kernel<float, 8>), grid, block, 0, s, (const float*)q, (const float*)kcache, (const float*)vcache, (float*)out, pad, pos, H, smax, out_mtp);
-        break;
-      case ITTS_BF16:
-        hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 8>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)kcache, (const bf16_t*)vcache, (bf16_t*)out, pad, pos, H, smax, out_mtp);
-        break;
-      case ITTS_F16:
-        hipLaunchKernelGGL((attn_decode_kernel<f16_t, 8>), grid, block, 0, s, (const f16_t*)q, (const f16_t*)kcache, (const f16_t*)vcache, (f16_t*)out, pad, pos, H, smax, out_mtp);
-        break;
-      default:
-        ITTS_REQUIRE(false, "itts_attn_decode: unknown dtype %d", dtype);
-    }
-    return check_launch("itts_attn_decode");
-  }
+  const bool ind = kv_rows != nullptr;
+#define ITTS_AD(TT_, NW_, IND_)                                                                                             \
+  hipLaunchKernelGGL((attn_decode_kernel<TT_, NW_, IND_>), grid, block, 0, s, (const TT_*)q, (const TT_*)kcache,           \
+                     (const TT_*)vcache, (TT_*)out, pad, pos, H, smax, out_mtp, kv_rows, kv_step, B)
+#define ITTS_AD_T(TT_)                                                            \
+  do {                                                                            \
+    if (g_attn_waves == 8) { if (ind) ITTS_AD(TT_, 8, true); else ITTS_AD(TT_, 8, false); } \
+    else { if (ind) ITTS_AD(TT_, 4, true); else ITTS_AD(TT_, 4, false); }          \
+  } while (0)
   switch (dtype) {
     case ITTS_F32:
-      hipLaunchKernelGGL((attn_decode_kernel<float, 4>), grid, block, 0, s, (const float*)q, (const float*)kcache, (const float*)vcache, (float*)out, pad, pos, H, smax, out_mtp);
+      ITTS_AD_T(float);
       break;
     case ITTS_BF16:
-      hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 4>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)kcache, (const bf16_t*)vcache, (bf16_t*)out, pad, pos, H, smax, out_mtp);
+      ITTS_AD_T(bf16_t);
       break;
     case ITTS_F16:
-      hipLaunchKernelGGL((attn_decode_kernel<f16_t, 4>), grid, block, 0, s, (const f16_t*)q, (const f16_t*)kcache, (const f16_t*)vcache, (f16_t*)out, pad, pos, H, smax, out_mtp);
+      ITTS_AD_T(f16_t);
       break;
     default:
       ITTS_REQUIRE(false, "itts_attn_decode: unknown dtype %d", dtype);
   }
+#undef ITTS_AD_T
+#undef ITTS_AD
   return check_launch("itts_attn_decode");
 }
 

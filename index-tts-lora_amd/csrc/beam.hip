@@ -91,6 +91,8 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p) {
   __shared__ int nx_tok[BM_MAXB], nx_src[BM_MAXB];       // next beams: token, source beam
   __shared__ int add_slot[BM_MAXB], add_beam[BM_MAXB];   // hypotheses closed this step
   __shared__ int sh_nadd;
+  __shared__ int picks[2 * BM_MAXB];      // drawn / taken candidates (lane 0 bookkeeping; LDS keeps it out of scratch)
+  __shared__ float nx_score[BM_MAXB];
 
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nb = p.nb, V = p.V;
@@ -227,7 +229,6 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p) {
     }
     __syncthreads();
     if (tid == 0) {
-      int picks[2 * BM_MAXB];
       int npick = 0;
       const int want = min(2 * nb, np);
       if (p.do_sample) {
@@ -268,7 +269,6 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p) {
       float worst = p.worst[b];
       float best = -INFINITY;
       for (int i = 0; i < npick; ++i) best = fmaxf(best, ss[picks[i]]);
-      float nx_score[BM_MAXB];
       for (int rank = 0; rank < npick && nxt < nb; ++rank) {
         const int flat = si[picks[rank]];
         const int beam = flat / V, tok = flat - beam * V;
@@ -359,6 +359,20 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p) {
   }
 }
 
+// KV rows follow their beams WITHOUT moving a byte of the cache (GPT2InferenceModel._reorder_cache, model.py:207-218, as
+// a table permutation).  tbl[parity][r][j] = physical cache row that holds position j of logical row r.  Runs right after
+// beam_step_kernel (state[0] = k + 1 tokens, state[1] = P = the position the next step appends): table k+1 is written from
+// table k -- positions < P come from the source beam's row, position P lives in row r itself.  One workgroup per row.
+__global__ __launch_bounds__(256) void beam_kv_rows_kernel(int32_t* __restrict__ tbl, const int32_t* __restrict__ src,
+                                                            const int32_t* __restrict__ state, int R, int smax) {
+  const int r = blockIdx.x, k1 = state[0], P = state[1];
+  const int32_t* srow = tbl + ((int64_t)((k1 + 1) & 1) * R + src[r]) * smax;
+  int32_t* drow = tbl + ((int64_t)(k1 & 1) * R + r) * smax;
+  const int nvalid = min(P, smax);
+  for (int j = threadIdx.x; j < nvalid; j += 256) drow[j] = srow[j];
+  if (threadIdx.x == 0 && P < smax) drow[P] = r;
+}
+
 // Permute the KV rows of each batch element by src (row r <- row src[r]) for cache positions [0, state[1]).
 // One workgroup per (head, batch element, layer x {K,V}); every thread moves whole 16-byte chunks of ALL num_beams
 // rows (loads of all sources before the first store), so the permutation is done in place.
@@ -435,8 +449,15 @@ extern "C" int itts_beam_step(const itts_beam_args* a, void* stream) {
   p.seed_lo = (uint32_t)(a->seed & 0xFFFFFFFFull);
   p.seed_hi = (uint32_t)(a->seed >> 32);
   p.eos = a->eos_token;
+
   hipLaunchKernelGGL(beam_step_kernel, dim3(a->B), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("itts_beam_step");
+}
+
+extern "C" int itts_beam_kv_rows(int32_t* kv_rows, const int32_t* src, const int32_t* state, int rows, int smax, void* stream) {
+  ITTS_REQUIRE(kv_rows && src && state && rows > 0 && smax > 0, "itts_beam_kv_rows: bad arguments");
+  hipLaunchKernelGGL(beam_kv_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, kv_rows, src, state, rows, smax);
+  return check_launch("itts_beam_kv_rows");
 }
 
 extern "C" int itts_beam_reorder_kv(void* kcache, void* vcache, const int32_t* src, const int32_t* state, int layers, int B,

@@ -90,41 +90,45 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
     int idx = tid + i * 256;
     lv[i] = idx < V ? lg[idx] : 0.f;
   }
-  // ---- repetition-penalty membership bitmap
+  // ---- raw logits -> LDS, then the repetition penalty as a pass over the HISTORY (<= k + n_extra ids, a few per thread)
+  //      instead of a membership test (and, for flagged lanes' waves, an IEEE division) on each of the 8194 scores: the
+  //      bitmap only de-duplicates -- the first thread to set an id's bit applies the penalty to that id's score
   for (int i = tid; i < SM_MAXV / 32; i += 256) flag[i] = 0u;
   if (tid == 0) { sh_n = 0; sh_tok = p.stop_token; sh_keep = 0; }
-  __syncthreads();
-  if (p.rep_penalty != 1.0f) {
-    for (int i = tid; i < p.n_extra; i += 256) {
-      int id = p.extra_ids[i];
-      if (id >= 0 && id < V) atomicOr(&flag[id >> 5], 1u << (id & 31));
-    }
-    int nh = min(k, p.hist_cap);
-    for (int i = tid; i < nh; i += 256) {
-      int id = p.history[(int64_t)b * p.hist_cap + i];
-      if (id >= 0 && id < V) atomicOr(&flag[id >> 5], 1u << (id & 31));
-    }
+#pragma unroll
+  for (int i = 0; i < SM_MAXV / 256; ++i) {
+    int idx = tid + i * 256;
+    if (idx < V) sv[idx] = lv[i];
   }
   __syncthreads();
   SSTAMP(1);
-  const float inv_t = (p.do_sample && p.temperature != 1.0f) ? 1.0f / p.temperature : 1.0f;
-  {
-    // all bitmap words first (independent LDS reads in flight together), then the arithmetic
-    uint32_t fw[SM_MAXV / 256];
-#pragma unroll
-    for (int i = 0; i < SM_MAXV / 256; ++i) {
-      int idx = tid + i * 256;
-      fw[i] = idx < V ? flag[idx >> 5] : 0u;
+  if (p.rep_penalty != 1.0f) {
+    const int nh = min(k, p.hist_cap);
+    for (int i = tid; i < p.n_extra + nh; i += 256) {
+      const int id = i < p.n_extra ? p.extra_ids[i] : p.history[(int64_t)b * p.hist_cap + (i - p.n_extra)];
+      if (id >= 0 && id < V) {
+        const uint32_t bit = 1u << (id & 31);
+        if (!(atomicOr(&flag[id >> 5], bit) & bit)) {
+          const float v = sv[id];
+          sv[id] = v < 0.f ? v * p.rep_penalty : v / p.rep_penalty;
+        }
+      }
     }
+    __syncthreads();
+  }
+  const float inv_t = (p.do_sample && p.temperature != 1.0f) ? 1.0f / p.temperature : 1.0f;
+#pragma unroll
+  for (int i = 0; i < SM_MAXV / 256; ++i) {   // processed scores back into registers (independent LDS reads)
+    int idx = tid + i * 256;
+    lv[i] = idx < V ? sv[idx] : 0.f;
+  }
+  if (inv_t != 1.0f) {
 #pragma unroll
     for (int i = 0; i < SM_MAXV / 256; ++i) {
       int idx = tid + i * 256;
       if (idx < V) {
-        float v = lv[i];
-        if ((fw[i] >> (idx & 31)) & 1u) v = v < 0.f ? v * p.rep_penalty : v / p.rep_penalty;
-        if (inv_t != 1.0f) v = v / p.temperature;
-        lv[i] = v;
-        sv[idx] = v;
+        lv[i] = lv[i] / p.temperature;
+        sv[idx] = lv[i];
       }
     }
   }
@@ -178,14 +182,19 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
       uint32_t* tmax = reinterpret_cast<uint32_t*>(ss);   // ss is free until the rank sort
       tmax[tid] = kmax;
       __syncthreads();
-      int rank = 0;
-#pragma unroll 8
-      for (int j4 = 0; j4 < 64; ++j4) {   // broadcast 16-byte reads, eight in flight
-        const u32x4 o4 = *reinterpret_cast<const u32x4*>(tmax + j4 * 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) rank += (o4[e] > kmax || (o4[e] == kmax && j4 * 4 + e < tid)) ? 1 : 0;
+      if (wave == 0) {
+        // ONE wave finds the kk-th largest of the 256 maxima by bitwise bisection over its 4 values per lane: ballots and
+        // scalar popcounts only, no barrier per round (a workgroup-wide round costs ~0.25 us of barrier + LDS turnaround)
+        const u32x4 m4 = *reinterpret_cast<const u32x4*>(tmax + lane * 4);
+        uint32_t t = 0u;
+        for (int bit = 31; bit >= 0; --bit) {
+          const uint32_t cand = t | (1u << bit);
+          const int cnt = __popcll(__ballot(m4[0] >= cand)) + __popcll(__ballot(m4[1] >= cand)) +
+                          __popcll(__ballot(m4[2] >= cand)) + __popcll(__ballot(m4[3] >= cand));
+          if (cnt >= kk) t = cand;
+        }
+        if (lane == 0) sh_prefix = t;
       }
-      if (rank == kk - 1) sh_prefix = kmax;
       __syncthreads();
       thr = sh_prefix;
       int cnt = 0;

@@ -79,13 +79,14 @@ _SIGNATURES = {
     "itts_embed_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                   C.c_int, C.c_void_p, C.c_void_p]),
     "itts_attn_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "itts_attn_prefill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_attn_prefill_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_sample": (C.c_int, [C.POINTER(SampleArgs), C.c_void_p]),
     "itts_beam_step": (C.c_int, [C.POINTER(BeamArgs), C.c_void_p]),
+    "itts_beam_kv_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "itts_beam_reorder_kv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int64, C.c_int, C.c_void_p]),
     "itts_tanh_pcm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
@@ -282,9 +283,10 @@ def embed_step(tokens, table, pos_table, step, pos_add, h, epoch=None):
            "itts_embed_step")
 
 
-def attn_decode(q, kcache, vcache, out, pad, pos, B, H, smax, out_packed=False):
+def attn_decode(q, kcache, vcache, out, pad, pos, B, H, smax, out_packed=False, kv_rows=None, kv_step=None):
+    """kv_rows int32 [2][B][smax] + kv_step (device word): beam-search row table instead of permuted cache rows."""
     _check(lib().itts_attn_decode(_p(q), _p(kcache), _p(vcache), _p(out), _p(pad), _p(pos), B, H, smax, dt(q.dtype),
-                                  int(bool(out_packed)), _stream()), "itts_attn_decode")
+                                  int(bool(out_packed)), _p(kv_rows), _p(kv_step), _stream()), "itts_attn_decode")
 
 
 def attn_prefill(qkv, out, kcache, vcache, pad, B, S, H, smax):
@@ -328,6 +330,12 @@ def beam_step(logits, num_beams, tokens, src, beam_scores, hist, hyp_score, hyp_
     a.rep_penalty, a.temperature, a.top_p, a.length_penalty = float(rep_penalty), float(temperature), float(top_p), float(length_penalty)
     a.top_k, a.do_sample, a.seed, a.eos_token = int(top_k), int(bool(do_sample)), int(seed), int(eos_token)
     _check(lib().itts_beam_step(C.byref(a), _stream()), "itts_beam_step")
+
+
+def beam_kv_rows(kv_rows, src, state):
+    """kv_rows int32 [2][R][smax]: permute the row table by src (call right after beam_step)."""
+    _, R, smax = kv_rows.shape
+    _check(lib().itts_beam_kv_rows(_p(kv_rows), _p(src), _p(state), R, smax, _stream()), "itts_beam_kv_rows")
 
 
 def beam_reorder_kv(kc, vc, src, state, B, num_beams):

@@ -52,6 +52,11 @@ class GPTEngine:
         # T-typed activations of the decode step (xn, attention output, MLP hidden) live in the packed fragment layout
         # (include/indextts_hip.h): the GEMMs read them as contiguous 1-KiB blocks.  ITTS_PACKED_ACT=0: row-major (same bits).
         self.pa = os.environ.get("ITTS_PACKED_ACT", "1") == "1"
+        # beam search: KV rows follow their beams through a row TABLE read by the attention kernel ("table", no cache bytes
+        # move) or by permuting the cache rows in place ("copy": itts_beam_reorder_kv, the reference form of
+        # GPT2InferenceModel._reorder_cache, model.py:207-218; 1 ms per token at 32 x 3 rows)
+        self.beam_kv = os.environ.get("ITTS_BEAM_KV", "table")
+        self._kv_rows = None   # the table of the beam decode in progress (None outside decode_beam)
         self.max_rows_per_launch = 16 if dtype == torch.float32 else 96   # rows one skinny-GEMM launch covers
 
         self.layers = []
@@ -96,7 +101,8 @@ class GPTEngine:
         e = copy.copy(self)
         e._cap_b = e._cap_s = 0
         e._graphs = {}
-        e._beam_cap = (0, 0)
+        e._beam_cap = (0, 0, 0)
+        e._kv_rows = None
         e._sink = torch.zeros(4, dtype=torch.int32, device=self.device)
         e.tail_cnt = torch.zeros_like(self.tail_cnt)
         return e
@@ -262,7 +268,8 @@ class GPTEngine:
         for i, l in enumerate(self.layers):
             nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv"], l["b_qkv"], x=xn, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
                             vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s, x_packed=pa)
-            nat.attn_decode(self.q, self.kc[i], self.vc[i], self.a, self.pad, pos, B, H, self._cap_s, out_packed=pa)
+            nat.attn_decode(self.q, self.kc[i], self.vc[i], self.a, self.pad, pos, B, H, self._cap_s, out_packed=pa,
+                            kv_rows=self._kv_rows, kv_step=step if self._kv_rows is not None else None)
             last = i + 1 == self.L
             nxt = self.ln_f if last else self.layers[i + 1]["ln1"]
             nxt2 = self.final_norm if last else None
@@ -363,7 +370,7 @@ class GPTEngine:
     # ------------------------------------------------------------------------------------------------ beam search
     def _ensure_beam(self, B: int, nb: int):
         R, dev = B * nb, self.device
-        if getattr(self, "_beam_cap", (0, 0)) == (B, nb):
+        if getattr(self, "_beam_cap", (0, 0, 0)) == (B, nb, self._cap_s):
             return
         # the buffers below are about to be replaced: every captured beam step holds their addresses, so those graphs
         # must go with them (a B=4 -> B=3 -> B=4 sequence would otherwise replay a graph over freed memory)
@@ -379,7 +386,8 @@ class GPTEngine:
         self.b_n_hyp = torch.zeros(B, dtype=torch.int32, device=dev)
         self.b_worst = torch.zeros(B, dtype=torch.float32, device=dev)
         self.b_done = torch.zeros(B, dtype=torch.int32, device=dev)
-        self._beam_cap = (B, nb)
+        self.b_kv_rows = torch.zeros(2, R, self._cap_s, dtype=torch.int32, device=dev)   # [parity][logical row][position]
+        self._beam_cap = (B, nb, self._cap_s)
 
     def _beam_select(self, B, nb, sp):
         R = B * nb
@@ -388,7 +396,10 @@ class GPTEngine:
                       self.b_hyp_tok, self.b_n_hyp, self.b_worst, self.b_done, self.state, self.extra_ids,
                       sp["repetition_penalty"], sp["temperature"], sp["top_k"], sp["top_p"], sp["do_sample"],
                       sp.get("length_penalty", 0.0), sp["seed"], self.stop_mel)
-        nat.beam_reorder_kv(self.kc, self.vc, self.b_src, self.state, B, nb)
+        if self._kv_rows is not None:
+            nat.beam_kv_rows(self._kv_rows, self.b_src, self.state)
+        else:
+            nat.beam_reorder_kv(self.kc, self.vc, self.b_src, self.state, B, nb)
 
     def _step_kernels_beam(self, B, nb, sp):
         self._step_transformer(B * nb)
@@ -411,10 +422,21 @@ class GPTEngine:
         self.b_n_hyp.zero_()
         self.b_worst.fill_(1e9)
         self.b_done.zero_()
+        if self.beam_kv == "table":
+            self.b_kv_rows[0] = torch.arange(R, dtype=torch.int32, device=self.device)[:, None]   # identity: every row holds itself
+            self._kv_rows = self.b_kv_rows
+        else:
+            self._kv_rows = None
+        try:
+            return self._decode_beam_loop(B, nb, max_new, sp, use_graph, check_every)
+        finally:
+            self._kv_rows = None
+
+    def _decode_beam_loop(self, B, nb, max_new, sp, use_graph, check_every):
         sp = self._seed_to_state(sp)
         self._beam_select(B, nb, sp)  # token 1 from the prefill logits
         n = 1
-        key = ("beam", B, nb, tuple(sorted(sp.items())))
+        key = ("beam", B, nb, self.beam_kv, tuple(sorted(sp.items())))
         while n < max_new:
             if use_graph and not self.force_eager and n >= 2:
                 g = self._graphs.get(key)

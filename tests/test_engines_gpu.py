@@ -238,12 +238,17 @@ def test_beam_decode_matches_host_driven_oracle(gpt_small_fp32, do_sample):
         eng.state[1] += 1
         eng._step_transformer(R)
     want = ref.finalize()
-    for use_graph in (False, True):
-        eng.prefill(emb_r, pad_r, max_new)
-        got = eng.decode_beam(max_new, sp, nb, use_graph=use_graph, check_every=4).cpu().numpy()
-        w = min(got.shape[1], want.shape[1])
-        assert np.array_equal(got[:, :w], want[:, :w]), (use_graph, got, want)
-        assert (got[:, w:] == 8193).all() and (want[:, w:] == 8193).all()
+    # "table": KV rows follow their beams through the row table the attention kernel reads (no cache bytes move);
+    # "copy": the cache rows are permuted in place (itts_beam_reorder_kv, the reference form of _reorder_cache)
+    for kv in ("table", "copy"):
+        for use_graph in (False, True):
+            eng.beam_kv = kv
+            eng.prefill(emb_r, pad_r, max_new)
+            got = eng.decode_beam(max_new, sp, nb, use_graph=use_graph, check_every=4).cpu().numpy()
+            w = min(got.shape[1], want.shape[1])
+            assert np.array_equal(got[:, :w], want[:, :w]), (kv, use_graph, got, want)
+            assert (got[:, w:] == 8193).all() and (want[:, w:] == 8193).all()
+    eng.beam_kv = "table"
     # the reference-API entry point takes the same route
     codes = m.inference_speech(cond_mel, text, do_sample=do_sample, num_beams=nb, top_k=30, top_p=0.8, temperature=1.0,
                                repetition_penalty=10.0, length_penalty=0.0, max_generate_length=max_new, seed=5)

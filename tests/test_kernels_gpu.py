@@ -623,6 +623,42 @@ def test_gemm_skinny_reducer_tail_equals_ln_reduce_launch(nat, dtype, M, K, two)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attn_decode_row_table_equals_permuted_cache(nat, dtype):
+    """Beam search: attention through the KV row table (itts_beam_kv_rows + kv_rows argument) equals attention over a cache
+    whose rows were permuted by itts_beam_reorder_kv -- over several steps with changing parents."""
+    B, nb, H, smax = 2, 3, 4, 64
+    R, D = B * nb, H * 64
+    kc, vc = rnd(1, R, H, smax, 64, seed=210).to(dtype), rnd(1, R, H, smax, 64, seed=211).to(dtype)
+    kc2, vc2 = kc.clone(), vc.clone()
+    pad = torch.tensor([0, 0, 0, 3, 3, 3], dtype=torch.int32, device=DEV)
+    tbl = torch.zeros(2, R, smax, dtype=torch.int32, device=DEV)
+    tbl[0] = torch.arange(R, dtype=torch.int32, device=DEV)[:, None]
+    state_t = torch.zeros(8, dtype=torch.int32, device=DEV)   # table form: [0] step, [1] position
+    state_c = torch.zeros(8, dtype=torch.int32, device=DEV)
+    P0 = 20
+    srcs = [[0, 0, 1, 5, 3, 3], [2, 1, 1, 3, 4, 5], [0, 1, 2, 4, 4, 4], [1, 1, 1, 3, 5, 3]]
+    for step, src_l in enumerate(srcs):
+        src = torch.tensor(src_l, dtype=torch.int32, device=DEV)
+        # what the beam step kernel does to the loop state: one more token, one more position
+        state_t[0], state_t[1] = step + 1, P0 + step
+        state_c[0], state_c[1] = step + 1, P0 + step
+        nat.beam_kv_rows(tbl, src, state_t)
+        nat.beam_reorder_kv(kc2, vc2, src, state_c, B, nb)
+        # the transformer step appends position P for every row (same new k/v in both forms)
+        P = P0 + step
+        newk, newv = rnd(R, H, 64, seed=220 + step).to(dtype), rnd(R, H, 64, seed=230 + step).to(dtype)
+        kc[0, :, :, P], vc[0, :, :, P] = newk, newv
+        kc2[0, :, :, P], vc2[0, :, :, P] = newk, newv
+        q = rnd(R, D, seed=240 + step).to(dtype)
+        pos = torch.tensor([P], dtype=torch.int32, device=DEV)
+        out_t, out_c = torch.empty(R, D, dtype=dtype, device=DEV), torch.empty(R, D, dtype=dtype, device=DEV)
+        nat.attn_decode(q, kc[0], vc[0], out_t, pad, pos, R, H, smax, kv_rows=tbl, kv_step=state_t[0:1])
+        nat.attn_decode(q, kc2[0], vc2[0], out_c, pad, pos, R, H, smax)
+        assert torch.equal(out_t, out_c), step
+    assert not torch.equal(kc, kc2)   # the table form never moved a cache row
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_attn_prefill_packed_equals_left_padded(nat, dtype):
     """Packed rows (no padding rows at all) give the attention outputs and the KV cache contents of the left-padded form
     for every real position."""

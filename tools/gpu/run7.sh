@@ -1,0 +1,15 @@
+set -o pipefail
+cd $GRAFT_REPO_ROOT
+timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py -m gpu -x -q > gpurun_out/t7_kern.log 2>&1 || { tail -30 gpurun_out/t7_kern.log; exit 1; }
+tail -2 gpurun_out/t7_kern.log
+timeout -k 10 900 python -m pytest tests/test_engines_gpu.py tests/test_configs_gpu.py -m gpu -x -q > gpurun_out/t7_eng.log 2>&1 || { tail -40 gpurun_out/t7_eng.log; exit 1; }
+tail -2 gpurun_out/t7_eng.log
+timeout -k 10 200 python tools/timeline_sample.py gpurun_out/timeline_sample.json || exit 1
+timeout -k 10 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-concurrency --no-roofline > gpurun_out/b7.json 2> gpurun_out/b7.log || { tail -30 gpurun_out/b7.log; exit 1; }
+python - <<'PY'
+import json
+j=json.load(open("gpurun_out/b7.json"))
+print(j["value"], j["phases_ms"], j["decode_step"]["us"], j["first_token_ms"])
+PY
+timeout -k 10 300 python tools/bench_configs.py > gpurun_out/side7.log 2>&1; tail -5 gpurun_out/side7.log
+echo ALLDONE
