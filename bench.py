@@ -39,6 +39,26 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+_JSON_OUT = None
+
+
+def claim_stdout():
+    """stdout carries exactly ONE JSON line.  Libraries (gloo, RCCL, MIOpen ...) write to file descriptor 1 from C++, so the
+    descriptor itself is pointed at stderr and the original is kept aside for the final line."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    return _JSON_OUT
+
+
+def emit_json(obj):
+    out = claim_stdout()
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
 def build_weights_rank0():
     import weights
     t0 = time.time()
@@ -283,11 +303,10 @@ def stub_main(args, rank, world):
                                           "rows": sorted(mine)})
     audio_s_job = sum(p["audio_s_per_step"] for p in per_rank)
     if rank == 0:
-        print(json.dumps({"metric": "stub", "value": round(audio_s_job * args.steps / elapsed, 2), "unit": "audio-seconds/sec",
+        emit_json({"metric": "stub", "value": round(audio_s_job * args.steps / elapsed, 2), "unit": "audio-seconds/sec",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
                           "scaling": "weak", "data": "stub", "ranks_seen": ranks_seen, "per_rank": per_rank,
-                          "audio_seconds_per_step_job": audio_s_job, "config": {"workload": f"stub of config {args.config}"}}),
-              flush=True)
+                          "audio_seconds_per_step_job": audio_s_job, "config": {"workload": f"stub of config {args.config}"}})
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -324,6 +343,7 @@ def main():
         # no external launcher: become the supervisor of N ranks.  This happens before ANY GPU call in this process.
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
+    claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -680,7 +700,7 @@ def main():
             result["cpu_baseline"]["reference_in_build_container"] = json.load(open(ref))
 
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit_json(result)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

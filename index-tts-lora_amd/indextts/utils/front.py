@@ -2,8 +2,9 @@
 
 `TextTokenizer` mirrors the reference surface (indextts/utils/front.py:227-424): tokenize / encode /
 convert_tokens_to_ids / split_sentences on a SentencePiece model after CJK-character splitting + upper-casing
-(utils/common.py:39-63).  `TextNormalizer` is a light stand-in: the reference's WeTextProcessing-based normaliser is an
-optional dependency that is not available offline; text is passed through with full-width punctuation folded.
+(utils/common.py:39-63).  `TextNormalizer` restates the reference's regex pre/post-processing (language routing, contraction rewrite, pinyin and
+name protection, punctuation maps; pinned by tests/golden/text_normalizer.json) around the two WeTextProcessing
+normalisers, which are used when that optional package is importable and passed through otherwise.
 When no `bpe.model` exists (offline benchmarking with synthetic weights) `TextTokenizer(..., allow_synthetic=True)`
 falls back to a deterministic one-piece-per-character vocabulary so that the pipeline can still be exercised."""
 import os
@@ -21,14 +22,127 @@ def tokenize_by_CJK_char(line: str, do_upper_case=True) -> str:
 
 
 class TextNormalizer:
-    _PUNCT = {"，": ",", "。": ".", "！": "!", "？": "?", "；": ",", "：": ",", "、": ",", "（": "'", "）": "'", "“": "'",
-              "”": "'", "‘": "'", "’": "'", "《": "'", "》": "'", "…": "...", "—": "-", "～": "-", "~": "-", "\n": " "}
+    """Text normaliser with the reference's surface and control flow (indextts/utils/front.py:11-219).
 
+    The reference wraps two WeTextProcessing normalisers (zh / en number-date-unit verbalisation, loaded in `load()`) in
+    regex pre/post-processing.  WeTextProcessing is an optional dependency that cannot be fetched offline: `load()` uses it
+    when importable and otherwise keeps pass-through normalisers (a warning says so once).  Everything AROUND those two
+    calls is restated here and pinned by reference-run fixtures (tests/golden/text_normalizer.json):
+      * language routing: Chinese path when the text has a CJK character, no latin letter, is an e-mail address, or
+        carries tone-numbered pinyin (`xuan4`), else English path (front.py:92-101);
+      * "what's / it's / that's ..." -> "... is" (front.py:88, 132, 150);
+      * pinyin protection: tone-numbered syllables are swapped for placeholders before normalisation and restored after,
+        upper-cased, with j/q/x + u written as v (ju4 -> JV4) (front.py:148-160, 196-226);
+      * name protection: 中文·中文(-中文) names survive the punctuation map (front.py:162-194);
+      * the punctuation maps (front.py:19-59)."""
+
+    # full-width / bracket / quote folding applied after normalisation (interface data of front.py:19-55)
+    _FOLD = (("：", ","), ("；", ","), (";", ","), ("，", ","), ("。", "."), ("！", "!"), ("？", "?"), ("\n", " "), ("·", "-"),
+             ("、", ","), ("...", "…"), (",,,", "…"), ("，，，", "…"), ("……", "…"), ("“", "'"), ("”", "'"), ('"', "'"),
+             ("‘", "'"), ("’", "'"), ("（", "'"), ("）", "'"), ("(", "'"), (")", "'"), ("《", "'"), ("》", "'"), ("【", "'"),
+             ("】", "'"), ("[", "'"), ("]", "'"), ("—", "-"), ("～", "-"), ("~", "-"), ("「", "'"), ("」", "'"), (":", ","))
+
+    PINYIN_TONE_PATTERN = (r"(?<![a-z])((?:[bpmfdtnlgkhjqxzcsryw]|[zcs]h)?(?:[aeiouüv]|[ae]i|u[aio]|ao|ou|i[aue]|[uüv]e|"
+                           r"[uvü]ang?|uai|[aeiuv]n|[aeio]ng|ia[no]|i[ao]ng)|ng|er)([1-5])")
+    NAME_PATTERN = r"[\u4e00-\u9fff]+(?:[-·—][\u4e00-\u9fff]+){1,2}"
+    ENGLISH_CONTRACTION_PATTERN = r"(what|where|who|which|how|t?here|it|s?he|that|this)'s"
+
+    class _PassThrough:
+        def normalize(self, text):
+            return text
+
+    def __init__(self):
+        self.zh_normalizer = None
+        self.en_normalizer = None
+        self.char_rep_map = dict(self._FOLD)
+        self.zh_char_rep_map = {"$": ".", **self.char_rep_map}   # the Chinese path also folds "$" (front.py:56-59)
+        # one alternation per map, keys in table order: the leftmost-longest behaviour of the reference's pattern
+        self._fold_en = re.compile("|".join(re.escape(k) for k in self.char_rep_map))
+        self._fold_zh = re.compile("|".join(re.escape(k) for k in self.zh_char_rep_map))
+        self._pinyin = re.compile(self.PINYIN_TONE_PATTERN, re.IGNORECASE)
+        self._name = re.compile(self.NAME_PATTERN, re.IGNORECASE)
+
+    # ---- reference surface ------------------------------------------------------------------------------------
     def load(self):
+        if self.zh_normalizer is not None and self.en_normalizer is not None:
+            return self
+        try:  # the reference's optional dependency (front.py:103-127); absent offline
+            from tn.chinese.normalizer import Normalizer as NormalizerZh
+            from tn.english.normalizer import Normalizer as NormalizerEn
+            self.zh_normalizer = NormalizerZh(remove_interjections=False, remove_erhua=False, overwrite_cache=False)
+            self.en_normalizer = NormalizerEn(overwrite_cache=False)
+        except Exception:  # noqa: BLE001
+            if not getattr(TextNormalizer, "_warned", False):
+                warnings.warn("WeTextProcessing is not installed: numbers, dates and units are passed to the tokenizer "
+                              "un-verbalised (punctuation, pinyin and name handling are active)", RuntimeWarning)
+                TextNormalizer._warned = True
+            self.zh_normalizer = self.en_normalizer = TextNormalizer._PassThrough()
         return self
 
+    def match_email(self, email: str) -> bool:
+        return re.match(r"^[a-zA-Z0-9]+@[a-zA-Z0-9]+\.[a-zA-Z]+$", email) is not None
+
+    def use_chinese(self, s: str) -> bool:
+        if re.search(r"[\u4e00-\u9fff]", s) or not re.search(r"[a-zA-Z]", s) or self.match_email(s):
+            return True
+        return self._pinyin.search(s) is not None
+
     def normalize(self, text: str) -> str:
-        return "".join(self._PUNCT.get(ch, ch) for ch in text).strip()
+        if not self.zh_normalizer or not self.en_normalizer:
+            print("[error] TextNormalizer.load() has not been called")
+            return ""
+        text = re.sub(self.ENGLISH_CONTRACTION_PATTERN, r"\1 is", text, flags=re.IGNORECASE)
+        if not self.use_chinese(text):
+            try:
+                result = self.en_normalizer.normalize(text)
+            except Exception:  # noqa: BLE001
+                result = text
+            return self._fold_en.sub(lambda m: self.char_rep_map[m.group()], result)
+        held, pinyins = self.save_pinyin_tones(text.rstrip())
+        held, names = self.save_names(held)
+        try:
+            result = self.zh_normalizer.normalize(held)
+        except Exception:  # noqa: BLE001
+            result = ""
+        result = self.restore_pinyin_tones(self.restore_names(result, names), pinyins)
+        return self._fold_zh.sub(lambda m: self.zh_char_rep_map[m.group()], result)
+
+    def correct_pinyin(self, pinyin: str) -> str:
+        """j / q / x followed by u or ü spell the vowel ü: written v, whole syllable upper-cased (ju4 -> JV4);
+        other initials are returned untouched."""
+        if pinyin[0] not in "jqxJQX":
+            return pinyin
+        return re.sub(r"([jqx])[uü](n|e|an)*(\d)", r"\g<1>v\g<2>\g<3>", pinyin, flags=re.IGNORECASE).upper()
+
+    @staticmethod
+    def _hold(text, items, tag):
+        for i, item in enumerate(items):
+            text = text.replace(item, f"<{tag}_{chr(ord('a') + i)}>")
+        return text
+
+    def save_pinyin_tones(self, original_text: str):
+        found = ["".join(m) for m in self._pinyin.findall(original_text)]
+        if not found:
+            return original_text, None
+        items = list(dict.fromkeys(found))   # first-occurrence order (the reference's set() order is arbitrary; the
+        return self._hold(original_text, items, "pinyin"), items   # normalised text does not depend on it)
+
+    def restore_pinyin_tones(self, normalized_text: str, original_pinyin_list):
+        for i, pinyin in enumerate(original_pinyin_list or ()):
+            normalized_text = normalized_text.replace(f"<pinyin_{chr(ord('a') + i)}>", self.correct_pinyin(pinyin))
+        return normalized_text
+
+    def save_names(self, original_text: str):
+        found = self._name.findall(original_text)
+        if not found:
+            return original_text, None
+        items = list(dict.fromkeys(found))
+        return self._hold(original_text, items, "n"), items
+
+    def restore_names(self, normalized_text: str, original_name_list):
+        for i, name in enumerate(original_name_list or ()):
+            normalized_text = normalized_text.replace(f"<n_{chr(ord('a') + i)}>", name)
+        return normalized_text
 
 
 class TextTokenizer:

@@ -217,3 +217,106 @@ def test_beam_sample_row_processing_matches_transformers_processors():
         got = beam_ref.process_row(logits[0], hist[0], sp, 3)
         assert np.array_equal(np.isfinite(got), np.isfinite(s)), case
         np.testing.assert_allclose(got[np.isfinite(got)], s[np.isfinite(s)], rtol=2e-6, atol=2e-6)
+
+
+def test_beam_sample_bookkeeping_matches_transformers_with_injected_draws(monkeypatch):
+    """Pins the do_sample=True branch of oracle/beam_ref.py (processors with min_tokens_to_keep = 2 on log-probabilities,
+    candidate pool over num_beams x V, scorer bookkeeping on DRAWN -- not top -- candidates, EOS handling, finalize) against
+    the installed transformers' generate(num_beams=3, do_sample=True): the 2*num_beams candidate draws are INJECTED into both
+    sides (torch.multinomial on the HF side, beam_ref.draw_without_replacement on the oracle side are replaced by the same
+    rank-based picker over the same Philox numbers), so everything but the random stream itself is compared.
+    The injected picks are handed over sorted by score: transformers 4.44.2 (the reference's pin) sorts the drawn
+    candidates by score before BeamSearchScorer.process, the installed 5.x keeps draw order -- with sorted picks the two
+    orders coincide, so the comparison is valid for the 4.44.2 semantics the oracle restates."""
+    transformers = pytest.importorskip("transformers")
+    import warnings
+
+    from oracle import beam_ref
+    torch.manual_seed(1)
+    V, eos, nb = 40, 39, 3
+    cfg = transformers.GPT2Config(vocab_size=V, n_positions=64, n_embd=16, n_layer=2, n_head=2, bos_token_id=0, eos_token_id=eos,
+                                  pad_token_id=eos)
+
+    class Boosted(transformers.GPT2LMHeadModel):
+        boost = 0.0
+
+        def forward(self, *a, **k):
+            out = super().forward(*a, **k)
+            out.logits[..., eos] += self.boost
+            return out
+
+    m = Boosted(cfg).eval()
+    for p in m.parameters():
+        torch.nn.init.normal_(p, std=0.35)
+    SEED = 4242
+    step = {"k": 0}
+
+    class SmallPool(Exception):
+        pass
+
+    def ranks(n_alive_start, n_draw, k):
+        """positions (in the score-sorted pool) picked by draw 0..n_draw-1: uniform over the not-yet-drawn entries"""
+        alive = list(range(n_alive_start))
+        out = []
+        for i in range(min(n_draw, n_alive_start)):
+            u = float(beam_ref.uniform01(SEED, 0, k, i))
+            out.append(alive.pop(min(int(u * len(alive)), len(alive) - 1)))
+        return sorted(out)   # pool positions ascending = score descending: the order both sides then see
+
+    def fake_multinomial(probs, num_samples, replacement=False, generator=None):
+        assert probs.shape[0] == 1 and not replacement
+        p = probs[0].double().numpy()
+        ids = np.nonzero(p > 0)[0]
+        order = ids[np.lexsort((ids, -p[ids]))]
+        if order.size < num_samples:
+            raise SmallPool()   # real torch.multinomial raises here too (cannot draw 2*num_beams without replacement)
+        picks = ranks(order.size, num_samples, step["k"])
+        step["k"] += 1
+        return torch.from_numpy(order[picks].astype(np.int64))[None]
+
+    def fake_draw(pool_scores, n_draw, seed, b, k):
+        # entries whose weight exp(score - max) is 0 in fp32 (rows still at the -1e9 start score) are not candidates on
+        # either side: torch's softmax gives them probability exactly 0
+        e = np.exp((pool_scores - pool_scores[0]).astype(np.float32)).astype(np.float32)
+        return ranks(int((e > 0).sum()), n_draw, k)
+
+    monkeypatch.setattr(beam_ref, "draw_without_replacement", fake_draw)
+    n_eos = n_nontop = n_ok = 0
+    for trial in range(36):
+        m.boost = [0.0, 1.0, 2.0, 3.0][trial // 9]
+        g = torch.Generator().manual_seed(500 + trial)
+        P, max_new = 4, 10
+        prompt = torch.randint(1, V - 1, (1, P), generator=g)
+        lp = [0.0, 1.0, 0.0, 0.5][trial % 4]
+        rp = [1.0, 1.3][trial % 2]
+        tk, tp, temp = [8, 12, 20][trial % 3], [0.8, 0.95, 1.0][trial % 3], [1.0, 0.7][trial % 2]
+        step["k"] = 0
+        with torch.no_grad(), warnings.catch_warnings(), monkeypatch.context() as mp:
+            warnings.simplefilter("ignore")
+            mp.setattr(torch, "multinomial", fake_multinomial)
+            try:
+                out = m.generate(prompt, attention_mask=torch.ones_like(prompt), num_beams=nb, do_sample=True, top_k=tk, top_p=tp,
+                                 temperature=temp, max_new_tokens=max_new, length_penalty=lp, repetition_penalty=rp,
+                                 early_stopping=False, num_return_sequences=1, pad_token_id=eos, eos_token_id=eos)
+            except SmallPool:
+                continue   # top-p left fewer than 2*num_beams candidates: generate() cannot run this case at all
+        n_ok += 1
+        hf = out[0, P:].tolist()
+        sp = dict(do_sample=True, top_k=tk, top_p=tp, temperature=temp, repetition_penalty=rp)
+        bs = beam_ref.BeamSearch(1, nb, sp, prompt[0].tolist(), eos=eos, length_penalty=lp, seed=SEED)
+        for _ in range(max_new):
+            with torch.no_grad():
+                lg = m(torch.tensor(bs.hist[0])).logits[:, -1, :].float().numpy()
+            bs.step(lg)
+            if bs.all_done():
+                break
+        ref = bs.finalize()[0].tolist()
+        n = min(len(ref), len(hf))
+        assert ref[:n] == hf[:n] and all(t == eos for t in ref[n:] + hf[n:]), (trial, hf, ref)
+        n_eos += int(eos in hf)
+        # the drawn candidates must not simply be the top ones, or this would only repeat the beam-search test
+        with torch.no_grad():
+            greedy = m.generate(prompt, attention_mask=torch.ones_like(prompt), num_beams=nb, do_sample=False, max_new_tokens=max_new,
+                                length_penalty=lp, repetition_penalty=rp, early_stopping=False, pad_token_id=eos, eos_token_id=eos)
+        n_nontop += int(greedy[0, P:].tolist()[:n] != hf[:n])
+    assert n_ok >= 20 and n_eos >= 4 and n_nontop >= 8, (n_ok, n_eos, n_nontop)
