@@ -48,7 +48,7 @@ extern "C" {
 #define ITTS_BF16 1
 #define ITTS_F16 2
 
-#define ITTS_ABI_VERSION 2
+#define ITTS_ABI_VERSION 3
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -184,14 +184,34 @@ int itts_layernorm(const float* h, const float* w, const float* b, const float* 
 
 /* Residual update + LayerNorm for the decode step:
  *   if (nslab > 0)  h[m][:] += bias[:] + slab[0][m][:] + ... + slab[nslab-1][m][:]      (fixed order; h updated in place)
+ *                   [+ runtime LoRA, below]
  *   y[m][:] = LN(h[m][:]; w, b)   (then LN(.; w2, b2) if w2 != NULL),  y is T [M][D].
- * slab is fp32 [nslab][M][D] as written by itts_gemm_skinny(ITTS_EPI_SLAB_F32).
+ * slab is fp32 [nslab][M][slab_stride] as written by itts_gemm_skinny(ITTS_EPI_SLAB_F32) with N = slab_stride (0 = D).
  * y_packed != 0 (needs D % 256 == 0): y is written in the packed activation layout.
  * state_bump (int32[2] device words or NULL): both words are incremented once by this launch -- the decode loop's step
- * counter and cache position, advanced here (a launch that reads neither) instead of by the sampling kernel. */
-int itts_ln_reduce(float* h, const float* slab, int nslab, const float* bias, const float* w, const float* b,
-                   const float* w2, const float* b2, void* y, int M, int D, int dtype, int y_packed, int32_t* state_bump,
-                   void* stream);
+ * counter and cache position, advanced here (a launch that reads neither) instead of by the sampling kernel.
+ * Runtime LoRA of the producing projection (lora_b != NULL; unmerged adapters, peft convention y = x W + (x A^T) B^T alpha/r):
+ * the projection's packed weight carries A^T * alpha/r as lora_r extra output COLUMNS (N = D + 16*ceil(r/16) in the
+ * GEMM), so slab columns [D, D + r) hold the split-K partials of x A; this kernel adds (sum of those) @ lora_b, with lora_b
+ * = B^T fp32 [r][D].  The LoRA A.B product is thereby fused into the output projection + its residual update: no extra
+ * launch, no merged copy of the weight. */
+typedef struct itts_ln_reduce_args {
+  int dtype, M, D;
+  float* h;
+  const float* slab;
+  int nslab, slab_stride;
+  const float* bias;
+  const float* w;
+  const float* b;
+  const float* w2;
+  const float* b2;
+  void* y;
+  int y_packed;
+  int32_t* state_bump;
+  const float* lora_b;
+  int lora_r;
+} itts_ln_reduce_args;
+int itts_ln_reduce(const itts_ln_reduce_args* a, void* stream);
 
 /* h[b][:] = table[tokens[b]][:] + pos_table[*step + pos_add][:]   (fp32 tables, fp32 h).  If epoch != NULL, *epoch is
  * incremented once (the first launch of a decode step advances the epoch of that step's reducer tails). */

@@ -296,8 +296,10 @@ __global__ __launch_bounds__(1024) void ln_reduce_wide_kernel(float* __restrict_
                                                               const float* __restrict__ bias, const float* __restrict__ w,
                                                               const float* __restrict__ b, const float* __restrict__ w2,
                                                               const float* __restrict__ b2, T* __restrict__ y, int M, int D,
-                                                              int32_t* __restrict__ bump, int y_pa) {
+                                                              int32_t* __restrict__ bump, int y_pa, int sstride,
+                                                              const float* __restrict__ lora_b, int lora_r) {
   __shared__ float red[2][2][16];
+  __shared__ float xa[64];   // runtime LoRA: (x A) of this row, summed over the split-K slabs
   const int row = blockIdx.x, tid = threadIdx.x, nw = blockDim.x >> 6;
   if (bump != nullptr && row == 0 && tid == 0) { bump[0] += 1; bump[1] += 1; }   // nobody in this launch reads them
   float* hr = h + (int64_t)row * D;
@@ -313,10 +315,28 @@ __global__ __launch_bounds__(1024) void ln_reduce_wide_kernel(float* __restrict_
     f32x4 bs = {0.f, 0.f, 0.f, 0.f};
     if (bias != nullptr) bs = ld16<f32x4>(bias + tid * 4);
 #pragma unroll
-    for (int sidx = 0; sidx < NSLAB; ++sidx) sl[sidx] = ld16<f32x4>(slab + ((int64_t)sidx * M + row) * D + tid * 4);
+    for (int sidx = 0; sidx < NSLAB; ++sidx) sl[sidx] = ld16<f32x4>(slab + ((int64_t)sidx * M + row) * sstride + tid * 4);
     v += bs;
 #pragma unroll
     for (int sidx = 0; sidx < NSLAB; ++sidx) v += sl[sidx];  // same association order as the one-wave form
+    if (lora_r > 0) {
+      // Runtime LoRA of the producing projection: its packed weight carried A (scaled) as lora_r extra output columns, so
+      // columns [D, D + r) of the slabs hold the split-K partials of x A; the update is  v += (x A) B  with B fp32 [r][D].
+      // Fixed orders (slabs, then j = 0..r-1): deterministic.  Equal to the merged weight W + A B within rounding.
+      if (tid < lora_r) {
+        float t = 0.f;
+#pragma unroll
+        for (int sidx = 0; sidx < NSLAB; ++sidx) t += slab[((int64_t)sidx * M + row) * sstride + D + tid];
+        xa[tid] = t;
+      }
+      __syncthreads();
+      for (int j = 0; j < lora_r; ++j) {
+        const f32x4 bj = ld16<f32x4>(lora_b + (int64_t)j * D + tid * 4);
+        const float t = xa[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(t, bj[e], v[e]);
+      }
+    }
     st16(hr + tid * 4, v);
   }
   wide_layernorm<LN2>(v, lw, lb, lw2, lb2, &red[0][0][0], tid, nw, D, true);
@@ -324,18 +344,24 @@ __global__ __launch_bounds__(1024) void ln_reduce_wide_kernel(float* __restrict_
 }
 
 template <typename T, int NV>
-static int launch_ln_reduce(float* h, const float* slab, int nslab, const float* bias, const float* w, const float* b,
-                            const float* w2, const float* b2, T* y, int M, int D, int32_t* bump, int y_pa, hipStream_t s) {
+static int launch_ln_reduce(const itts_ln_reduce_args& a, hipStream_t s) {
+  float* h = a.h;
+  const float *slab = a.slab, *bias = a.bias, *w = a.w, *b = a.b, *w2 = a.w2, *b2 = a.b2;
+  T* y = (T*)a.y;
+  const int M = a.M, D = a.D, nslab = a.nslab, y_pa = a.y_packed, lora_r = a.lora_b ? a.lora_r : 0;
+  const int sstride = a.slab_stride > 0 ? a.slab_stride : D;
+  int32_t* bump = a.state_bump;
+  const float* lora_b = a.lora_b;
   const bool wide = (D % 256 == 0) && D <= 4096;
-  if (y_pa && !wide) {
-    set_error("itts_ln_reduce: a packed y needs D %% 256 == 0 (D=%d)", D);
+  if ((y_pa || lora_r > 0 || sstride != D) && !wide) {
+    set_error("itts_ln_reduce: packed y / slab_stride / LoRA need D %% 256 == 0 (D=%d)", D);
     return ITTS_ERR_INVALID;
   }
   dim3 grid(M), block(wide ? D / 4 : 64);
   const bool two = w2 != nullptr;
 #define ITTS_LNR(NS, L2)                                                                                                   \
   do {                                                                                                                     \
-    if (wide) hipLaunchKernelGGL((ln_reduce_wide_kernel<T, NS, L2>), grid, block, 0, s, h, slab, bias, w, b, w2, b2, y, M, D, bump, y_pa); \
+    if (wide) hipLaunchKernelGGL((ln_reduce_wide_kernel<T, NS, L2>), grid, block, 0, s, h, slab, bias, w, b, w2, b2, y, M, D, bump, y_pa, sstride, lora_b, lora_r); \
     else hipLaunchKernelGGL((ln_reduce_kernel<T, NV, NS, L2>), grid, block, 0, s, h, slab, bias, w, b, w2, b2, y, M, D, bump);     \
   } while (0)
   if (nslab == 0) {
@@ -476,26 +502,29 @@ extern "C" int itts_layernorm(const float* h, const float* w, const float* b, co
   return check_launch("itts_layernorm");
 }
 
-extern "C" int itts_ln_reduce(float* h, const float* slab, int nslab, const float* bias, const float* w, const float* b,
-                              const float* w2, const float* b2, void* y, int M, int D, int dtype, int y_packed,
-                              int32_t* state_bump, void* stream) {
-  ITTS_REQUIRE(h && w && b && y, "itts_ln_reduce: null pointer");
-  ITTS_REQUIRE(nslab >= 0 && (nslab == 0 || slab != nullptr), "itts_ln_reduce: slab missing");
-  ITTS_REQUIRE((w2 == nullptr) == (b2 == nullptr), "itts_ln_reduce: pass both or neither of w2/b2");
+extern "C" int itts_ln_reduce(const itts_ln_reduce_args* a, void* stream) {
+  ITTS_REQUIRE(a && a->h && a->w && a->b && a->y, "itts_ln_reduce: null pointer");
+  const int D = a->D;
+  ITTS_REQUIRE(a->nslab >= 0 && (a->nslab == 0 || a->slab != nullptr), "itts_ln_reduce: slab missing");
+  ITTS_REQUIRE((a->w2 == nullptr) == (a->b2 == nullptr), "itts_ln_reduce: pass both or neither of w2/b2");
   // D % 256 == 0 (<= 4096): one float4 per thread, D/4 threads per row; any other D <= 1280: one wave per row
   ITTS_REQUIRE(D % 4 == 0 && D > 0 && ((D % 256 == 0 && D <= 4096) || D <= 4 * 64 * 5),
                "itts_ln_reduce: unsupported D=%d (a multiple of 256 up to 4096, or any multiple of 4 up to 1280)", D);
-  if (M == 0) return ITTS_OK;
+  ITTS_REQUIRE(a->slab_stride == 0 || a->slab_stride >= D, "itts_ln_reduce: slab_stride %d < D", a->slab_stride);
+  if (a->lora_b != nullptr)
+    ITTS_REQUIRE(a->lora_r > 0 && a->lora_r <= 64 && a->nslab > 0 && a->slab_stride >= D + a->lora_r,
+                 "itts_ln_reduce: LoRA needs 1 <= r <= 64, slabs, and slab_stride >= D + r");
+  if (a->M == 0) return ITTS_OK;
   hipStream_t s = (hipStream_t)stream;
-  switch (dtype) {
+  switch (a->dtype) {
     case ITTS_F32:
-      return launch_ln_reduce<float, 5>(h, slab, nslab, bias, w, b, w2, b2, (float*)y, M, D, state_bump, y_packed, s);
+      return launch_ln_reduce<float, 5>(*a, s);
     case ITTS_BF16:
-      return launch_ln_reduce<bf16_t, 5>(h, slab, nslab, bias, w, b, w2, b2, (bf16_t*)y, M, D, state_bump, y_packed, s);
+      return launch_ln_reduce<bf16_t, 5>(*a, s);
     case ITTS_F16:
-      return launch_ln_reduce<f16_t, 5>(h, slab, nslab, bias, w, b, w2, b2, (f16_t*)y, M, D, state_bump, y_packed, s);
+      return launch_ln_reduce<f16_t, 5>(*a, s);
   }
-  ITTS_REQUIRE(false, "itts_ln_reduce: unknown dtype %d", dtype);
+  ITTS_REQUIRE(false, "itts_ln_reduce: unknown dtype %d", a->dtype);
 }
 
 extern "C" int itts_embed_step(const int32_t* tokens, const float* table, const float* pos_table, const int32_t* step,

@@ -34,6 +34,13 @@ class SkinnyArgs(C.Structure):
                 ("tail_acquire", C.c_int), ("x_packed", C.c_int), ("y_packed", C.c_int), ("tail_y_packed", C.c_int)]
 
 
+class LnReduceArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("M", C.c_int), ("D", C.c_int), ("h", C.c_void_p), ("slab", C.c_void_p), ("nslab", C.c_int),
+                ("slab_stride", C.c_int), ("bias", C.c_void_p), ("w", C.c_void_p), ("b", C.c_void_p), ("w2", C.c_void_p),
+                ("b2", C.c_void_p), ("y", C.c_void_p), ("y_packed", C.c_int), ("state_bump", C.c_void_p), ("lora_b", C.c_void_p),
+                ("lora_r", C.c_int)]
+
+
 class ConvArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("Tin", C.c_int), ("Tout", C.c_int), ("Cin", C.c_int),
                 ("N", C.c_int), ("taps", C.c_int), ("off0", C.c_int), ("dil", C.c_int), ("x", C.c_void_p),
@@ -74,8 +81,7 @@ _SIGNATURES = {
     "itts_gemm_conv": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "itts_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "itts_ln_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                 C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "itts_ln_reduce": (C.c_int, [C.POINTER(LnReduceArgs), C.c_void_p]),
     "itts_embed_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                   C.c_int, C.c_void_p, C.c_void_p]),
     "itts_attn_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -109,7 +115,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.itts_abi_version() != 2:
+        if L.itts_abi_version() != 3:
             raise NativeError("libindextts_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -267,12 +273,21 @@ def layernorm(h, w, b, out, w2=None, b2=None):
     return out
 
 
-def ln_reduce(h, w, b, out, slab=None, nslab=0, bias=None, w2=None, b2=None, state_bump=None, y_packed=False):
-    """h fp32 [M,D] (updated in place when nslab > 0) -> out T [M,D] = LN(h + bias + sum(slabs)).
-    state_bump: int32[2] device words incremented once by the launch (decode loop: step counter and cache position)."""
+def ln_reduce(h, w, b, out, slab=None, nslab=0, bias=None, w2=None, b2=None, state_bump=None, y_packed=False, slab_stride=0,
+              lora_b=None):
+    """h fp32 [M,D] (updated in place when nslab > 0) -> out T [M,D] = LN(h + bias + sum(slabs) [+ (x A) lora_b]).
+    state_bump: int32[2] device words incremented once by the launch (decode loop: step counter and cache position).
+    lora_b fp32 [r, D] (= B^T alpha/r-free: the scale rides on A): runtime LoRA of the producing projection, whose slabs are
+    slab_stride = D + 16*ceil(r/16) wide."""
     M, D = h.shape
-    _check(lib().itts_ln_reduce(_p(h), _p(slab), nslab, _p(bias), _p(w), _p(b), _p(w2), _p(b2), _p(out), M, D,
-                                dt(out.dtype), int(bool(y_packed)), _p(state_bump), _stream()), "itts_ln_reduce")
+    a = LnReduceArgs()
+    a.dtype, a.M, a.D = dt(out.dtype), M, D
+    a.h, a.slab, a.nslab, a.slab_stride = _p(h), _p(slab), int(nslab), int(slab_stride)
+    a.bias, a.w, a.b, a.w2, a.b2 = _p(bias), _p(w), _p(b), _p(w2), _p(b2)
+    a.y, a.y_packed, a.state_bump = _p(out), int(bool(y_packed)), _p(state_bump)
+    if lora_b is not None:
+        a.lora_b, a.lora_r = _p(lora_b), lora_b.shape[0]
+    _check(lib().itts_ln_reduce(C.byref(a), _stream()), "itts_ln_reduce")
     return out
 
 

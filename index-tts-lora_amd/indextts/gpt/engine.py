@@ -59,6 +59,8 @@ class GPTEngine:
         self._kv_rows = None   # the table of the beam decode in progress (None outside decode_beam)
         self.max_rows_per_launch = 16 if dtype == torch.float32 else 96   # rows one skinny-GEMM launch covers
 
+        self._W = W          # kept (by reference) for attach_lora: the engine itself only holds packed copies
+        self.lora = False
         self.layers = []
         for i in range(layers):
             p = f"gpt.h.{i}."
@@ -94,6 +96,53 @@ class GPTEngine:
         self.weight_bytes = sum(t.numel() * t.element_size() for l in self.layers for t in
                                 (l["w_qkv"], l["w_o"], l["w_fc"], l["w_pr"])) + self.w_head.numel()
 
+    # ------------------------------------------------------------------------------------------------ runtime LoRA
+    def attach_lora(self, adapters: dict, scaling: float):
+        """Unmerged LoRA adapters at run time (the reference always merges them before saving, train.py:802-832; this is the
+        north_star's "LoRA A.B fused into the output projection").  `adapters`: {"gpt.h.{i}.attn.c_proj": (A, B), ...} with
+        the peft tensors of a Conv1D target (fan_in_fan_out=True): A = lora_A.weight [r, in], B = lora_B.weight [out, r];
+        y = x W + (x A^T) B^T * scaling, scaling = lora_alpha / r (train.py:555-563).
+          * output projections (attn.c_proj, mlp.c_proj): stay UNMERGED in the decode loop -- A^T * scaling rides along as
+            16*ceil(r/16) extra output columns of the packed weight (the split-K GEMM produces x A next to x W), and the
+            [residual-reduce + LayerNorm] launch that follows adds (x A) B^T: no extra launch, no merged weight copy;
+          * attn.c_attn / mlp.c_fc adapters, and every adapter in the large-M passes (prefill, latent), are merged into
+            packed copies here (their GEMMs have no reduce stage to carry the correction)."""
+        dev, T, D = self.device, self.dtype, self.D
+        W = self._W
+
+        def f32(k):
+            return W[k].detach().to(dev, torch.float32)
+
+        def packed(w):
+            return nat.pack_weight(w.to(T).contiguous())
+
+        for i, l in enumerate(self.layers):
+            p = f"gpt.h.{i}."
+            for name, wkey in (("attn.c_attn", "w_qkv"), ("mlp.c_fc", "w_fc")):
+                if p + name in adapters:
+                    A, Bm = (t.detach().to(dev, torch.float32) for t in adapters[p + name])
+                    l[wkey] = packed(f32(p + name + ".weight") + (A.t() @ Bm.t()) * scaling)
+            for name, wkey, tag in (("attn.c_proj", "w_o", "o"), ("mlp.c_proj", "w_pr", "pr")):
+                if p + name not in adapters:
+                    continue
+                A, Bm = (t.detach().to(dev, torch.float32) for t in adapters[p + name])
+                r = A.shape[0]
+                if r > 64:
+                    raise ValueError("runtime LoRA supports rank <= 64")
+                rp = (r + 15) // 16 * 16
+                base = f32(p + name + ".weight")                                  # [K, D]
+                ext = torch.zeros(base.shape[0], D + rp, dtype=torch.float32, device=dev)
+                ext[:, :D] = base
+                ext[:, D:D + r] = A.t() * scaling
+                l[wkey + "_lora"] = packed(ext)                                   # decode: [W | A^T s], N = D + rp
+                l["lora_b_" + tag] = Bm.t().contiguous()                          # [r, D] fp32, applied by ln_reduce
+                l["lora_n_" + tag] = D + rp
+                l[wkey + "_merged"] = packed(base + (A.t() @ Bm.t()) * scaling)   # large-M passes
+        self.lora = True
+        self._graphs.clear()
+        if hasattr(self, "slab") and self.slab.shape[2] < D + 64:
+            self._cap_b = self._cap_s = 0   # the slabs need room for the extra columns: reallocate on the next prefill
+
     def fork(self) -> "GPTEngine":
         """A second engine over the SAME packed weights (read-only, shared) with its own KV cache, scratch buffers, loop
         state and captured graphs: what a concurrent request needs (infer.RequestPool)."""
@@ -125,7 +174,7 @@ class GPTEngine:
         self.a = torch.zeros(Bp, self.D, dtype=T, device=dev)
         self.f = torch.zeros(Bp, 4 * self.D, dtype=T, device=dev)
         self.xn = torch.zeros(Bp, self.D, dtype=T, device=dev)
-        self.slab = torch.zeros(self.KSPLIT, B, self.D, dtype=torch.float32, device=dev)
+        self.slab = torch.zeros(self.KSPLIT, B, self.D + 64, dtype=torch.float32, device=dev)   # + runtime-LoRA columns
         self.logits = torch.zeros(B, self.V, dtype=torch.float32, device=dev)
         self.tokens = torch.zeros(B, dtype=torch.int32, device=dev)
         self.finished = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -156,10 +205,10 @@ class GPTEngine:
                 nat.attn_prefill(qkv, att, kc, vc, pad, B, S, H, self._cap_s)
             else:
                 nat.attn_prefill_packed(qkv, att, kc, vc, row_off, cache_shift, B, S, H, self._cap_s)
-            nat.gemm_conv(T, 1, M, M, D, D, l["w_o"], att, h, bias=l["b_o"], y_f32=True, resid=h)
+            nat.gemm_conv(T, 1, M, M, D, D, l.get("w_o_merged", l["w_o"]), att, h, bias=l["b_o"], y_f32=True, resid=h)
             nat.layernorm(h, l["ln2"][0], l["ln2"][1], xn)
             nat.gemm_conv(T, 1, M, M, D, 4 * D, l["w_fc"], xn, ff, bias=l["b_fc"], act=1)
-            nat.gemm_conv(T, 1, M, M, 4 * D, D, l["w_pr"], ff, h, bias=l["b_pr"], y_f32=True, resid=h)
+            nat.gemm_conv(T, 1, M, M, 4 * D, D, l.get("w_pr_merged", l["w_pr"]), ff, h, bias=l["b_pr"], y_f32=True, resid=h)
         return h
 
     def _head(self, h_rows, B):
@@ -257,7 +306,7 @@ class GPTEngine:
         step, pos = self.state[0:1], self.state[1:2]
         h, xn, pa = self.h[:B], self.xn, self.pa   # xn / a / f: whole buffers (packed layout is addressed from the base)
         slab = self.slab.view(-1)[: KS * B * D].view(KS, B, D)  # [ks][B][D] on a contiguous prefix of the buffer
-        tail = self.decode_mode == "tail" and B <= self.max_rows_per_launch
+        tail = self.decode_mode == "tail" and B <= self.max_rows_per_launch and not self.lora   # tails carry no LoRA term
         if bump is None:
             bump = getattr(self, "_pending_bump", False)
         self._pending_bump = False
@@ -280,14 +329,25 @@ class GPTEngine:
                 nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], None, x=self.f, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS, x_packed=pa,
                                 tail=self._tail(2 * i + 1, h, xn, l["b_pr"], nxt, nxt2))
             else:
-                nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS, x_packed=pa)
-                nat.ln_reduce(h, l["ln2"][0], l["ln2"][1], xn, slab=slab, nslab=KS, bias=l["b_o"], y_packed=pa)
+                # out-projection: split-K slabs; with a runtime adapter the GEMM also produces x A in extra columns and the
+                # reduce launch adds (x A) B^T
+                n_o = l.get("lora_n_o", D)
+                sl_o = self.slab.view(-1)[: KS * B * n_o].view(KS, B, n_o)
+                nat.gemm_skinny(T, B, n_o, D, l.get("w_o_lora", l["w_o"]), None, x=self.a, epi=nat.EPI_SLAB_F32, yf=sl_o, ksplit=KS,
+                                x_packed=pa)
+                nat.ln_reduce(h, l["ln2"][0], l["ln2"][1], xn, slab=sl_o, nslab=KS, bias=l["b_o"], y_packed=pa,
+                              slab_stride=n_o, lora_b=l.get("lora_b_o"))
                 nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f, x_packed=pa, y_packed=pa)
-                nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], None, x=self.f, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS, x_packed=pa)
+                n_p = l.get("lora_n_pr", D)
+                sl_p = self.slab.view(-1)[: KS * B * n_p].view(KS, B, n_p)
+                nat.gemm_skinny(T, B, n_p, 4 * D, l.get("w_pr_lora", l["w_pr"]), None, x=self.f, epi=nat.EPI_SLAB_F32, yf=sl_p, ksplit=KS,
+                                x_packed=pa)
                 if last:
-                    nat.ln_reduce(h, nxt[0], nxt[1], xn, slab=slab, nslab=KS, bias=l["b_pr"], w2=nxt2[0], b2=nxt2[1], y_packed=pa)
+                    nat.ln_reduce(h, nxt[0], nxt[1], xn, slab=sl_p, nslab=KS, bias=l["b_pr"], w2=nxt2[0], b2=nxt2[1], y_packed=pa,
+                                  slab_stride=n_p, lora_b=l.get("lora_b_pr"))
                 else:
-                    nat.ln_reduce(h, nxt[0], nxt[1], xn, slab=slab, nslab=KS, bias=l["b_pr"], y_packed=pa)
+                    nat.ln_reduce(h, nxt[0], nxt[1], xn, slab=sl_p, nslab=KS, bias=l["b_pr"], y_packed=pa, slab_stride=n_p,
+                                  lora_b=l.get("lora_b_pr"))
         nat.gemm_skinny(T, B, self.V, D, self.w_head, self.b_head, x=self.xn, epi=nat.EPI_STORE_F32, yf=self.logits, x_packed=pa)
 
     def _poll(self):

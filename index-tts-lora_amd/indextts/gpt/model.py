@@ -193,6 +193,14 @@ class UnifiedVoice:
         out = self.engine.decode(max_new, sp, force_stop=force_stop, return_logits=return_logits)
         return out
 
+    def attach_lora(self, adapters: dict, scaling: float):
+        """Unmerged LoRA adapters at run time (peft tensors of the Conv1D targets attn.c_attn / attn.c_proj / mlp.c_fc /
+        mlp.c_proj, train.py:555-563): see GPTEngine.attach_lora.  The reference itself only ever loads merged weights."""
+        if self.engine is None:
+            raise RuntimeError("call post_init_gpt2_config() first")
+        self.engine.attach_lora(adapters, scaling)
+        return self
+
     def replica(self) -> "UnifiedVoice":
         """Same weights (shared tensors), separate decode state: see GPTEngine.fork()."""
         import copy

@@ -378,3 +378,45 @@ def test_packed_activations_and_tail_mode_give_the_same_bits(dtype):
         outs.append(eng.decode(20, sp, return_logits=True))
     for codes, logits in outs[1:]:
         assert torch.equal(codes, outs[0][0]) and torch.equal(logits, outs[0][1])
+
+
+def test_runtime_lora_equals_merged_checkpoint():
+    """Unmerged LoRA adapters attached at run time (GPTEngine.attach_lora: A rides as extra columns of the two output
+    projections, B is applied by the reduce launch; c_attn / c_fc adapters are merged at attach time) against the way the
+    reference ships fine-tuned models: the adapters merged into the base weights before loading (train.py:802-832).
+    fp32, 2 layers: logits of the prefill and of 10 greedy decode steps agree to 1e-3; same greedy codes."""
+    from indextts.gpt.model import UnifiedVoice
+    cfg = dict(weights.reference_config()["gpt"], layers=2)
+    sd = weights.gpt_state_dict(2)
+    g = torch.Generator().manual_seed(3)
+    r, scaling = 8, 2.0
+    adapters = {}
+    merged = dict(sd)
+    for i in range(2):
+        for name in ("attn.c_attn", "attn.c_proj", "mlp.c_fc", "mlp.c_proj"):
+            key = f"gpt.h.{i}.{name}"
+            k_in, n_out = sd[key + ".weight"].shape
+            A = torch.randn(r, k_in, generator=g) * 0.02
+            Bm = torch.randn(n_out, r, generator=g) * 0.02
+            adapters[key] = (A, Bm)
+            merged[key + ".weight"] = sd[key + ".weight"] + (A.t() @ Bm.t()) * scaling
+    cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
+    text = torch.from_numpy(np.load(os.path.join(G, "gpt_small.npz"))["text"]).to(DEV)
+    kw = dict(do_sample=False, num_beams=1, repetition_penalty=10.0, max_generate_length=10, return_logits=True)
+    outs = []
+    for state, lora in ((merged, None), (sd, adapters)):
+        m = UnifiedVoice(**cfg)
+        m.load_state_dict(state)
+        m.to(DEV).to(torch.float32).post_init_gpt2_config(kv_cache=True)
+        if lora is not None:
+            m.attach_lora(lora, scaling)
+            assert m.engine.lora and "w_o_lora" in m.engine.layers[0] and m.engine.layers[1]["lora_n_pr"] == 1280 + 16
+        outs.append(m.inference_speech(cond_mel, text, **kw))
+    (c0, l0), (c1, l1) = outs
+    assert (l0 - l1).abs().max().item() < 1e-3
+    assert torch.equal(c0, c1)
+    base = UnifiedVoice(**cfg)
+    base.load_state_dict(sd)
+    base.to(DEV).to(torch.float32).post_init_gpt2_config(kv_cache=True)
+    cb, lbase = base.inference_speech(cond_mel, text, **kw)
+    assert (lbase - l0).abs().max().item() > 1e-2, "the adapters must actually change the logits"

@@ -547,6 +547,48 @@ def test_packed_activation_layout_end_to_end(nat, dtype, M):
     assert torch.equal(nat.unpack_activation(a_pk, M, D), a_rm)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("r", [4, 16, 24])
+def test_runtime_lora_fused_into_output_projection(nat, dtype, r):
+    """y = x W + (x A^T) B^T s  with A^T s carried as extra output columns of the split-K projection and B^T applied by the
+    [residual-reduce + LayerNorm] launch (itts_ln_reduce lora_b): equal to the same pipeline on the MERGED weight W + A^T B^T s
+    up to rounding of the merged weight to T, and to the fp32 formula."""
+    M, K, D, KSP, s_ = 32, 5120, 1280, 3, 2.0
+    x = rnd(M, K, seed=300).to(dtype)
+    W = rnd(K, D, seed=301) * 0.03
+    A = rnd(r, K, seed=302) * 0.05          # peft lora_A.weight [r, in]
+    Bm = rnd(D, r, seed=303) * 0.05         # peft lora_B.weight [out, r]
+    bias = rnd(D, seed=304)
+    lw, lb = 1.0 + 0.1 * rnd(D, seed=305), 0.1 * rnd(D, seed=306)
+    h0 = rnd(M, D, seed=307, scale=2.0)
+    rp = (r + 15) // 16 * 16
+    ext = torch.zeros(K, D + rp, device=DEV)
+    ext[:, :D] = W
+    ext[:, D:D + r] = A.t() * s_
+    wp_ext = nat.pack_weight(ext.to(dtype))
+    slab = torch.zeros(KSP, M, D + rp, device=DEV)
+    nat.gemm_skinny(dtype, M, D + rp, K, wp_ext, None, x=x, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KSP)
+    h, y = h0.clone(), torch.empty(M, D, dtype=dtype, device=DEV)
+    nat.ln_reduce(h, lw, lb, y, slab=slab, nslab=KSP, bias=bias, slab_stride=D + rp, lora_b=Bm.t().contiguous())
+    xf = x.float()
+    xa = xf @ (A.t() * s_).to(dtype).float()
+    h_ref = h0 + bias + xf @ W.to(dtype).float() + xa @ Bm.t()
+    tol = 2e-3 if dtype == torch.float32 else 3e-2
+    assert (h - h_ref).abs().max().item() < tol
+    assert (y.float() - F.layer_norm(h_ref, (D,), lw, lb, 1e-5)).abs().max().item() < (2e-3 if dtype == torch.float32 else 5e-2)
+    # the merged-weight pipeline gives the same residual stream within the rounding of the merged weight
+    wp_m = nat.pack_weight((W + (A.t() @ Bm.t()) * s_).to(dtype))
+    slab_m = torch.zeros(KSP, M, D, device=DEV)
+    nat.gemm_skinny(dtype, M, D, K, wp_m, None, x=x, epi=nat.EPI_SLAB_F32, yf=slab_m, ksplit=KSP)
+    h_m, y_m = h0.clone(), torch.empty(M, D, dtype=dtype, device=DEV)
+    nat.ln_reduce(h_m, lw, lb, y_m, slab=slab_m, nslab=KSP, bias=bias)
+    assert (h - h_m).abs().max().item() < (2e-3 if dtype == torch.float32 else 0.25)
+    # and without an adapter the extra arguments change nothing
+    h_p, y_p = h0.clone(), torch.empty(M, D, dtype=dtype, device=DEV)
+    nat.ln_reduce(h_p, lw, lb, y_p, slab=slab_m, nslab=KSP, bias=bias, slab_stride=D)
+    assert torch.equal(h_p, h_m) and torch.equal(y_p, y_m)
+
+
 def test_gemm_skinny_qkv_cache_epilogue_many_rows(nat):
     """QKV epilogue at 96 rows (batch 32 x 3 beams): q rows, and k/v scattered into the cache at *pos, per head."""
     dtype, M, H, smax, pos = torch.bfloat16, 96, 20, 64, 17
