@@ -105,6 +105,8 @@ class IndexTTS:
         else:
             self.gpt_path = None
 
+        self._cache_conds = None
+        self._feat_graphs = {}
         self.gpt = UnifiedVoice(**self.cfg.gpt)
         if _weights is None:
             load_checkpoint(self.gpt, self.gpt_path)
@@ -134,8 +136,6 @@ class IndexTTS:
 
         self.cache_audio_prompt = None
         self.cache_cond_mel = None
-        self._feat_graphs = {}
-        self._cache_conds = None
         self._cache_spk = None
         self.gr_progress = None
         self.model_version = self.cfg.version if "version" in self.cfg else None
@@ -148,6 +148,37 @@ class IndexTTS:
             except Exception as e:  # noqa: BLE001
                 print(f">> [error] could not read speaker info: {e}")
         self.mel_extractor = MelSpectrogramFeatures()
+
+    # `tts.gpt` is replaceable, as the reference's callers do when they hot-swap a fine-tuned checkpoint (api.py:118-175,
+    # webui.py:107-160: build UnifiedVoice(**tts.cfg.gpt), load_checkpoint, .to / .eval / .half, post_init_gpt2_config, then
+    # `tts.gpt = new_gpt; tts.gpt_path = path`).  Everything derived from the old weights goes with it: cached conditioning
+    # latents and the captured conditioner graph.
+    @property
+    def gpt(self):
+        return self._gpt
+
+    @gpt.setter
+    def gpt(self, module):
+        self._gpt = module
+        self._cache_conds = None
+        self._feat_graphs = {}
+
+    @gpt.deleter
+    def gpt(self):   # `del tts.gpt` before the swap (api.py:160)
+        self._gpt = None
+
+    def reload_gpt(self, model_path: str):
+        """The reference's model hot-swap (api.py:137-169) as one call: a new UnifiedVoice from `model_path` in this
+        instance's precision replaces `self.gpt`.  Returns the config dict load_checkpoint found next to the file."""
+        new_gpt = UnifiedVoice(**self.cfg.gpt)
+        info = load_checkpoint(new_gpt, model_path)
+        new_gpt = new_gpt.to(self.device).to(self.gpt_dtype).eval()
+        new_gpt.post_init_gpt2_config(use_deepspeed=False, kv_cache=True, half=self.gpt_dtype != torch.float32)
+        del self.gpt
+        self.torch_empty_cache()
+        self.gpt = new_gpt
+        self.gpt_path = model_path
+        return info
 
     @classmethod
     def from_weights(cls, cfg, gpt_state_dict, bigvgan_state_dict, device="cuda:0", is_fp16=True, precision_config=None):
@@ -162,7 +193,6 @@ class IndexTTS:
         import copy
         r = copy.copy(self)
         r.gpt = self.gpt.replica()
-        r._feat_graphs = {}
         r.cache_audio_prompt = r.cache_cond_mel = r._cache_conds = r._cache_spk = None
         return r
 

@@ -388,3 +388,86 @@ def test_on_disk_constructor_cli_and_speaker_conditions(tmp_path, capsys):
         os.chdir(cwd)
     with wave.open(out, "rb") as w:
         assert (w.getframerate(), w.getnchannels(), w.getsampwidth()) == (24000, 1, 2) and w.getnframes() % 1024 == 0 and w.getnframes() > 0
+
+
+def _model_dir(tmp, seed_shift=0.0):
+    """config.yaml + gpt.pth + bigvgan_generator.pth + bpe.model + a 44.1 kHz stereo prompt in `tmp` (2-layer GPT)."""
+    import yaml
+
+    from indextts.utils.audio import write_pcm16
+    cfg = weights.reference_config()
+    cfg["gpt"]["layers"] = 2
+    gsd = weights.gpt_state_dict(2)
+    with open(os.path.join(tmp, "config.yaml"), "w") as f:
+        yaml.safe_dump(cfg, f)
+    torch.save({"model": gsd}, os.path.join(tmp, "gpt.pth"))
+    other = {k: (v * 1.5 if k.endswith("mel_head.weight") or k.endswith("c_fc.weight") else v) for k, v in gsd.items()}
+    os.makedirs(os.path.join(tmp, "ft"), exist_ok=True)
+    torch.save(other, os.path.join(tmp, "ft", "gpt_finetuned.pth"))          # a bare state dict: the other accepted format
+    torch.save({"generator": weights.bigvgan_state_dict()}, os.path.join(tmp, "bigvgan_generator.pth"))
+    _train_bpe(tmp)
+    t = np.arange(int(44100 * 1.5)) / 44100.0
+    stereo = np.stack([0.3 * np.sin(2 * np.pi * 220 * t), 0.2 * np.sin(2 * np.pi * 330 * t)], 1)
+    prompt = os.path.join(tmp, "prompt.wav")
+    write_pcm16(prompt, (stereo * 32767).astype(np.int16), 44100)
+    return prompt
+
+
+def test_rest_api_and_model_hot_swap(tmp_path):
+    """The callers' row: the reference's REST surface (api.py:35-300) over this build -- /tts with a
+    JSON body, a urlencoded form and a multipart upload, X-Seed reproducibility, the status codes, /models, and
+    /model/reload hot-swapping tts.gpt (api.py:118-175) with the caches derived from the old weights dropped; plus the WebUI
+    hook `tts.gr_progress(value, desc=...)` (webui.py:195, infer.py:591-593)."""
+    import io
+    import wave
+    import warnings
+
+    from starlette.testclient import TestClient
+
+    import api as itts_api
+    from indextts.infer import IndexTTS
+    tmp = str(tmp_path)
+    prompt = _model_dir(tmp)
+    tts = IndexTTS(cfg_path=os.path.join(tmp, "config.yaml"), model_dir=tmp, is_fp16=True)
+    calls = []
+    tts.gr_progress = lambda value, desc=None: calls.append((value, desc))
+    app = itts_api.create_app(tts, model_dir=tmp, config_path=os.path.join(tmp, "config.yaml"),
+                              finetune_dir=os.path.join(tmp, "ft"), output_dir=os.path.join(tmp, "out"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        c = TestClient(app)
+        body = dict(text="你好世界. HELLO WORLD!", prompt_audio_path=prompt, infer_mode="normal", seed=7, max_mel_tokens=9)
+        r1 = c.post("/tts", json=body)
+        assert r1.status_code == 200, r1.text
+        assert r1.headers["content-type"] == "audio/wav" and r1.headers["x-seed"] == "7"
+        with wave.open(io.BytesIO(r1.content), "rb") as w:
+            assert (w.getframerate(), w.getnchannels(), w.getsampwidth()) == (24000, 1, 2) and w.getnframes() % 1024 == 0
+        assert calls and calls[0][0] == 0.1 and all(0.0 <= v <= 1.0 for v, _ in calls)   # progress hook was driven
+        r2 = c.post("/tts", json=body)
+        assert r2.content == r1.content, "same seed, same request -> same audio"
+        r3 = c.post("/tts", json=dict(body, seed=8))
+        assert r3.status_code == 200 and r3.headers["x-seed"] == "8" and r3.content != r1.content
+        # the reference's form encodings: urlencoded, and multipart with an uploaded prompt
+        r4 = c.post("/tts", data={k: str(v) for k, v in body.items()})
+        assert r4.status_code == 200 and r4.content == r1.content
+        with open(prompt, "rb") as f:
+            r5 = c.post("/tts", data={"text": body["text"], "infer_mode": "fast", "seed": "7", "max_mel_tokens": "9"},
+                        files={"prompt_audio": ("p.wav", f.read(), "audio/wav")})
+        assert r5.status_code == 200 and r5.content[:4] == b"RIFF"
+        # status codes of api.py:209-226
+        assert c.post("/tts", json=dict(text="hi")).status_code == 400
+        assert c.post("/tts", json=dict(text="hi", prompt_audio_path=os.path.join(tmp, "nope.wav"))).status_code == 404
+        assert c.post("/tts", json=dict(prompt_audio_path=prompt)).status_code == 422
+        # /models and the hot swap
+        m = c.get("/models").json()
+        assert m["current_model"] == "gpt.pth" and [x["type"] for x in m["models"]] == ["base", "finetune"]
+        assert c.post("/model/reload", json={"model_filename": "missing.pth"}).status_code == 404
+        old_engine = tts.gpt.engine
+        rr = c.post("/model/reload", json={"model_filename": m["models"][1]["filename"]})
+        assert rr.status_code == 200 and rr.json()["status"] == "success"
+        assert tts.gpt.engine is not old_engine and tts.gpt_path.endswith("gpt_finetuned.pth") and tts._cache_conds is None
+        assert c.get("/models").json()["current_model"] == "gpt_finetuned.pth"
+        r6 = c.post("/tts", json=body)
+        assert r6.status_code == 200 and r6.content != r1.content, "the swapped checkpoint must be the one that speaks"
+        assert c.post("/model/reload", json={"model_filename": "gpt.pth"}).status_code == 200
+        assert c.post("/tts", json=body).content == r1.content, "swapping back restores the original voice bit for bit"
