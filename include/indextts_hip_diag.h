@@ -12,7 +12,10 @@ extern "C" {
 #endif
 
 /* tuning overrides: key 1 = column tiles per skinny-GEMM workgroup, key 2 = waves per skinny-GEMM workgroup, key 3 =
- * plain-GEMM kernel override (0 restores the built-in heuristic), key 4 = waves per decode-attention workgroup (4 or 8) */
+ * plain-GEMM kernel override (0 restores the built-in heuristic), key 4 = waves per decode-attention workgroup (4 or 8),
+ * key 5 = ablation BIT MASK of the tiled convolution kernel for timing experiments (results are WRONG when non-zero):
+ * 1 = no weight-fragment loads, 2 = no MFMA, 4 = no LDS fragment reads, 8 = no activation prefetch after the first chunk,
+ * 16 = no epilogue */
 int itts_debug_set(int key, int value);
 
 /* every later itts_gemm_skinny launch writes 16 x u64 per workgroup (linear id = blockIdx.y * gridDim.x + blockIdx.x) to
@@ -21,6 +24,11 @@ int itts_debug_set(int key, int value);
  * s_memtime, [11] / [12] s_memrealtime at entry / exit (100 MHz, comparable across workgroups and launches), [13] XCC id.
  * NULL switches the stamps off. */
 int itts_debug_stamps(void* buf);
+
+/* the same for gemm_conv_kernel (the tiled convolution): 16 x u64 per workgroup: s_memtime at 0 entry, 1 first activation
+ * prefetch issued, 2 first chunk staged in LDS, 3 all MFMA steps done, 4 epilogue issued, 5 stores drained; [12] HW_ID,
+ * [13] XCC id, [14] / [15] s_memrealtime at entry / exit */
+int itts_debug_stamps_conv(void* buf);
 
 /* the same for itts_sample: 16 x u64 per batch row: s_memtime at 0 entry, 1 logits + bitmap done, 2 processed scores in LDS,
  * 3 threshold known, 4 candidates compacted, 5 rank sort done, 6 token drawn, 7 bookkeeping done; [14] / [15] s_memrealtime

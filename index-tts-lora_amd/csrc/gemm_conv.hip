@@ -35,14 +35,30 @@ struct ConvParams {
   float scale;
   int NT, KT;
   int MB, NB, GM;  // m-blocks per batch element, n-blocks, m-blocks per L2 group (XCD-aware tile order)
+  int exp;         // diagnostic build only (itts_debug_set key 5): ablation switches of the tiled kernel, 0 in the product
+#if ITTS_STAMPS
+  unsigned long long* stamps;   // diagnostic build: 16 x u64 per workgroup (itts_debug_stamps_conv)
+#endif
 };
+
+#if ITTS_STAMPS
+unsigned long long* g_stamp_buf_conv = nullptr;
+#define CSTAMP(i) ITTS_STAMP_IF(p.stamps != nullptr, i)
+#else
+#define CSTAMP(i) do { } while (0)
+#endif
+#if ITTS_DIAG
+int g_conv_exp = 0;
+#define ITTS_CONV_EXP(p) ((p).exp)
+#else
+#define ITTS_CONV_EXP(p) 0
+#endif
 
 // XCD-aware tile order (speed only): workgroups are dealt round-robin to the 8 XCDs, so give each XCD a CONTIGUOUS
 // run of the tile sequence, and order the sequence so that 32 consecutive tiles form a compact GM x (32/GM) patch of
 // the output -- its activation rows and weight columns then stay in that XCD's 4-MiB L2 instead of being re-fetched
 // from the Infinity Cache by every tile.
-__device__ __forceinline__ void tile_of_workgroup(const ConvParams& p, int& mblk, int& nblk, int& b) {
-  const int bid = blockIdx.x, nwg = gridDim.x;
+__device__ __forceinline__ void tile_of_workgroup(const ConvParams& p, int bid, int nwg, int& mblk, int& nblk, int& b) {
   const int xcd = bid & 7, q = bid >> 3, base = nwg >> 3, rem = nwg & 7;
   const int L = xcd * base + min(xcd, rem) + q;
   const int MBt = p.MB * p.B;
@@ -184,6 +200,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
   }
 }
 
+static int conv_num_cus() {
+  static int n = 0;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+    (void)hipGetLastError();
+  });
+  return n;
+}
+
 // CK = k-steps of channels staged per chunk (2 for convolutions, whose taps multiply the MFMA work per chunk; 4 for
 // plain GEMMs).  HALO = compile-time bound on (taps-1)*dil (0 for plain GEMMs) that sizes the staging registers.
 // Waves per SIMD the register budget is sized for: 8-wave workgroups put 2 waves on each SIMD (one wave's MFMAs run under
@@ -194,6 +223,13 @@ struct ConvOcc {
   static constexpr int WPS = (NW == 8) ? 2 : ((TM * TN <= 16) ? 2 : 1);
 };
 
+// PERSISTENT, cross-tile pipelined: the grid is one round of resident workgroups (launch_conv asks the occupancy API) and
+// a workgroup walks the tile sequence with stride gridDim.x.  The activation rows of the NEXT tile's first chunk are
+// requested while the current tile's last chunk is multiplied, the weight-fragment cursor runs two steps ahead straight
+// across the tile boundary, and the epilogue's stores drain under the next tile's work.  Measured before this change
+// (profiles/r02_conv_ablation.txt): with one tile per workgroup and one workgroup per CU (177 VGPRs), [launch + HBM
+// latency of the first chunk] and [epilogue] sat un-overlapped around every tile -- removing MFMAs, weight loads and LDS
+// reads TOGETHER only took 16 % off, the per-tile skeleton was 60-85 % of the kernel.
 template <typename T, int WM, int WN, int TM, int TN, int CK, int HALO>
 __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void gemm_conv_kernel(ConvParams p) {
   typedef Elem<T> EL;
@@ -208,35 +244,43 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#if ITTS_STAMPS
+  unsigned long long st_[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) st_[i] = 0;
+  if (p.stamps != nullptr && tid == 0) st_[14] = __builtin_amdgcn_s_memrealtime();
+#endif
+  CSTAMP(0);
   const int g = lane >> 4, r = lane & 15;
   const int wm = wave / WN, wn = wave % WN;
-  int mblk, nblk, b;
-  tile_of_workgroup(p, mblk, nblk, b);
-  const int t0 = mblk * BM;
-  const int nt0 = nblk * (BN / 16) + wn * TN;
+  const int total = p.MB * p.NB * p.B;         // tiles; tile L of the XCD-aware order is handled by workgroup L % gridDim.x
   const int HR = BM + (p.taps - 1) * p.dil;   // staged rows
   const int NC = (p.KT + CK - 1) / CK;        // channel chunks
   // Range-checked buffer descriptors: out-of-range rows (conv zero padding, M tail) and disabled lanes read zeros with
   // no branch around the load, so the compiler keeps counted waits instead of draining the queue at every join.
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T*>((const T*)p.x + (int64_t)b * p.x_bstride), 0, (int)((int64_t)p.Tin * p.Cin * (int)sizeof(T)), 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.wp), 0, (int)((int64_t)p.taps * p.NT * p.KT * 1024), 0x00020000);
   constexpr unsigned OOB = 0xFFFFFFFFu;
 
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  struct Tile {
+    int b, t0, nt0;
+  };
+  auto tile_at = [&](int L) {
+    int mblk, nblk, b;
+    tile_of_workgroup(p, L, total, mblk, nblk, b);
+    return Tile{b, mblk * BM, nblk * (BN / 16) + wn * TN};
+  };
 
+  f32x4 acc[TM][TN];
   frag stg[MAXST];
-  auto prefetch_a = [&](int c) {
+  auto prefetch_a = [&](int c, const Tile& tl) {
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>((const T*)p.x + (int64_t)tl.b * p.x_bstride), 0, (int)((int64_t)p.Tin * p.Cin * (int)sizeof(T)), 0x00020000);
 #pragma unroll
     for (int q = 0; q < MAXST; ++q) {
       int idx = tid + q * NTH;
       int i = idx / SEGS, seg = idx - i * SEGS;
-      int tin = t0 + p.off0 + i;
+      int tin = tl.t0 + p.off0 + i;
       int col = c * (CK * KS) + seg * E;
       bool ok = (i < HR) && (col < p.Cin);
       unsigned off = ok ? (unsigned)((tin * p.Cin + col) * (int)sizeof(T)) : OOB;  // tin < 0 wraps to a huge offset
@@ -251,32 +295,52 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
       if (i < HR) st16(lds + i * ROWB + seg * 16, stg[q]);
     }
   };
-  // Flat step space: step = (chunk c, tap j, k-step kk within the chunk); weight block = ((j*NT + nt)*KT + c*CK + kk).
-  auto fetch_b = [&](frag (&bf)[TN], int c, int j, int kk) {
+  // Flat step space: step = (tile, chunk c, tap j, k-step kk within the chunk); weight block = ((j*NT + nt)*KT + c*CK + kk).
+  // The fetch cursor (fc, fj, fk) belongs to the tile whose column block is f_nt0; past the last tile f_ok is false.
+  int fc = 0, fj = 0, fk = 0, f_nt0 = 0, f_next = 0;
+  bool f_ok = false;
+  auto fetch_b = [&](frag (&bf)[TN]) {
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-      int nt = nt0 + tn;
-      bool ok = (nt < p.NT) && (c < NC);
-      unsigned off = ok ? (unsigned)((((j * p.NT + nt) * p.KT + c * CK + kk) * 64 + lane) * 16) : OOB;
+      int nt = f_nt0 + tn;
+      bool ok = (nt < p.NT) && f_ok;
+      if (ITTS_CONV_EXP(p) & 1) ok = false;   // ablation bit 0: nobody loads weight fragments
+      unsigned off = ok ? (unsigned)((((fj * p.NT + nt) * p.KT + fc * CK + fk) * 64 + lane) * 16) : OOB;
       bf[tn] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0));
     }
-  };
-  auto advance = [&](int& c, int& j, int& kk) {
-    int nkk = min(CK, p.KT - c * CK);
-    if (++kk >= nkk) {
-      kk = 0;
-      if (++j == p.taps) {
-        j = 0;
-        ++c;
+    // advance; at the end of a tile the cursor moves on to the column block of the workgroup's next tile
+    int nkk = min(CK, p.KT - fc * CK);
+    if (++fk >= nkk) {
+      fk = 0;
+      if (++fj == p.taps) {
+        fj = 0;
+        if (++fc == NC) {
+          fc = 0;
+          f_ok = f_next < total;
+          if (f_ok) f_nt0 = tile_at(f_next).nt0;
+          f_next += gridDim.x;
+        }
       }
     }
   };
   auto load_a = [&](frag (&af)[TM], int j, int kk) {
+    if (ITTS_CONV_EXP(p) & 4) {   // ablation bit 2: no LDS fragment reads
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) af[tm] = zero_frag<frag>();
+      return;
+    }
     const unsigned char* abase = lds + (wm * TM * 16 + r + j * p.dil) * ROWB + kk * 64 + g * 16;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) af[tm] = ld16<frag>(abase + tm * 16 * ROWB);
   };
   auto mma_all = [&](frag (&af)[TM], frag (&bf)[TN]) {
+    if (ITTS_CONV_EXP(p) & 2) {   // ablation bit 1: no MFMA (operands kept alive)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) asm volatile("" ::"v"(af[tm]));
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) asm volatile("" ::"v"(bf[tn]));
+      return;
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -285,47 +349,88 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
 
   frag b0[TN], b1[TN], b2[TN];
   frag a0[TM], a1[TM];
-  int fc = 0, fj = 0, fk = 0;  // cursor of the next weight fetch (runs two steps ahead, across chunk boundaries)
-  fetch_b(b0, fc, fj, fk);
-  advance(fc, fj, fk);
-  fetch_b(b1, fc, fj, fk);
-  advance(fc, fj, fk);
-  prefetch_a(0);
-  for (int c = 0; c < NC; ++c) {
-    __syncthreads();  // everyone finished reading the previous chunk
-    commit_a();
-    __syncthreads();
-    if (c + 1 < NC) prefetch_a(c + 1);
-    const int nkk = min(CK, p.KT - c * CK);
-    const int nit = p.taps * nkk;
-    // A fragments ping-pong between two register sets: the LDS reads of step it+1 are in flight under the MFMAs of step it
-    int j = 0, kk = 0;
-    load_a(a0, 0, 0);
-    for (int it = 0; it < nit; it += 2) {
-      int j1 = j, k1 = kk + 1;
-      if (k1 == nkk) { k1 = 0; ++j1; }
-      fetch_b(b2, fc, fj, fk);
-      advance(fc, fj, fk);
-      if (it + 1 < nit) load_a(a1, j1, k1);
-      mma_all(a0, b0);
+  int L = blockIdx.x;
+  if (L >= total) return;
+  Tile cur = tile_at(L);
+  f_nt0 = cur.nt0;
+  f_ok = true;
+  f_next = L + gridDim.x;
+  fetch_b(b0);
+  fetch_b(b1);
+  prefetch_a(0, cur);
+  CSTAMP(1);
+  for (; L < total; L += gridDim.x) {
+    const bool has_next = L + (int)gridDim.x < total;
+    Tile nxt = cur;
+    if (has_next) nxt = tile_at(L + gridDim.x);
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) { b0[tn] = b1[tn]; b1[tn] = b2[tn]; }
-      if (it + 1 < nit) {
-        int j2 = j1, k2 = k1 + 1;
-        if (k2 == nkk) { k2 = 0; ++j2; }
-        fetch_b(b2, fc, fj, fk);
-        advance(fc, fj, fk);
-        if (it + 2 < nit) load_a(a0, j2, k2);
-        mma_all(a1, b0);
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < NC; ++c) {
+      __syncthreads();  // everyone finished reading the previous chunk
+      commit_a();
+      __syncthreads();
+#if ITTS_STAMPS
+      if (c == 0 && L == (int)blockIdx.x) CSTAMP(2);
+#endif
+      if (!(ITTS_CONV_EXP(p) & 8)) {   // ablation bit 3: later chunks re-use the first chunk's rows
+        if (c + 1 < NC) prefetch_a(c + 1, cur);
+        else if (has_next) prefetch_a(0, nxt);   // the next tile's first chunk, under this tile's last chunk + epilogue
+      }
+      const int nkk = min(CK, p.KT - c * CK);
+      const int nit = p.taps * nkk;
+      // A fragments ping-pong between two register sets: the LDS reads of step it+1 are in flight under the MFMAs of step it
+      int j = 0, kk = 0;
+      load_a(a0, 0, 0);
+      for (int it = 0; it < nit; it += 2) {
+        int j1 = j, k1 = kk + 1;
+        if (k1 == nkk) { k1 = 0; ++j1; }
+        fetch_b(b2);
+        if (it + 1 < nit) load_a(a1, j1, k1);
+        mma_all(a0, b0);
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) { b0[tn] = b1[tn]; b1[tn] = b2[tn]; }
-        j = j2;
-        kk = k2;
+        if (it + 1 < nit) {
+          int j2 = j1, k2 = k1 + 1;
+          if (k2 == nkk) { k2 = 0; ++j2; }
+          fetch_b(b2);
+          if (it + 2 < nit) load_a(a0, j2, k2);
+          mma_all(a1, b0);
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) { b0[tn] = b1[tn]; b1[tn] = b2[tn]; }
+          j = j2;
+          kk = k2;
+        }
       }
     }
+#if ITTS_STAMPS
+    if (L == (int)blockIdx.x) CSTAMP(3);
+#endif
+    if (!(ITTS_CONV_EXP(p) & 16))   // ablation bit 4: no epilogue
+      conv_epilogue<T, TM, TN>(p, acc, cur.b, cur.t0 + wm * TM * 16, cur.nt0, g, r);
+#if ITTS_STAMPS
+    if (L == (int)blockIdx.x) CSTAMP(4);
+#endif
+    cur = nxt;
   }
-
-  conv_epilogue<T, TM, TN>(p, acc, b, t0 + wm * TM * 16, nt0, g, r);
+#if ITTS_STAMPS
+  if (p.stamps != nullptr && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long te_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te_)::"memory");
+    unsigned xcc_, hwid_;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid_));
+    st_[5] = te_;
+    st_[12] = hwid_;
+    st_[13] = xcc_ & 0xF;
+    st_[15] = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* o_ = p.stamps + (size_t)blockIdx.x * 16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o_[i] = st_[i];
+  }
+#endif
 }
 
 template <typename T, int WM, int WN, int TM, int TN, int CK, int HALO>
@@ -348,12 +453,21 @@ static int launch_conv(const ConvParams& p, hipStream_t s) {
     set_error("itts_gemm_conv: too many tiles (%lld)", (long long)total);
     return ITTS_ERR_INVALID;
   }
-  dim3 grid((unsigned)total);
   static std::once_flag attr;   // one-shot per instantiation, safe under concurrent first calls (RequestPool threads)
   std::call_once(attr, [] {
     (void)hipFuncSetAttribute((const void*)gemm_conv_kernel<T, WM, WN, TM, TN, CK, HALO>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
   });
+  // persistent grid: one round of resident workgroups (a multiple of 8, so that a workgroup's tiles stay on its XCD's run
+  // of the tile order); nothing waits on another workgroup, so an over-estimate only costs a second round
+  int per_cu = 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gemm_conv_kernel<T, WM, WN, TM, TN, CK, HALO>,
+                                                   WM * WN * 64, ldsb) != hipSuccess || per_cu < 1)
+    per_cu = 1;
+  (void)hipGetLastError();
+  int64_t g = (int64_t)conv_num_cus() * per_cu;
+  if (g > total) g = total;
+  dim3 grid((unsigned)g);
   hipLaunchKernelGGL((gemm_conv_kernel<T, WM, WN, TM, TN, CK, HALO>), grid, dim3(WM * WN * 64), ldsb, s, q);
   return check_launch("itts_gemm_conv");
 }
@@ -384,7 +498,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_plain_kernel(ConvParams 
   const int g = lane >> 4, r = lane & 15;
   const int wm = wave / WN, wn = wave % WN;
   int mblk, nblk, b;
-  tile_of_workgroup(p, mblk, nblk, b);
+  tile_of_workgroup(p, blockIdx.x, gridDim.x, mblk, nblk, b);
   const int t0 = mblk * BM;
   const int nt0 = nblk * (BN / 16) + wn * TN;
   const int NC = (p.KT + CK - 1) / CK;
@@ -445,6 +559,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_plain_kernel(ConvParams 
     for (int tm = 0; tm < TM; ++tm) af[tm] = ld16<frag>(buf + a_off + tm * 16 * ROWB + kk * 64);
   };
   auto mma_all = [&](frag (&af)[TM], frag (&bf)[TN]) {
+    if (ITTS_CONV_EXP(p) & 2) {   // ablation bit 1: no MFMA (operands kept alive)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) asm volatile("" ::"v"(af[tm]));
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) asm volatile("" ::"v"(bf[tn]));
+      return;
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -638,13 +759,29 @@ static int dispatch_conv(const ConvParams& p, hipStream_t s) {
     // Measured on MI355X (bf16, M = 3008 / 7488, N = 1280..5120, K = 1280 / 5120): 128 x 128 pipelined 435-720 TFLOP/s,
     // 256 x 128 pipelined 300-625, the unpipelined 256 x 128 tile of the convolution kernel 260-540.
     if (g_conv_cfg == 5) return launch_plain<T, 2, 4, 8, 2>(p, s);   // 256 x 128
-    if (g_conv_cfg == 1) return launch_conv<T, 2, 4, 8, 2, 4, 0>(p, s);
     return launch_plain<T, 2, 4, 4, 2>(p, s);                        // 128 x 128, two workgroups per CU
   }
   if (plain && p.N % 64 == 0) {
     const int64_t rows = (int64_t)p.B * ((p.Tout + 255) / 256);
     return (rows * (p.N / 64) >= 448) ? launch_conv<T, 4, 2, 4, 2, 4, 0>(p, s) : launch_conv<T, 4, 2, 2, 2, 4, 0>(p, s);
   }
+#if ITTS_DIAG
+  if (g_conv_cfg == 10) {   // experiment: 4-wave workgroups (two per CU at 2 waves per SIMD), same per-wave tiles
+    if (p.N % 128 == 0) return launch_conv<T, 2, 2, 4, 4, 2, CV_MAX_HALO>(p, s);
+    if (p.N % 64 == 0) return launch_conv<T, 2, 2, 4, 2, 2, CV_MAX_HALO>(p, s);
+    if (p.N % 96 == 0) return launch_conv<T, 2, 2, 4, 3, 2, CV_MAX_HALO>(p, s);
+  }
+  if (g_conv_cfg == 11) {   // experiment: 4-wave workgroups, half-height wave tiles (fewer registers -> more waves per SIMD)
+    if (p.N % 128 == 0) return launch_conv<T, 2, 2, 2, 4, 2, CV_MAX_HALO>(p, s);
+    if (p.N % 64 == 0) return launch_conv<T, 2, 2, 2, 2, 2, CV_MAX_HALO>(p, s);
+    if (p.N % 96 == 0) return launch_conv<T, 2, 2, 2, 3, 2, CV_MAX_HALO>(p, s);
+  }
+  if (g_conv_cfg == 12) {   // experiment: 8-wave workgroups with half-height wave tiles
+    if (p.N % 128 == 0) return launch_conv<T, 2, 4, 4, 2, 2, CV_MAX_HALO>(p, s);
+    if (p.N % 64 == 0) return launch_conv<T, 4, 2, 2, 2, 2, CV_MAX_HALO>(p, s);
+    if (p.N % 96 == 0) return launch_conv<T, 4, 2, 2, 3, 2, CV_MAX_HALO>(p, s);
+  }
+#endif
   if (p.N % 128 == 0) return launch_conv<T, 2, 4, 8, 2, 2, CV_MAX_HALO>(p, s);
   if (p.N % 64 == 0) return launch_conv<T, 4, 2, 4, 2, 2, CV_MAX_HALO>(p, s);
   if (p.N % 96 == 0) return launch_conv<T, 4, 2, 4, 3, 2, CV_MAX_HALO>(p, s);
@@ -690,6 +827,14 @@ static int conv_params_from_args(const itts_conv_args* a, ConvParams& p, const c
   p.accumulate = a->accumulate;
   p.scale = a->scale;
   const int ks = a->dtype == ITTS_F32 ? 16 : 32;
+#if ITTS_DIAG
+  p.exp = g_conv_exp;
+#else
+  p.exp = 0;
+#endif
+#if ITTS_STAMPS
+  p.stamps = g_stamp_buf_conv;
+#endif
   p.NT = (a->N + 15) / 16;
   p.KT = (a->Cin + ks - 1) / ks;
   p.MB = p.NB = p.GM = 1;

@@ -565,13 +565,14 @@ extern "C" int itts_skinny_plan(int dtype, int M, int N, int K, int ksplit, int*
 
 #if ITTS_DIAG
 // ---- diagnostic build only (libindextts_hip_diag.so, include/indextts_hip_diag.h); absent from the product library
-namespace itts { extern int g_conv_cfg; extern int g_attn_waves; }
+namespace itts { extern int g_conv_cfg; extern int g_attn_waves; extern int g_conv_exp; }
 
 extern "C" int itts_debug_set(int key, int value) {
   if (key == 1) itts::g_tune_ntb = value;
   else if (key == 2) itts::g_tune_nw = value;
   else if (key == 3) itts::g_conv_cfg = value;
   else if (key == 4) itts::g_attn_waves = (value == 8) ? 8 : 4;
+  else if (key == 5) itts::g_conv_exp = value;
   else return ITTS_ERR_INVALID;
   return ITTS_OK;
 }
@@ -580,6 +581,18 @@ extern "C" int itts_debug_set(int key, int value) {
 extern "C" int itts_debug_stamps(void* buf) {
 #if ITTS_STAMPS
   itts::g_stamp_buf = (unsigned long long*)buf;
+  return ITTS_OK;
+#else
+  (void)buf;
+  return ITTS_ERR_INVALID;
+#endif
+}
+
+// the same for the tiled convolution kernel: 16 x u64 per workgroup (tools/timeline_conv.py)
+namespace itts { extern unsigned long long* g_stamp_buf_conv; }
+extern "C" int itts_debug_stamps_conv(void* buf) {
+#if ITTS_STAMPS
+  itts::g_stamp_buf_conv = (unsigned long long*)buf;
   return ITTS_OK;
 #else
   (void)buf;

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     # the diagnostic entry points (include/indextts_hip_diag.h: tuning overrides, time stamps) are NOT in the product library
     diag = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "indextts_hip_diag.h")).read(), flags=re.S)
     dsyms = sorted(set(re.findall(r"\b(itts_[a-z0-9_]+)\s*\(", diag)))
-    assert dsyms == ["itts_debug_set", "itts_debug_stamps", "itts_debug_stamps_sample"]
+    assert dsyms == ["itts_debug_set", "itts_debug_stamps", "itts_debug_stamps_conv", "itts_debug_stamps_sample"]
     for s in dsyms:
         assert not hasattr(lib, s), f"{s} (diagnostic build only) is exported by the product library"
     lib.itts_abi_version.restype = ctypes.c_int

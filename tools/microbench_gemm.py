@@ -44,6 +44,8 @@ def bench(name, dtype, B, T, Cin, N, taps, dil, y_f32=False, resid=False, act=0)
 
 
 bf, fh = torch.bfloat16, torch.float16
+if os.environ.get("ITTS_CONV_EXP"):
+    nat.debug_set(5, int(os.environ["ITTS_CONV_EXP"]))
 if os.environ.get("ITTS_CONV_CFG"):
     nat.debug_set(3, int(os.environ["ITTS_CONV_CFG"]))
     print("plain-GEMM tile cfg", os.environ["ITTS_CONV_CFG"])
