@@ -220,16 +220,21 @@ static int conv_num_cus() {
 template <int WM, int WN, int TM, int TN>
 struct ConvOcc {
   static constexpr int NW = WM * WN;
-  static constexpr int WPS = (NW == 8) ? 2 : ((TM * TN <= 16) ? 2 : 1);
+  static constexpr int WPS = (NW == 8) ? 2 : ((TM * TN <= 8) ? 2 : 1);
 };
 
 // PERSISTENT, cross-tile pipelined: the grid is one round of resident workgroups (launch_conv asks the occupancy API) and
 // a workgroup walks the tile sequence with stride gridDim.x.  The activation rows of the NEXT tile's first chunk are
-// requested while the current tile's last chunk is multiplied, the weight-fragment cursor runs two steps ahead straight
-// across the tile boundary, and the epilogue's stores drain under the next tile's work.  Measured before this change
-// (profiles/r02_conv_ablation.txt): with one tile per workgroup and one workgroup per CU (177 VGPRs), [launch + HBM
-// latency of the first chunk] and [epilogue] sat un-overlapped around every tile -- removing MFMAs, weight loads and LDS
-// reads TOGETHER only took 16 % off, the per-tile skeleton was 60-85 % of the kernel.
+// requested while the current tile's last chunk is multiplied, the weight fragments of the next TAP (CK k-steps x TN
+// column blocks) are requested at the start of the current tap -- straight across chunk and tile boundaries -- and the
+// epilogue's stores drain under the next tile's work.
+//
+// Everything that addresses weights or picks the LDS row of a tap is WAVE-UNIFORM and kept in SGPRs (the wave index goes
+// through readfirstlane so the compiler can prove it): a weight load is `buffer_load  v(lane*16), s(block offset)`, the tap
+// cursor is three scalar adds.  The first version of this loop carried the cursor in VGPRs (it inherited divergence from
+// threadIdx.x >> 6): ~100 VALU instructions per 16 MFMAs, and in-kernel stamps showed the tap loop at 390 ns per k-step
+// with the MFMAs, weight loads and LDS reads all REMOVED (profiles/r02_conv_ablation.txt) -- index arithmetic, not data
+// movement, bounded the kernel.
 template <typename T, int WM, int WN, int TM, int TN, int CK, int HALO>
 __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void gemm_conv_kernel(ConvParams p) {
   typedef Elem<T> EL;
@@ -243,7 +248,8 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
   static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #if ITTS_STAMPS
   unsigned long long st_[16];
 #pragma unroll
@@ -256,11 +262,15 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
   const int total = p.MB * p.NB * p.B;         // tiles; tile L of the XCD-aware order is handled by workgroup L % gridDim.x
   const int HR = BM + (p.taps - 1) * p.dil;   // staged rows
   const int NC = (p.KT + CK - 1) / CK;        // channel chunks
+  const int nkk_last = p.KT - (NC - 1) * CK;  // k-steps of the last chunk (== CK unless KT % CK)
   // Range-checked buffer descriptors: out-of-range rows (conv zero padding, M tail) and disabled lanes read zeros with
   // no branch around the load, so the compiler keeps counted waits instead of draining the queue at every join.
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.wp), 0, (int)((int64_t)p.taps * p.NT * p.KT * 1024), 0x00020000);
   constexpr unsigned OOB = 0xFFFFFFFFu;
+  const int w_tap = p.NT * p.KT * 1024;        // bytes between the weight blocks of neighbouring taps
+  const int w_col = p.KT * 1024;               // ... of neighbouring 16-column blocks
+  const unsigned w_lane = (unsigned)lane * 16;
 
   struct Tile {
     int b, t0, nt0;
@@ -295,43 +305,48 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
       if (i < HR) st16(lds + i * ROWB + seg * 16, stg[q]);
     }
   };
-  // Flat step space: step = (tile, chunk c, tap j, k-step kk within the chunk); weight block = ((j*NT + nt)*KT + c*CK + kk).
-  // The fetch cursor (fc, fj, fk) belongs to the tile whose column block is f_nt0; past the last tile f_ok is false.
-  int fc = 0, fj = 0, fk = 0, f_nt0 = 0, f_next = 0;
-  bool f_ok = false;
-  auto fetch_b = [&](frag (&bf)[TN]) {
+  // Weight cursor (scalar): w_off = byte offset of block (tap fj, column block 0 of this wave's tile, k-step fc*CK).
+  // A column block past NT (N tail) is clamped onto the last one: its products land in accumulators the epilogue drops.
+  // k-steps past KT in the last chunk read the neighbouring block (or zeros past the end): their activations are zero.
+  int w_tn[TN];
+  int fc = 0, fj = 0, f_next = 0, w_off = 0;
+  auto w_tile = [&](int nt0) {
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      int nt = f_nt0 + tn;
-      bool ok = (nt < p.NT) && f_ok;
-      if (ITTS_CONV_EXP(p) & 1) ok = false;   // ablation bit 0: nobody loads weight fragments
-      unsigned off = ok ? (unsigned)((((fj * p.NT + nt) * p.KT + fc * CK + fk) * 64 + lane) * 16) : OOB;
-      bf[tn] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0));
-    }
-    // advance; at the end of a tile the cursor moves on to the column block of the workgroup's next tile
-    int nkk = min(CK, p.KT - fc * CK);
-    if (++fk >= nkk) {
-      fk = 0;
-      if (++fj == p.taps) {
-        fj = 0;
-        if (++fc == NC) {
-          fc = 0;
-          f_ok = f_next < total;
-          if (f_ok) f_nt0 = tile_at(f_next).nt0;
-          f_next += gridDim.x;
-        }
+    for (int tn = 0; tn < TN; ++tn) w_tn[tn] = min(nt0 + tn, p.NT - 1) * w_col;
+  };
+  auto fetch_b = [&](frag (&bf)[CK][TN]) {
+#pragma unroll
+    for (int kk = 0; kk < CK; ++kk)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        if (ITTS_CONV_EXP(p) & 1) bf[kk][tn] = zero_frag<frag>();   // ablation bit 0: nobody loads weight fragments
+        else bf[kk][tn] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rw, w_lane, w_off + w_tn[tn] + kk * 1024, 0));
+      }
+    // advance one tap; at the end of a tile move on to the column blocks of the workgroup's next tile (or stay: the
+    // loads after the last tile are never used)
+    w_off += w_tap;
+    if (++fj == p.taps) {
+      fj = 0;
+      w_off += CK * 1024 - p.taps * w_tap;
+      if (++fc == NC) {
+        fc = 0;
+        w_off = 0;
+        if (f_next < total) w_tile(tile_at(f_next).nt0);
+        f_next += gridDim.x;
       }
     }
   };
-  auto load_a = [&](frag (&af)[TM], int j, int kk) {
+  const unsigned char* a_lane = lds + (wm * TM * 16 + r) * ROWB + g * 16;
+  const int a_tap = p.dil * ROWB;
+  auto load_a = [&](frag (&af)[TM], int j, int kk) {   // j, kk wave-uniform
     if (ITTS_CONV_EXP(p) & 4) {   // ablation bit 2: no LDS fragment reads
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) af[tm] = zero_frag<frag>();
       return;
     }
-    const unsigned char* abase = lds + (wm * TM * 16 + r + j * p.dil) * ROWB + kk * 64 + g * 16;
+    const unsigned char* ab = a_lane + j * a_tap + kk * 64;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) af[tm] = ld16<frag>(abase + tm * 16 * ROWB);
+    for (int tm = 0; tm < TM; ++tm) af[tm] = ld16<frag>(ab + tm * 16 * ROWB);
   };
   auto mma_all = [&](frag (&af)[TM], frag (&bf)[TN]) {
     if (ITTS_CONV_EXP(p) & 2) {   // ablation bit 1: no MFMA (operands kept alive)
@@ -347,16 +362,35 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
       for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = EL::mma(bf[tn], af[tm], acc[tm][tn]);  // weights as A: transposed tile
   };
 
-  frag b0[TN], b1[TN], b2[TN];
-  frag a0[TM], a1[TM];
+  frag bA[CK][TN], bB[CK][TN];   // weight fragments of the current / the next tap (roles swap every tap)
+  frag a0[TM], a1[TM];           // activation fragments ping-pong between k-steps
+  // One tap of a FULL chunk (CK k-steps): the next tap's weights are requested first, then every k-step issues the LDS
+  // reads of the following k-step before its own MFMAs.  P = parity of the tap inside the statically unrolled pair, so
+  // that the a0/a1 roles are compile-time: k-step (j, kk) uses set (P*CK + kk) & 1.
+  auto tap_full = [&](auto Ptag, frag (&cur)[CK][TN], frag (&nxt)[CK][TN], int j) {
+    constexpr int P = decltype(Ptag)::value;
+    fetch_b(nxt);
+    const bool more = j + 1 < p.taps;
+#pragma unroll
+    for (int kk = 0; kk < CK; ++kk) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const bool cur0 = (((P * CK + kk) & 1) == 0);
+      if (kk + 1 < CK) {
+        if (cur0) load_a(a1, j, kk + 1); else load_a(a0, j, kk + 1);
+      } else if (more) {
+        if (cur0) load_a(a1, j + 1, 0); else load_a(a0, j + 1, 0);
+      }
+      if (cur0) mma_all(a0, cur[kk]); else mma_all(a1, cur[kk]);
+    }
+  };
+
   int L = blockIdx.x;
   if (L >= total) return;
   Tile cur = tile_at(L);
-  f_nt0 = cur.nt0;
-  f_ok = true;
+  w_tile(cur.nt0);
   f_next = L + gridDim.x;
-  fetch_b(b0);
-  fetch_b(b1);
+  fetch_b(bA);
   prefetch_a(0, cur);
   CSTAMP(1);
   for (; L < total; L += gridDim.x) {
@@ -378,29 +412,40 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
         if (c + 1 < NC) prefetch_a(c + 1, cur);
         else if (has_next) prefetch_a(0, nxt);   // the next tile's first chunk, under this tile's last chunk + epilogue
       }
-      const int nkk = min(CK, p.KT - c * CK);
-      const int nit = p.taps * nkk;
-      // A fragments ping-pong between two register sets: the LDS reads of step it+1 are in flight under the MFMAs of step it
-      int j = 0, kk = 0;
-      load_a(a0, 0, 0);
-      for (int it = 0; it < nit; it += 2) {
-        int j1 = j, k1 = kk + 1;
-        if (k1 == nkk) { k1 = 0; ++j1; }
-        fetch_b(b2);
-        if (it + 1 < nit) load_a(a1, j1, k1);
-        mma_all(a0, b0);
+      const int nkk = (c + 1 < NC) ? CK : nkk_last;
+      if (nkk == CK) {
+        // k-step (0, 0) of a chunk uses a0 when the unrolled pair starts at an even tap: (P*CK + 0) & 1 == 0 for P = 0
+        load_a(a0, 0, 0);
+        int j = 0;
+        for (; j + 1 < p.taps; j += 2) {
+          tap_full(std::integral_constant<int, 0>{}, bA, bB, j);
+          if constexpr ((CK & 1) != 0) {
+            tap_full(std::integral_constant<int, 1>{}, bB, bA, j + 1);
+          } else {
+            tap_full(std::integral_constant<int, 0>{}, bB, bA, j + 1);
+          }
+        }
+        if (j < p.taps) {   // odd tap count: the last tap ran out of bA and fetched the next one into bB
+          tap_full(std::integral_constant<int, 0>{}, bA, bB, j);
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) { b0[tn] = b1[tn]; b1[tn] = b2[tn]; }
-        if (it + 1 < nit) {
-          int j2 = j1, k2 = k1 + 1;
-          if (k2 == nkk) { k2 = 0; ++j2; }
-          fetch_b(b2);
-          if (it + 2 < nit) load_a(a0, j2, k2);
-          mma_all(a1, b0);
+          for (int kk = 0; kk < CK; ++kk)
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn) { b0[tn] = b1[tn]; b1[tn] = b2[tn]; }
-          j = j2;
-          kk = k2;
+            for (int tn = 0; tn < TN; ++tn) bA[kk][tn] = bB[kk][tn];
+        }
+      } else {
+        // short last chunk (KT % CK != 0): plain order, no register ping-pong
+        for (int j = 0; j < p.taps; ++j) {
+          fetch_b(bB);
+#pragma unroll
+          for (int kk = 0; kk < CK; ++kk)
+            if (kk < nkk) {
+              load_a(a0, j, kk);
+              mma_all(a0, bA[kk]);
+            }
+#pragma unroll
+          for (int kk = 0; kk < CK; ++kk)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bA[kk][tn] = bB[kk][tn];
         }
       }
     }

@@ -32,6 +32,12 @@ NW = 1 << 16
 stamps = torch.zeros(NW, 16, dtype=torch.int64, device=dev)
 
 
+if os.environ.get("ITTS_CONV_EXP"):
+    nat.debug_set(5, int(os.environ["ITTS_CONV_EXP"]))
+if os.environ.get("ITTS_CONV_CFG"):
+    nat.debug_set(3, int(os.environ["ITTS_CONV_CFG"]))
+
+
 def run():
     nat.gemm_conv(dt, B, T, T, C, C, wp, x, y, taps=taps, off0=-pad, dil=dil, bias=bias)
 
@@ -46,8 +52,8 @@ s = stamps.cpu().numpy().astype(np.float64)
 s = s[s[:, 15] > 0]
 n = s.shape[0]
 clk = np.median((s[:, 5] - s[:, 0]) / np.maximum(s[:, 15] - s[:, 14], 1.0)) * 100.0
-seg = ["issue first prefetch", "first chunk staged (HBM latency + LDS commit)", "chunk loop (LDS reads, weight loads, MFMA)",
-       "epilogue issue", "store drain"]
+seg = ["issue first prefetch", "first chunk staged (HBM latency + LDS commit)", "first tile: chunk loop (LDS reads, weight loads, MFMA)",
+       "first tile: epilogue issue", "remaining tiles + store drain"]
 out = {"shape": dict(C=C, taps=taps, dil=dil, T=T, B=B), "workgroups": n, "clock_mhz": round(float(clk))}
 out["segments_us"] = {name: round(float(np.median((s[:, i + 1] - s[:, i]) / clk)), 2) for i, name in enumerate(seg)}
 out["wg_life_us"] = {"median": round(float(np.median((s[:, 5] - s[:, 0]) / clk)), 2),
