@@ -43,7 +43,17 @@ struct ConvParams {
 
 #if ITTS_STAMPS
 unsigned long long* g_stamp_buf_conv = nullptr;
-#define CSTAMP(i) ITTS_STAMP_IF(p.stamps != nullptr, i)
+// stamps live in LDS, not in registers: 16 x u64 of VGPRs pushed the big tiles into scratch in the diagnostic build
+#define CSTAMP(i)                                                                                        \
+  do {                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    if (p.stamps != nullptr && threadIdx.x == 0) {                                                       \
+      unsigned long long t_;                                                                             \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                         \
+      st_[i] = t_;                                                                                       \
+    }                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+  } while (0)
 #else
 #define CSTAMP(i) do { } while (0)
 #endif
@@ -220,7 +230,7 @@ static int conv_num_cus() {
 template <int WM, int WN, int TM, int TN>
 struct ConvOcc {
   static constexpr int NW = WM * WN;
-  static constexpr int WPS = (NW == 8) ? 2 : ((TM * TN <= 8) ? 2 : 1);
+  static constexpr int WPS = (NW == 8) ? 2 : ((TM * TN <= 16 && !(WM == 4 && WN == 1)) ? 2 : 1);   // the 4x1 stacks stage 10 row fragments per thread
 };
 
 // PERSISTENT, cross-tile pipelined: the grid is one round of resident workgroups (launch_conv asks the occupancy API) and
@@ -245,15 +255,14 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
   constexpr int ROWB = CK * 64 + 16;           // LDS bytes per staged row (payload + 16 B pad: conflict-free b128 reads)
   constexpr int NTH = WM * WN * 64;            // threads per workgroup (4 or 8 waves)
   constexpr int MAXST = ((BM + HALO) * SEGS + NTH - 1) / NTH;
-  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
+  static_assert(WM * WN >= 2 && WM * WN <= 8, "2 to 8 waves per workgroup");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #if ITTS_STAMPS
-  unsigned long long st_[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) st_[i] = 0;
+  __shared__ unsigned long long st_[16];
+  if (tid < 16) st_[tid] = 0;
   if (p.stamps != nullptr && tid == 0) st_[14] = __builtin_amdgcn_s_memrealtime();
 #endif
   CSTAMP(0);
@@ -319,8 +328,7 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
     for (int kk = 0; kk < CK; ++kk)
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
-        if (ITTS_CONV_EXP(p) & 1) bf[kk][tn] = zero_frag<frag>();   // ablation bit 0: nobody loads weight fragments
-        else bf[kk][tn] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rw, w_lane, w_off + w_tn[tn] + kk * 1024, 0));
+        bf[kk][tn] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rw, w_lane, w_off + w_tn[tn] + kk * 1024, 0));
       }
     // advance one tap; at the end of a tile move on to the column blocks of the workgroup's next tile (or stay: the
     // loads after the last tile are never used)
@@ -339,23 +347,11 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
   const unsigned char* a_lane = lds + (wm * TM * 16 + r) * ROWB + g * 16;
   const int a_tap = p.dil * ROWB;
   auto load_a = [&](frag (&af)[TM], int j, int kk) {   // j, kk wave-uniform
-    if (ITTS_CONV_EXP(p) & 4) {   // ablation bit 2: no LDS fragment reads
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) af[tm] = zero_frag<frag>();
-      return;
-    }
     const unsigned char* ab = a_lane + j * a_tap + kk * 64;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) af[tm] = ld16<frag>(ab + tm * 16 * ROWB);
   };
   auto mma_all = [&](frag (&af)[TM], frag (&bf)[TN]) {
-    if (ITTS_CONV_EXP(p) & 2) {   // ablation bit 1: no MFMA (operands kept alive)
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) asm volatile("" ::"v"(af[tm]));
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) asm volatile("" ::"v"(bf[tn]));
-      return;
-    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -371,17 +367,20 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
     constexpr int P = decltype(Ptag)::value;
     fetch_b(nxt);
     const bool more = j + 1 < p.taps;
+    // sched_barrier: the scheduler otherwise sinks the early LDS reads down to their first use to save registers, which
+    // puts the LDS latency in front of every pair of MFMAs
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < CK; ++kk) {
-      constexpr int dummy = 0;
-      (void)dummy;
       const bool cur0 = (((P * CK + kk) & 1) == 0);
       if (kk + 1 < CK) {
         if (cur0) load_a(a1, j, kk + 1); else load_a(a0, j, kk + 1);
       } else if (more) {
         if (cur0) load_a(a1, j + 1, 0); else load_a(a0, j + 1, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
       if (cur0) mma_all(a0, cur[kk]); else mma_all(a1, cur[kk]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -402,16 +401,21 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int c = 0; c < NC; ++c) {
-      __syncthreads();  // everyone finished reading the previous chunk
+#if ITTS_STAMPS
+      const bool stc = (c == 1 && L == (int)blockIdx.x);   // one steady-state chunk of the first tile, decomposed
+      if (stc) CSTAMP(6);
+#endif
+      // Raw barriers with an LDS-only wait: __syncthreads() would also drain vmcnt, i.e. wait for the weight fragments of the
+      // next tap that were requested a moment ago (measured: 3 us per chunk in the two barriers).
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone finished reading the previous chunk
       commit_a();
-      __syncthreads();
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #if ITTS_STAMPS
       if (c == 0 && L == (int)blockIdx.x) CSTAMP(2);
+      if (stc) CSTAMP(8);
 #endif
-      if (!(ITTS_CONV_EXP(p) & 8)) {   // ablation bit 3: later chunks re-use the first chunk's rows
-        if (c + 1 < NC) prefetch_a(c + 1, cur);
-        else if (has_next) prefetch_a(0, nxt);   // the next tile's first chunk, under this tile's last chunk + epilogue
-      }
+      if (c + 1 < NC) prefetch_a(c + 1, cur);
+      else if (has_next) prefetch_a(0, nxt);   // the next tile's first chunk, under this tile's last chunk + epilogue
       const int nkk = (c + 1 < NC) ? CK : nkk_last;
       if (nkk == CK) {
         // k-step (0, 0) of a chunk uses a0 when the unrolled pair starts at an even tap: (P*CK + 0) & 1 == 0 for P = 0
@@ -424,6 +428,11 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
           } else {
             tap_full(std::integral_constant<int, 0>{}, bB, bA, j + 1);
           }
+#if ITTS_STAMPS
+          if (stc && j == 0) CSTAMP(9);
+          if (stc && j == 2) CSTAMP(10);
+          if (stc && j == 4) CSTAMP(11);
+#endif
         }
         if (j < p.taps) {   // odd tap count: the last tap ran out of bA and fetched the next one into bB
           tap_full(std::integral_constant<int, 0>{}, bA, bB, j);
@@ -432,6 +441,9 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) bA[kk][tn] = bB[kk][tn];
         }
+#if ITTS_STAMPS
+        if (stc) CSTAMP(7);
+#endif
       } else {
         // short last chunk (KT % CK != 0): plain order, no register ping-pong
         for (int j = 0; j < p.taps; ++j) {
@@ -452,8 +464,7 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
 #if ITTS_STAMPS
     if (L == (int)blockIdx.x) CSTAMP(3);
 #endif
-    if (!(ITTS_CONV_EXP(p) & 16))   // ablation bit 4: no epilogue
-      conv_epilogue<T, TM, TN>(p, acc, cur.b, cur.t0 + wm * TM * 16, cur.nt0, g, r);
+    conv_epilogue<T, TM, TN>(p, acc, cur.b, cur.t0 + wm * TM * 16, cur.nt0, g, r);
 #if ITTS_STAMPS
     if (L == (int)blockIdx.x) CSTAMP(4);
 #endif
@@ -471,14 +482,13 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
     st_[12] = hwid_;
     st_[13] = xcc_ & 0xF;
     st_[15] = __builtin_amdgcn_s_memrealtime();
-    unsigned long long* o_ = p.stamps + (size_t)blockIdx.x * 16;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) o_[i] = st_[i];
   }
+  __syncthreads();
+  if (p.stamps != nullptr && tid < 16) p.stamps[(size_t)blockIdx.x * 16 + tid] = st_[tid];
 #endif
 }
 
-template <typename T, int WM, int WN, int TM, int TN, int CK, int HALO>
+template <typename T, int WM, int WN, int TM, int TN, int CK, int HALO, bool PERSIST = false>
 static int launch_conv(const ConvParams& p, hipStream_t s) {
   constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
   int HR = BM + (p.taps - 1) * p.dil;
@@ -503,15 +513,19 @@ static int launch_conv(const ConvParams& p, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)gemm_conv_kernel<T, WM, WN, TM, TN, CK, HALO>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
   });
-  // persistent grid: one round of resident workgroups (a multiple of 8, so that a workgroup's tiles stay on its XCD's run
-  // of the tile order); nothing waits on another workgroup, so an over-estimate only costs a second round
-  int per_cu = 1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gemm_conv_kernel<T, WM, WN, TM, TN, CK, HALO>,
-                                                   WM * WN * 64, ldsb) != hipSuccess || per_cu < 1)
-    per_cu = 1;
-  (void)hipGetLastError();
-  int64_t g = (int64_t)conv_num_cus() * per_cu;
-  if (g > total) g = total;
+  // PERSIST: one round of resident workgroups walks the tile sequence (a multiple of 8 workgroups, so that a workgroup's
+  // tiles stay on its XCD's run of the tile order); nothing waits on another workgroup, so an over-estimate only costs a
+  // second round.  Otherwise one workgroup per tile, dispatched by the hardware as CUs free up.
+  int64_t g = total;
+  if (PERSIST || (ITTS_CONV_EXP(q) & 32)) {
+    int per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gemm_conv_kernel<T, WM, WN, TM, TN, CK, HALO>,
+                                                     WM * WN * 64, ldsb) != hipSuccess || per_cu < 1)
+      per_cu = 1;
+    (void)hipGetLastError();
+    g = (int64_t)conv_num_cus() * per_cu;
+    if (g > total) g = total;
+  }
   dim3 grid((unsigned)g);
   hipLaunchKernelGGL((gemm_conv_kernel<T, WM, WN, TM, TN, CK, HALO>), grid, dim3(WM * WN * 64), ldsb, s, q);
   return check_launch("itts_gemm_conv");
@@ -604,13 +618,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_plain_kernel(ConvParams 
     for (int tm = 0; tm < TM; ++tm) af[tm] = ld16<frag>(buf + a_off + tm * 16 * ROWB + kk * 64);
   };
   auto mma_all = [&](frag (&af)[TM], frag (&bf)[TN]) {
-    if (ITTS_CONV_EXP(p) & 2) {   // ablation bit 1: no MFMA (operands kept alive)
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) asm volatile("" ::"v"(af[tm]));
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) asm volatile("" ::"v"(bf[tn]));
-      return;
-    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -811,25 +818,26 @@ static int dispatch_conv(const ConvParams& p, hipStream_t s) {
     return (rows * (p.N / 64) >= 448) ? launch_conv<T, 4, 2, 4, 2, 4, 0>(p, s) : launch_conv<T, 4, 2, 2, 2, 4, 0>(p, s);
   }
 #if ITTS_DIAG
-  if (g_conv_cfg == 10) {   // experiment: 4-wave workgroups (two per CU at 2 waves per SIMD), same per-wave tiles
-    if (p.N % 128 == 0) return launch_conv<T, 2, 2, 4, 4, 2, CV_MAX_HALO>(p, s);
-    if (p.N % 64 == 0) return launch_conv<T, 2, 2, 4, 2, 2, CV_MAX_HALO>(p, s);
-    if (p.N % 96 == 0) return launch_conv<T, 2, 2, 4, 3, 2, CV_MAX_HALO>(p, s);
+  if (g_conv_cfg == 10) {   // the 8-wave tiles of the first version (256-row tiles, one workgroup per CU), for A/B runs
+    if (p.N % 128 == 0) return launch_conv<T, 2, 4, 8, 2, 2, CV_MAX_HALO>(p, s);
+    if (p.N % 64 == 0) return launch_conv<T, 4, 2, 4, 2, 2, CV_MAX_HALO>(p, s);
+    if (p.N % 96 == 0) return launch_conv<T, 4, 2, 4, 3, 2, CV_MAX_HALO>(p, s);
   }
-  if (g_conv_cfg == 11) {   // experiment: 4-wave workgroups, half-height wave tiles (fewer registers -> more waves per SIMD)
-    if (p.N % 128 == 0) return launch_conv<T, 2, 2, 2, 4, 2, CV_MAX_HALO>(p, s);
-    if (p.N % 64 == 0) return launch_conv<T, 2, 2, 2, 2, 2, CV_MAX_HALO>(p, s);
-    if (p.N % 96 == 0) return launch_conv<T, 2, 2, 2, 3, 2, CV_MAX_HALO>(p, s);
-  }
-  if (g_conv_cfg == 12) {   // experiment: 8-wave workgroups with half-height wave tiles
-    if (p.N % 128 == 0) return launch_conv<T, 2, 4, 4, 2, 2, CV_MAX_HALO>(p, s);
-    if (p.N % 64 == 0) return launch_conv<T, 4, 2, 2, 2, 2, CV_MAX_HALO>(p, s);
-    if (p.N % 96 == 0) return launch_conv<T, 4, 2, 2, 3, 2, CV_MAX_HALO>(p, s);
+  if (g_conv_cfg == 15) {   // 6 waves side by side for 192 columns
+    if (p.N % 192 == 0) return launch_conv<T, 1, 6, 8, 2, 2, CV_MAX_HALO, true>(p, s);
   }
 #endif
-  if (p.N % 128 == 0) return launch_conv<T, 2, 4, 8, 2, 2, CV_MAX_HALO>(p, s);
-  if (p.N % 64 == 0) return launch_conv<T, 4, 2, 4, 2, 2, CV_MAX_HALO>(p, s);
-  if (p.N % 96 == 0) return launch_conv<T, 4, 2, 4, 3, 2, CV_MAX_HALO>(p, s);
+  // Tile choice (MI355X, fp16, batch 32; profiles/r02_conv_tiles.txt).  Two 4-wave workgroups per CU beat one 8-wave
+  // workgroup everywhere: each workgroup stalls once per channel chunk on the in-order memory queue (its weight loads sit
+  // behind the next chunk's activation rows), and the other workgroup's MFMAs fill that hole.
+  //   N % 128: four waves SIDE BY SIDE (128 x 32 each, 128 x 128 per workgroup): no weight fragment is loaded by two waves
+  //            of a workgroup, the per-CU L2->L1 weight traffic is that of the old 256 x 128 tile.  C = 768 k = 11: 244 us
+  //            (953 TFLOP/s) against 388 us before; k = 3 d = 5: 100 against 134; C = 384: 146-153 against 185.
+  //   N % 64 / N % 96 (C = 192, 96: HBM-heavy, 1.1 / 2.3 FLOP per byte per tap): 2 x 2 waves of 64 x 32 / 64 x 48,
+  //            persistent grid (the epilogue's stores overlap the next tile): 192 / 233 us against 268 / 273.
+  if (p.N % 128 == 0) return launch_conv<T, 1, 4, 8, 2, 2, CV_MAX_HALO>(p, s);
+  if (p.N % 64 == 0) return launch_conv<T, 2, 2, 4, 2, 2, CV_MAX_HALO, true>(p, s);
+  if (p.N % 96 == 0) return launch_conv<T, 2, 2, 4, 3, 2, CV_MAX_HALO, true>(p, s);
   if (p.N % 48 == 0) return launch_conv<T, 4, 1, 4, 3, 2, CV_MAX_HALO>(p, s);
   return launch_conv<T, 4, 1, 4, 2, 2, CV_MAX_HALO>(p, s);
 }

@@ -56,6 +56,13 @@ seg = ["issue first prefetch", "first chunk staged (HBM latency + LDS commit)", 
        "first tile: epilogue issue", "remaining tiles + store drain"]
 out = {"shape": dict(C=C, taps=taps, dil=dil, T=T, B=B), "workgroups": n, "clock_mhz": round(float(clk))}
 out["segments_us"] = {name: round(float(np.median((s[:, i + 1] - s[:, i]) / clk)), 2) for i, name in enumerate(seg)}
+def med(a, b):
+    ok = (s[:, a] > 0) & (s[:, b] > 0)
+    return round(float(np.median((s[ok, a] - s[ok, b]) / clk)), 2) if ok.any() else None
+
+
+out["chunk1_us"] = {"barrier + LDS commit + barrier": med(8, 6), "prefetch issue + taps 0-1": med(9, 8), "taps 2-3": med(10, 9),
+                    "taps 4-5": med(11, 10), "whole chunk": med(7, 6)}
 out["wg_life_us"] = {"median": round(float(np.median((s[:, 5] - s[:, 0]) / clk)), 2),
                      "p90": round(float(np.percentile((s[:, 5] - s[:, 0]) / clk, 90)), 2)}
 t0 = s[:, 14].min()
