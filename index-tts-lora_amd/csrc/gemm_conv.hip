@@ -510,8 +510,10 @@ static int launch_conv(const ConvParams& p, hipStream_t s) {
   }
   static std::once_flag attr;   // one-shot per instantiation, safe under concurrent first calls (RequestPool threads)
   std::call_once(attr, [] {
+    // 160 KiB minus the static block of the diagnostic build's stamps; a refusal must not stay behind as the thread's last error
     (void)hipFuncSetAttribute((const void*)gemm_conv_kernel<T, WM, WN, TM, TN, CK, HALO>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
+                              160 * 1024 - 256);
+    (void)hipGetLastError();
   });
   // PERSIST: one round of resident workgroups walks the tile sequence (a multiple of 8 workgroups, so that a workgroup's
   // tiles stay on its XCD's run of the tile order); nothing waits on another workgroup, so an over-estimate only costs a
