@@ -6,6 +6,14 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
+def _free_port():
+    """A port the kernel just handed out (a pid-derived number can be taken, which made the rendezvous fail now and then)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -33,7 +41,7 @@ def _worker(rank, world, port, q):
 def test_broadcast_and_sharding_two_ranks():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -91,7 +99,7 @@ def _run_bench(extra_args, env_extra=None, launcher=False):
     env.update(env_extra or {})
     cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + extra_args
     if launcher:  # the driver's command line for N > 1
-        port = 29500 + (os.getpid() * 7) % 2000
+        port = _free_port()
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.join(ROOT, "bench.py")] + extra_args
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
