@@ -48,7 +48,7 @@ extern "C" {
 #define ITTS_BF16 1
 #define ITTS_F16 2
 
-#define ITTS_ABI_VERSION 3
+#define ITTS_ABI_VERSION 4
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -300,7 +300,13 @@ typedef struct itts_beam_args {
   int top_k, do_sample; /* do_sample != 0 requires 1 <= top_k <= 128 (one 1024-entry candidate pool per batch element) */
   uint64_t seed;        /* Philox key = seed + the 64-bit value in state[4..5], as in itts_sample_args */
   int eos_token;
+  /* scratch between the step's two launches (per-row candidates -> per-batch-element pooling); caller-owned, no init:
+   * cand_scores / cand_ids [B*num_beams][ITTS_BEAM_CAND] each, cand_n [B*num_beams] */
+  float* cand_scores;
+  int32_t* cand_ids;
+  int32_t* cand_n;
 } itts_beam_args;
+#define ITTS_BEAM_CAND 1024
 int itts_beam_step(const itts_beam_args* a, void* stream);
 
 /* KV rows follow their beams as a TABLE (GPT2InferenceModel._reorder_cache, model.py:207-218, without moving cache bytes):

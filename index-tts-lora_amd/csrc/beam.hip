@@ -1,10 +1,11 @@
 // Beam search / beam-sample step of the decode loop (num_beams > 1), on device, no host synchronisation per step.
 // Restates, for the call at indextts/gpt/model.py:710-715, transformers 4.44.2 `GenerationMixin._beam_search` +
 // `BeamSearchScorer.process` + `BeamHypotheses.add/is_done` (third-party; the restatement and its own random stream are
-// specified in oracle/beam_ref.py, which this kernel matches token for token).  One workgroup per batch element; its
-// num_beams rows are processed one after the other with the workgroup-wide machinery of the sampling kernel, their kept
-// candidates pooled, 2*num_beams of them drawn (or taken), and the scorer bookkeeping done by one lane.
-// The KV cache rows are then permuted by itts_beam_reorder_kv (rows of finished / unchanged batch elements are skipped).
+// specified in oracle/beam_ref.py, which these kernels match token for token).  Two launches per step: one workgroup per
+// ROW runs the workgroup-wide machinery of the sampling kernel over that row's logits and leaves its kept candidates in a
+// scratch array; one workgroup per BATCH ELEMENT then pools its beams' candidates, draws 2*num_beams of them (or takes
+// the best), and one lane does the scorer bookkeeping.
+// The KV cache follows through itts_beam_kv_rows (a row table; itts_beam_reorder_kv is the copying reference form).
 #include "common.h"
 
 namespace itts {
@@ -34,6 +35,9 @@ struct BeamParams {
   int top_k, do_sample;
   uint32_t seed_lo, seed_hi;
   int eos;
+  float* cand_s;       // [R][BM_MAXC] phase-1 output: candidate score + running beam score
+  int32_t* cand_i;     // [R][BM_MAXC]                 beam * V + token
+  int32_t* cand_n;     // [R]
 };
 
 __device__ __forceinline__ uint32_t bkey(float f) {
@@ -75,147 +79,223 @@ __device__ __forceinline__ float block_sum(float v, float* scratch, int tid) {
   return r;
 }
 
-__global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p) {
-  __shared__ float sv[BM_MAXV];
+// ---- Phase 1: one workgroup per ROW (batch element x beam).  log-softmax -> repetition penalty -> temperature -> top-k ->
+// top-p (min_tokens_to_keep = 2) of that row; its kept candidates, sorted (score desc, id asc), go to the scratch arrays as
+// (row score + running beam score, beam * V + token).  Until round 2 the pooling workgroup did its beams' rows one after
+// the other (32 workgroups busy, 181 us per token at 32 x 3); the arithmetic of a row is unchanged.
+__global__ __launch_bounds__(256) void beam_rows_kernel(BeamParams p) {
   __shared__ uint32_t flag[BM_MAXV / 32];
-  __shared__ float cs[BM_MAXC];   // row candidates (unsorted)    | later: exp weights of the pool
-  __shared__ int ci[BM_MAXC];     //                              | later: alive flags of the pool
-  __shared__ float ss[BM_MAXC];   // row candidates (sorted)      | later: sorted pool scores
-  __shared__ int si[BM_MAXC];     //                              | later: sorted pool flat indices
-  __shared__ float pool_s[BM_MAXC];
-  __shared__ int pool_i[BM_MAXC];
+  __shared__ float cs[BM_MAXC];   // row candidates (unsorted); later their softmax numerators
+  __shared__ int ci[BM_MAXC];
+  __shared__ float ss[BM_MAXC];   // row candidates (sorted)
+  __shared__ int si[BM_MAXC];
   __shared__ float scratch[4];
   __shared__ int cnt4[8];
-  __shared__ int sh_n, sh_keep, sh_np;
+  __shared__ int sh_n, sh_keep;
   __shared__ uint32_t sh_thr;
+
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = p.nb, V = p.V;
+  const int b = row / nb, beam = row - b * nb;
+  const int k = p.state[0];                 // step = tokens generated so far per row
+  const int R = p.B * nb;
+  const int32_t* hin = p.hist + (int64_t)(k & 1) * R * p.cap;
+  if (p.done[b] != 0) {                     // finished batch element: nothing to pool
+    if (tid == 0) p.cand_n[row] = 0;
+    return;
+  }
+  const float* lg = p.logits + (int64_t)row * p.ldl;
+  // ---- repetition-penalty membership bitmap of this row (fake prefix ids + its own generated tokens)
+  for (int i = tid; i < BM_MAXV / 32; i += 256) flag[i] = 0u;
+  if (tid == 0) sh_n = 0;
+  __syncthreads();
+  if (p.rep_penalty != 1.0f) {
+    for (int i = tid; i < p.n_extra; i += 256) {
+      int id = p.extra_ids[i];
+      if (id >= 0 && id < V) atomicOr(&flag[id >> 5], 1u << (id & 31));
+    }
+    const int nh = min(k, p.cap);
+    for (int i = tid; i < nh; i += 256) {
+      int id = hin[(int64_t)row * p.cap + i];
+      if (id >= 0 && id < V) atomicOr(&flag[id >> 5], 1u << (id & 31));
+    }
+  }
+  // ---- log-softmax (logits register-resident: one global read, per-thread partial sums in index order as before)
+  float lv[BM_MAXV / 256];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < BM_MAXV / 256; ++i) {
+    const int idx = tid + i * 256;
+    lv[i] = idx < V ? lg[idx] : -INFINITY;
+    mx = fmaxf(mx, lv[i]);
+  }
+  mx = block_max(mx, scratch, tid);
+  float se = 0.f;
+#pragma unroll
+  for (int i = 0; i < BM_MAXV / 256; ++i)
+    if (tid + i * 256 < V) se += expf(lv[i] - mx);
+  se = block_sum(se, scratch, tid);         // its barriers also order the bitmap
+  const float lse = mx + logf(se);
+  const bool warp = p.do_sample != 0;
+  uint32_t keys[BM_MAXV / 256];
+  uint32_t kmax = 0u;
+#pragma unroll
+  for (int i = 0; i < BM_MAXV / 256; ++i) {
+    const int idx = tid + i * 256;
+    float v = lv[i] - lse;
+    if (idx < V) {
+      if ((flag[idx >> 5] >> (idx & 31)) & 1u) v = v < 0.f ? v * p.rep_penalty : v / p.rep_penalty;
+      if (warp && p.temperature != 1.0f) v = v / p.temperature;
+    }
+    lv[i] = v;
+    keys[i] = idx < V ? bkey(v) : 0u;       // key 0 is below every real float key
+    kmax = max(kmax, keys[i]);
+  }
+  // ---- k-th largest key (beam search: the row's top 2*nb suffice for the global top 2*nb).  As in the sampling kernel:
+  //      the kk-th largest of the 256 per-thread maxima is a LOWER bound of the kk-th largest score, one wave finds it with
+  //      ballots only, and the exact kk-th (ties kept) falls out of the rank sort of the few scores above the bound; the
+  //      32-round bisection over all keys (a workgroup barrier per bit) is the fallback for heavily tied rows.
+  int kk = warp ? (p.top_k > 0 ? max(p.top_k, 2) : BM_MAXC) : 2 * nb;
+  kk = min(min(kk, V), BM_MAXC);
+  uint32_t thr = 0u;
+  bool exact = false;
+  if (kk <= 256) {
+    uint32_t* tmax = reinterpret_cast<uint32_t*>(ss);
+    tmax[tid] = kmax;
+    __syncthreads();
+    if (wave == 0) {
+      const u32x4 m4 = *reinterpret_cast<const u32x4*>(tmax + lane * 4);
+      uint32_t t = 0u;
+      for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = t | (1u << bit);
+        const int cnt = __popcll(__ballot(m4[0] >= cand)) + __popcll(__ballot(m4[1] >= cand)) +
+                        __popcll(__ballot(m4[2] >= cand)) + __popcll(__ballot(m4[3] >= cand));
+        if (cnt >= kk) t = cand;
+      }
+      if (lane == 0) sh_thr = t;
+    }
+    __syncthreads();
+    thr = sh_thr;
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < BM_MAXV / 256; ++i) cnt += __popcll(__ballot(keys[i] >= thr));
+    if (lane == 0) cnt4[wave] = cnt;
+    __syncthreads();
+    if (cnt4[0] + cnt4[1] + cnt4[2] + cnt4[3] > BM_MAXC) thr = 0u;   // too many ties above the bound: bisect exactly
+    __syncthreads();
+  }
+  if (thr == 0u) {
+    exact = true;
+    for (int bit = 31; bit >= 0; --bit) {
+      const uint32_t cand = thr | (1u << bit);
+      int cnt = 0;
+#pragma unroll
+      for (int i = 0; i < BM_MAXV / 256; ++i) cnt += __popcll(__ballot(keys[i] >= cand));
+      int* slot = &cnt4[(bit & 1) * 4];
+      if (lane == 0) slot[wave] = cnt;
+      __syncthreads();
+      if (slot[0] + slot[1] + slot[2] + slot[3] >= kk) thr = cand;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < BM_MAXV / 256; ++i) {   // the keys are still in registers: only the hits touch LDS
+    if (keys[i] >= thr && tid + i * 256 < V) {
+      int slot = atomicAdd(&sh_n, 1);
+      if (slot < BM_MAXC) { cs[slot] = lv[i]; ci[slot] = tid + i * 256; }
+    }
+  }
+  __syncthreads();
+  int n = min(sh_n, BM_MAXC);
+  for (int i = tid; i < n; i += 256) {   // rank sort: descending score, ascending id
+    float v = cs[i];
+    int id = ci[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      float w = cs[j];
+      rank += (w > v || (w == v && ci[j] < id)) ? 1 : 0;
+    }
+    ss[rank] = v;
+    si[rank] = id;
+  }
+  __syncthreads();
+  if (!exact && n > kk) {   // above the lower bound, sorted: the kk best plus everything tied with the kk-th
+    if (tid == 0) {
+      int keepk = kk;
+      const float kv = ss[kk - 1];
+      while (keepk < n && ss[keepk] == kv) ++keepk;
+      sh_n = keepk;
+    }
+    __syncthreads();
+    n = min(sh_n, BM_MAXC);
+  }
+  // softmax numerators in parallel (same values as the serial loop computed); lane 0 keeps the order-sensitive sums
+  for (int i = tid; i < n; i += 256) cs[i] = expf(ss[i] - ss[0]);
+  __syncthreads();
+  if (tid == 0) {
+    int keep = n;
+    if (warp && p.top_p < 1.0f) {
+      // TopPLogitsWarper with min_tokens_to_keep = 2: ascending cumulative probability <= 1 - top_p is removed
+      float total = 0.f;
+      for (int i = n - 1; i >= 0; --i) total += cs[i];
+      float cum = 0.f;
+      const float lim = 1.0f - p.top_p;
+      for (int i = n - 1; i >= 2; --i) {
+        cum += cs[i] / total;
+        if (cum <= lim) keep = i; else break;
+      }
+    }
+    if (!warp) keep = min(n, 2 * nb);
+    sh_keep = keep;
+    p.cand_n[row] = keep;
+  }
+  __syncthreads();
+  const int keep = sh_keep;
+  const float bsc = p.beam_scores[row];
+  for (int i = tid; i < keep; i += 256) {
+    p.cand_s[(int64_t)row * BM_MAXC + i] = ss[i] + bsc;
+    p.cand_i[(int64_t)row * BM_MAXC + i] = beam * V + si[i];
+  }
+}
+
+// ---- Phase 2: one workgroup per batch element pools its beams' candidates (in beam order, capped at BM_MAXC), draws
+// 2*num_beams of them without replacement (or takes the best), runs BeamSearchScorer.process and moves the histories.
+__global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p) {
+  __shared__ float cs[BM_MAXC];   // exp weights of the pool
+  __shared__ int ci[BM_MAXC];     // alive flags of the pool
+  __shared__ float ss[BM_MAXC];   // sorted pool scores
+  __shared__ int si[BM_MAXC];     // sorted pool flat indices
+  __shared__ float pool_s[BM_MAXC];
+  __shared__ int pool_i[BM_MAXC];
   __shared__ int nx_tok[BM_MAXB], nx_src[BM_MAXB];       // next beams: token, source beam
   __shared__ int add_slot[BM_MAXB], add_beam[BM_MAXB];   // hypotheses closed this step
   __shared__ int sh_nadd;
   __shared__ int picks[2 * BM_MAXB];      // drawn / taken candidates (lane 0 bookkeeping; LDS keeps it out of scratch)
   __shared__ float nx_score[BM_MAXB];
 
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, tid = threadIdx.x;
   const int nb = p.nb, V = p.V;
   const int k = p.state[0];                 // step = tokens generated so far per row
   const int R = p.B * nb;
   const int32_t* hin = p.hist + (int64_t)(k & 1) * R * p.cap;
   int32_t* hout = p.hist + (int64_t)((k + 1) & 1) * R * p.cap;
   const bool was_done = p.done[b] != 0;
-  if (tid == 0) { sh_np = 0; sh_nadd = 0; }
+  if (tid == 0) sh_nadd = 0;
   __syncthreads();
 
   if (!was_done) {
+    int np = 0;
     for (int beam = 0; beam < nb; ++beam) {
       const int row = b * nb + beam;
-      const float* lg = p.logits + (int64_t)row * p.ldl;
-      // ---- repetition-penalty membership bitmap of this row (fake prefix ids + its own generated tokens)
-      for (int i = tid; i < BM_MAXV / 32; i += 256) flag[i] = 0u;
-      if (tid == 0) sh_n = 0;
-      __syncthreads();
-      if (p.rep_penalty != 1.0f) {
-        for (int i = tid; i < p.n_extra; i += 256) {
-          int id = p.extra_ids[i];
-          if (id >= 0 && id < V) atomicOr(&flag[id >> 5], 1u << (id & 31));
-        }
-        const int nh = min(k, p.cap);
-        for (int i = tid; i < nh; i += 256) {
-          int id = hin[(int64_t)row * p.cap + i];
-          if (id >= 0 && id < V) atomicOr(&flag[id >> 5], 1u << (id & 31));
-        }
-      }
-      // ---- log-softmax
-      float mx = -INFINITY;
-      for (int i = tid; i < V; i += 256) {
-        float v = lg[i];
-        sv[i] = v;
-        mx = fmaxf(mx, v);
-      }
-      mx = block_max(mx, scratch, tid);
-      float se = 0.f;
-      for (int i = tid; i < V; i += 256) se += expf(sv[i] - mx);
-      se = block_sum(se, scratch, tid);
-      const float lse = mx + logf(se);
-      const bool warp = p.do_sample != 0;
-      for (int i = tid; i < V; i += 256) {
-        float v = sv[i] - lse;
-        if ((flag[i >> 5] >> (i & 31)) & 1u) v = v < 0.f ? v * p.rep_penalty : v / p.rep_penalty;
-        if (warp && p.temperature != 1.0f) v = v / p.temperature;
-        sv[i] = v;
-      }
-      __syncthreads();
-      // ---- k-th largest key by bitwise bisection (beam search: the row's top 2*nb suffice for the global top 2*nb)
-      int kk = warp ? (p.top_k > 0 ? max(p.top_k, 2) : BM_MAXC) : 2 * nb;
-      kk = min(min(kk, V), BM_MAXC);
-      uint32_t keys[BM_MAXV / 256];
-#pragma unroll
-      for (int i = 0; i < BM_MAXV / 256; ++i) {
-        int idx = tid + i * 256;
-        keys[i] = idx < V ? bkey(sv[idx]) : 0u;
-      }
-      uint32_t thr = 0u;
-      for (int bit = 31; bit >= 0; --bit) {
-        const uint32_t cand = thr | (1u << bit);
-        int cnt = 0;
-#pragma unroll
-        for (int i = 0; i < BM_MAXV / 256; ++i) cnt += __popcll(__ballot(keys[i] >= cand));
-        int* slot = &cnt4[(bit & 1) * 4];
-        if (lane == 0) slot[wave] = cnt;
-        __syncthreads();
-        if (slot[0] + slot[1] + slot[2] + slot[3] >= kk) thr = cand;
-      }
-      if (tid == 0) sh_thr = thr;
-      __syncthreads();
-      const uint32_t kth = sh_thr;
-      for (int i = tid; i < V; i += 256) {
-        if (bkey(sv[i]) >= kth) {
-          int slot = atomicAdd(&sh_n, 1);
-          if (slot < BM_MAXC) { cs[slot] = sv[i]; ci[slot] = i; }
-        }
-      }
-      __syncthreads();
-      const int n = min(sh_n, BM_MAXC);
-      for (int i = tid; i < n; i += 256) {   // rank sort: descending score, ascending id
-        float v = cs[i];
-        int id = ci[i];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) {
-          float w = cs[j];
-          rank += (w > v || (w == v && ci[j] < id)) ? 1 : 0;
-        }
-        ss[rank] = v;
-        si[rank] = id;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        int keep = n;
-        if (warp && p.top_p < 1.0f) {
-          // TopPLogitsWarper with min_tokens_to_keep = 2: ascending cumulative probability <= 1 - top_p is removed
-          float total = 0.f;
-          for (int i = n - 1; i >= 0; --i) total += expf(ss[i] - ss[0]);
-          float cum = 0.f;
-          const float lim = 1.0f - p.top_p;
-          for (int i = n - 1; i >= 2; --i) {
-            cum += expf(ss[i] - ss[0]) / total;
-            if (cum <= lim) keep = i; else break;
-          }
-        }
-        if (!warp) keep = min(n, 2 * nb);
-        keep = min(keep, BM_MAXC - sh_np);
-        sh_keep = keep;
-      }
-      __syncthreads();
-      const int keep = sh_keep, base = sh_np;
-      const float bsc = p.beam_scores[row];
+      const int keep = min(p.cand_n[row], BM_MAXC - np);
       for (int i = tid; i < keep; i += 256) {
-        pool_s[base + i] = ss[i] + bsc;
-        pool_i[base + i] = beam * V + si[i];
+        pool_s[np + i] = p.cand_s[(int64_t)row * BM_MAXC + i];
+        pool_i[np + i] = p.cand_i[(int64_t)row * BM_MAXC + i];
       }
-      __syncthreads();
-      if (tid == 0) sh_np = base + keep;
-      __syncthreads();
+      np += keep;
     }
+    __syncthreads();
     // ---- pool sorted by (score desc, flat index asc) -> ss / si
-    const int np = sh_np;
     for (int i = tid; i < np; i += 256) {
       float v = pool_s[i];
       int id = pool_i[i];
@@ -228,13 +308,16 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p) {
       si[rank] = id;
     }
     __syncthreads();
+    if (p.do_sample) {   // exp weights in parallel (the serial loop below computed the same values one by one)
+      for (int j = tid; j < np; j += 256) { cs[j] = expf(ss[j] - ss[0]); ci[j] = 1; }
+      __syncthreads();
+    }
     if (tid == 0) {
       int npick = 0;
       const int want = min(2 * nb, np);
       if (p.do_sample) {
         // key = launch argument + the 64-bit seed held in state[4..5] (lets a captured launch serve every seed)
         const uint64_t key = (((uint64_t)p.seed_hi << 32) | p.seed_lo) + (((uint64_t)(uint32_t)p.state[5] << 32) | (uint32_t)p.state[4]);
-        for (int j = 0; j < np; ++j) { cs[j] = expf(ss[j] - ss[0]); ci[j] = 1; }
         for (int i = 0; i < want; ++i) {
           float total = 0.f;
           for (int j = 0; j < np; ++j) if (ci[j]) total += cs[j];
@@ -409,7 +492,7 @@ using namespace itts;
 
 extern "C" int itts_beam_step(const itts_beam_args* a, void* stream) {
   ITTS_REQUIRE(a && a->logits && a->tokens && a->src && a->beam_scores && a->hist && a->hyp_score && a->hyp_len && a->hyp_tok &&
-                   a->n_hyp && a->worst && a->done && a->state,
+                   a->n_hyp && a->worst && a->done && a->state && a->cand_scores && a->cand_ids && a->cand_n,
                "itts_beam_step: null pointer");
   ITTS_REQUIRE(a->B > 0 && a->num_beams >= 2 && a->num_beams <= BM_MAXB, "itts_beam_step: num_beams=%d outside 2..%d", a->num_beams,
                BM_MAXB);
@@ -449,7 +532,11 @@ extern "C" int itts_beam_step(const itts_beam_args* a, void* stream) {
   p.seed_lo = (uint32_t)(a->seed & 0xFFFFFFFFull);
   p.seed_hi = (uint32_t)(a->seed >> 32);
   p.eos = a->eos_token;
+  p.cand_s = a->cand_scores;
+  p.cand_i = a->cand_ids;
+  p.cand_n = a->cand_n;
 
+  hipLaunchKernelGGL(beam_rows_kernel, dim3(a->B * a->num_beams), dim3(256), 0, (hipStream_t)stream, p);
   hipLaunchKernelGGL(beam_step_kernel, dim3(a->B), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("itts_beam_step");
 }

@@ -66,7 +66,11 @@ class BeamArgs(C.Structure):
                 ("n_hyp", C.c_void_p), ("worst", C.c_void_p), ("done", C.c_void_p), ("state", C.c_void_p),
                 ("extra_ids", C.c_void_p), ("n_extra", C.c_int), ("rep_penalty", C.c_float), ("temperature", C.c_float),
                 ("top_p", C.c_float), ("length_penalty", C.c_float), ("top_k", C.c_int), ("do_sample", C.c_int),
-                ("seed", C.c_uint64), ("eos_token", C.c_int)]
+                ("seed", C.c_uint64), ("eos_token", C.c_int),
+                ("cand_scores", C.c_void_p), ("cand_ids", C.c_void_p), ("cand_n", C.c_void_p)]
+
+
+BEAM_CAND = 1024   # ITTS_BEAM_CAND: candidate slots per row in the beam step's scratch
 
 
 _SIGNATURES = {
@@ -115,7 +119,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.itts_abi_version() != 3:
+        if L.itts_abi_version() != 4:
             raise NativeError("libindextts_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -332,10 +336,17 @@ def sample(logits, tokens, history, finished, state, extra_ids, force_stop, rep_
 
 
 def beam_step(logits, num_beams, tokens, src, beam_scores, hist, hyp_score, hyp_len, hyp_tok, n_hyp, worst, done, state,
-              extra_ids, rep_penalty, temperature, top_k, top_p, do_sample, length_penalty, seed, eos_token):
-    """logits fp32 [B*num_beams, V]; hist int32 [2, B*num_beams, cap]; see include/indextts_hip.h (itts_beam_args)."""
+              extra_ids, rep_penalty, temperature, top_k, top_p, do_sample, length_penalty, seed, eos_token, scratch=None):
+    """logits fp32 [B*num_beams, V]; hist int32 [2, B*num_beams, cap]; see include/indextts_hip.h (itts_beam_args).
+    scratch = (cand_scores fp32 [R, BEAM_CAND], cand_ids int32 [R, BEAM_CAND], cand_n int32 [R]) from beam_scratch(R);
+    allocated per call when omitted (tests) -- a captured decode loop must pass persistent buffers."""
     a = BeamArgs()
     R, V = logits.shape
+    if scratch is None:
+        scratch = beam_scratch(R, logits.device)
+    cs, cid, cn = scratch
+    assert cs.shape[0] >= R and cs.shape[1] == BEAM_CAND and cid.shape == cs.shape and cn.numel() >= R
+    a.cand_scores, a.cand_ids, a.cand_n = _p(cs), _p(cid), _p(cn)
     a.logits, a.B, a.num_beams, a.V, a.ldl = _p(logits), R // num_beams, int(num_beams), V, logits.stride(0)
     a.tokens, a.src, a.beam_scores = _p(tokens), _p(src), _p(beam_scores)
     a.hist, a.hist_cap = _p(hist), hist.shape[2]
@@ -345,6 +356,13 @@ def beam_step(logits, num_beams, tokens, src, beam_scores, hist, hyp_score, hyp_
     a.rep_penalty, a.temperature, a.top_p, a.length_penalty = float(rep_penalty), float(temperature), float(top_p), float(length_penalty)
     a.top_k, a.do_sample, a.seed, a.eos_token = int(top_k), int(bool(do_sample)), int(seed), int(eos_token)
     _check(lib().itts_beam_step(C.byref(a), _stream()), "itts_beam_step")
+
+
+def beam_scratch(rows, device="cuda"):
+    """Scratch between the two launches of a beam step (per-row candidates -> pooling), uninitialised."""
+    return (torch.empty(rows, BEAM_CAND, dtype=torch.float32, device=device),
+            torch.empty(rows, BEAM_CAND, dtype=torch.int32, device=device),
+            torch.empty(rows, dtype=torch.int32, device=device))
 
 
 def beam_kv_rows(kv_rows, src, state):

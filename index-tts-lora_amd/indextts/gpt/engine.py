@@ -447,6 +447,7 @@ class GPTEngine:
         self.b_worst = torch.zeros(B, dtype=torch.float32, device=dev)
         self.b_done = torch.zeros(B, dtype=torch.int32, device=dev)
         self.b_kv_rows = torch.zeros(2, R, self._cap_s, dtype=torch.int32, device=dev)   # [parity][logical row][position]
+        self.b_scratch = nat.beam_scratch(R, dev)   # per-row candidates handed from the step's first launch to its second
         self._beam_cap = (B, nb, self._cap_s)
 
     def _beam_select(self, B, nb, sp):
@@ -455,7 +456,7 @@ class GPTEngine:
         nat.beam_step(self.logits[:R], nb, self.tokens, self.b_src, self.b_scores, self.b_hist, self.b_hyp_score, self.b_hyp_len,
                       self.b_hyp_tok, self.b_n_hyp, self.b_worst, self.b_done, self.state, self.extra_ids,
                       sp["repetition_penalty"], sp["temperature"], sp["top_k"], sp["top_p"], sp["do_sample"],
-                      sp.get("length_penalty", 0.0), sp["seed"], self.stop_mel)
+                      sp.get("length_penalty", 0.0), sp["seed"], self.stop_mel, scratch=self.b_scratch)
         if self._kv_rows is not None:
             nat.beam_kv_rows(self._kv_rows, self.b_src, self.state)
         else:
