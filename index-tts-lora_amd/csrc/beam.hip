@@ -272,6 +272,10 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p) {
   __shared__ int sh_nadd;
   __shared__ int picks[2 * BM_MAXB];      // drawn / taken candidates (lane 0 bookkeeping; LDS keeps it out of scratch)
   __shared__ float nx_score[BM_MAXB];
+  __shared__ float sh_u[2 * BM_MAXB];     // the draws' uniforms
+  __shared__ float sh_hs[BM_MAXB];        // closed-hypothesis scores of this batch element
+  __shared__ int sh_nh;
+  __shared__ float sh_worst;
 
   const int b = blockIdx.x, tid = threadIdx.x;
   const int nb = p.nb, V = p.V;
@@ -308,31 +312,44 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p) {
       si[rank] = id;
     }
     __syncthreads();
-    if (p.do_sample) {   // exp weights in parallel (the serial loop below computed the same values one by one)
+    if (p.do_sample) {
+      // exp weights in parallel (the serial loop computed the same values one by one); the draws' uniforms and the
+      // batch element's hypothesis state (global loads the bookkeeping lane would otherwise wait for) meanwhile
       for (int j = tid; j < np; j += 256) { cs[j] = expf(ss[j] - ss[0]); ci[j] = 1; }
-      __syncthreads();
+      if (tid >= 64 && tid < 64 + 2 * BM_MAXB) {
+        const int i = tid - 64;
+        // key = launch argument + the 64-bit seed held in state[4..5] (lets a captured launch serve every seed)
+        const uint64_t key = (((uint64_t)p.seed_hi << 32) | p.seed_lo) + (((uint64_t)(uint32_t)p.state[5] << 32) | (uint32_t)p.state[4]);
+        uint32_t x = philox_first3((uint32_t)b, (uint32_t)k, (uint32_t)i, (uint32_t)key, (uint32_t)(key >> 32));
+        sh_u[i] = (float)(x >> 8) * (1.0f / 16777216.0f);
+      }
     }
+    if (tid >= 128 && tid < 128 + BM_MAXB) sh_hs[tid - 128] = (tid - 128) < nb ? p.hyp_score[b * nb + (tid - 128)] : 0.f;
+    if (tid == 192) { sh_nh = p.n_hyp[b]; sh_worst = p.worst[b]; }
+    __syncthreads();
     if (tid == 0) {
       int npick = 0;
       const int want = min(2 * nb, np);
       if (p.do_sample) {
-        // key = launch argument + the 64-bit seed held in state[4..5] (lets a captured launch serve every seed)
-        const uint64_t key = (((uint64_t)p.seed_hi << 32) | p.seed_lo) + (((uint64_t)(uint32_t)p.state[5] << 32) | (uint32_t)p.state[4]);
+        // Draws without replacement.  A drawn candidate's weight becomes 0: adding +0 leaves the fp32 running sums exactly
+        // what "skip the dead entries" gave, and both passes are straight loops the compiler can pipeline (they were
+        // branchy LDS chases: 60 us per step at 32 x 3).
         for (int i = 0; i < want; ++i) {
           float total = 0.f;
-          for (int j = 0; j < np; ++j) if (ci[j]) total += cs[j];
-          uint32_t x = philox_first3((uint32_t)b, (uint32_t)k, (uint32_t)i, (uint32_t)key, (uint32_t)(key >> 32));
-          float u = (float)(x >> 8) * (1.0f / 16777216.0f);
-          float thr2 = u * total, run = 0.f;
-          int pick = -1, last = -1;
+          for (int j = 0; j < np; ++j) total += cs[j];
+          const float thr2 = sh_u[i] * total;
+          float run = 0.f;
+          int pick = -1;
           for (int j = 0; j < np; ++j) {
-            if (!ci[j]) continue;
-            last = j;
             run += cs[j];
-            if (run > thr2) { pick = j; break; }
+            pick = (pick < 0 && run > thr2) ? j : pick;   // first j whose running sum passes: necessarily a live one
           }
-          if (pick < 0) pick = last;
+          if (pick < 0) {                                  // rounding left the last running sum at or below u * total
+            for (int j = np - 1; j >= 0; --j)
+              if (ci[j]) { pick = j; break; }
+          }
           ci[pick] = 0;
+          cs[pick] = 0.f;
           picks[npick++] = pick;
         }
         // torch.sort(descending) of the drawn scores; stable in draw order (insertion sort)
@@ -345,11 +362,11 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p) {
       } else {
         for (int i = 0; i < want; ++i) picks[npick++] = i;
       }
-      // ---- BeamSearchScorer.process for this batch element
+      // ---- BeamSearchScorer.process for this batch element (hypothesis scores mirrored in LDS: sh_hs)
       const float gen = (float)(k + 1);                         // cur_len - decoder_prompt_len
       const float lp_div = p.length_penalty == 0.f ? 1.f : powf(gen, p.length_penalty);
-      int nxt = 0, nh = p.n_hyp[b];
-      float worst = p.worst[b];
+      int nxt = 0, nh = sh_nh;
+      float worst = sh_worst;
       float best = -INFINITY;
       for (int i = 0; i < npick; ++i) best = fmaxf(best, ss[picks[i]]);
       for (int rank = 0; rank < npick && nxt < nb; ++rank) {
@@ -366,15 +383,16 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamParams p) {
             } else {  // evict the worst (lowest score, earliest slot)
               slot = 0;
               for (int h = 1; h < nb; ++h)
-                if (p.hyp_score[b * nb + h] < p.hyp_score[b * nb + slot]) slot = h;
+                if (sh_hs[h] < sh_hs[slot]) slot = h;
             }
+            sh_hs[slot] = hs;
             p.hyp_score[b * nb + slot] = hs;
             p.hyp_len[b * nb + slot] = k;
             add_slot[sh_nadd] = slot;
             add_beam[sh_nadd] = beam;
             ++sh_nadd;
-            worst = p.hyp_score[b * nb];
-            for (int h = 1; h < nh; ++h) worst = fminf(worst, p.hyp_score[b * nb + h]);
+            worst = sh_hs[0];
+            for (int h = 1; h < nh; ++h) worst = fminf(worst, sh_hs[h]);
           }
         } else {
           nx_tok[nxt] = tok;
