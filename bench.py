@@ -593,9 +593,10 @@ def main():
         beam_us = 1e3 * peb["prefilled"].elapsed_time(peb["decoded"]) / (MEL_TOKENS + 1)
         result["beam_sample"] = {"num_beams": 3, "rows": 3 * BATCH, "us_per_token": round(beam_us, 1),
                                  "ratio_to_num_beams_1": round(beam_us / step_us, 3), "kv": eng.beam_kv,
+                                 "prefill_ms": round(peb["conditioned"].elapsed_time(peb["prefilled"]), 2),
                                  "whole_step_ms": round(peb["start"].elapsed_time(peb["vocoded"]), 2),
                                  "note": "batch 32 x 3 beams, 141 tokens, top-k/top-p beam-sample on device; one weight pass per "
-                                         "token for all 96 rows"}
+                                         "token for all 96 rows; prompt prefilled and cached once per batch element (row table)"}
         log(f"[bench] beam-sample 32x3: {beam_us:.1f} us/token ({beam_us / step_us:.2f}x the num_beams=1 token)")
 
     if rank == 0 and not args.no_roofline:

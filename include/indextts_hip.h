@@ -222,7 +222,9 @@ int itts_embed_step(const int32_t* tokens, const float* table, const float* pos_
  * keys j in [pad[b], *pos] are visible (the key at *pos was just appended).  scale 1/8.  out_packed != 0: out is written in
  * the packed activation layout (M = B, K = H*64).
  * kv_rows / kv_step (both or neither): beam search without cache copies -- position j of logical row b is read from
- * physical cache row kv_rows[(*kv_step & 1)][b][j] (int32 [2][B][smax], maintained by itts_beam_step). */
+ * physical cache row kv_rows[(*kv_step & 1)][b][j] (int32 [2][B][smax], maintained by itts_beam_kv_rows).
+ * Entries of different rows may name the SAME physical row (the beams of a batch element share their prompt and common
+ * history; the engine caches the prompt once per batch element). */
 int itts_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, const int32_t* pad,
                      const int32_t* pos, int B, int H, int smax, int dtype, int out_packed, const int32_t* kv_rows,
                      const int32_t* kv_step, void* stream);

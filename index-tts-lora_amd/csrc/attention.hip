@@ -317,8 +317,8 @@ extern "C" int itts_attn_decode(const void* q, const void* kcache, const void* v
   ITTS_REQUIRE(B > 0 && H > 0 && smax > 0 && smax <= AD_MAXCTX, "itts_attn_decode: bad shape B=%d H=%d smax=%d (max %d)", B, H,
                smax, AD_MAXCTX);
   ITTS_REQUIRE((kv_rows == nullptr) == (kv_step == nullptr), "itts_attn_decode: pass both or neither of kv_rows / kv_step");
-  dim3 grid(H, B), block(g_attn_waves * 64);
   hipStream_t s = (hipStream_t)stream;
+  dim3 grid(H, B), block(g_attn_waves * 64);
   const bool ind = kv_rows != nullptr;
 #define ITTS_AD(TT_, NW_, IND_)                                                                                             \
   hipLaunchKernelGGL((attn_decode_kernel<TT_, NW_, IND_>), grid, block, 0, s, (const TT_*)q, (const TT_*)kcache,           \

@@ -57,6 +57,7 @@ class GPTEngine:
         # GPT2InferenceModel._reorder_cache, model.py:207-218; 1 ms per token at 32 x 3 rows)
         self.beam_kv = os.environ.get("ITTS_BEAM_KV", "table")
         self._kv_rows = None   # the table of the beam decode in progress (None outside decode_beam)
+        self._shared_prefix = None   # (B, num_beams) after prefill(beams=n): the prompt's K/V exists once per batch element
         self.max_rows_per_launch = 16 if dtype == torch.float32 else 96   # rows one skinny-GEMM launch covers
 
         self._W = W          # kept (by reference) for attach_lora: the engine itself only holds packed copies
@@ -217,15 +218,22 @@ class GPTEngine:
         nat.gemm_skinny(self.dtype, B, self.V, self.D, self.w_head, self.b_head, x=self.xn, epi=nat.EPI_STORE_F32,
                         yf=self.logits, x_packed=self.pa)
 
-    def prefill(self, prefix_emb: torch.Tensor, pad: torch.Tensor, max_new: int):
+    def prefill(self, prefix_emb: torch.Tensor, pad: torch.Tensor, max_new: int, beams: int = 1):
         """prefix_emb fp32 [B,P,D] (left-padded with zeros), pad int [B].  Runs prefix + start token (mel position 0,
         model.py:152-162), fills the KV cache rows [pad_b, P] of every element, leaves logits of the last position in
         self.logits.  The left-padding rows are never computed: the real rows are packed (one gather), the GEMMs run over
         sum(P + 1 - pad_b) rows instead of B*(P+1), and the attention kernel writes each element's keys at its padded
-        cache position, so the decode loop sees the reference's left-padded cache layout."""
+        cache position, so the decode loop sees the reference's left-padded cache layout.
+        beams > 1 (beam search with the row table): HF expands every row to `beams` identical rows BEFORE the first forward;
+        here the prompt is computed and cached ONCE per batch element (cache rows 0..B-1) and decode_beam() points the table
+        entries of all its beams at that copy -- a third of the prefill work and prompt cache at 3 beams, identical values
+        (the expanded rows are bit-wise copies).  The engine then holds B*beams rows: logits and pad are expanded here."""
         B, P, D = prefix_emb.shape
         S = P + 1
-        self._ensure(B, S + max_new + 1)
+        beams = int(beams)
+        if beams > 1 and self.beam_kv != "table":
+            raise ValueError("prefill(beams>1) needs the KV row table (beam_kv='table')")
+        self._ensure(B * beams, S + max_new + 1)
         dev = self.device
         start = self.mel_emb[self.start_mel] + self.mel_pos[0]
         emb = torch.cat([prefix_emb.to(dev, torch.float32), start.expand(B, 1, D)], dim=1).contiguous()
@@ -248,7 +256,14 @@ class GPTEngine:
         self.finished[:B] = 0
         self.history[:B].zero_()
         self._B, self._S = B, S
-        return self.logits[:B]
+        self._shared_prefix = None
+        if beams > 1:
+            R = B * beams
+            self.logits[:R] = self.logits[:B].repeat_interleave(beams, dim=0)
+            self.pad[:R] = self.pad[:B].repeat_interleave(beams)
+            self._B = R
+            self._shared_prefix = (B, beams)
+        return self.logits[: self._B]
 
     def latent(self, emb: torch.Tensor, lengths=None) -> torch.Tensor:
         """Teacher-forced pass (model.py:459-474): emb fp32 [B,S,D] (right-padded rows allowed) ->
@@ -472,6 +487,8 @@ class GPTEngine:
         right-padded with the stop token."""
         nb = int(num_beams)
         R = self._B
+        if self._shared_prefix is not None and self._shared_prefix[1] != nb:
+            raise ValueError("decode_beam(): prefill(beams=...) was given another beam count")
         assert R % nb == 0, "prefill() must have been given B*num_beams rows"
         B = R // nb
         if self._S + max_new + 1 > self._cap_s:
@@ -483,8 +500,13 @@ class GPTEngine:
         self.b_n_hyp.zero_()
         self.b_worst.fill_(1e9)
         self.b_done.zero_()
+        if self._shared_prefix is not None and self._shared_prefix != (B, nb):
+            raise ValueError("decode_beam(): prefill(beams=...) was given another batch / beam count")
         if self.beam_kv == "table":
-            self.b_kv_rows[0] = torch.arange(R, dtype=torch.int32, device=self.device)[:, None]   # identity: every row holds itself
+            rows = torch.arange(R, dtype=torch.int32, device=self.device)
+            self.b_kv_rows[0] = rows[:, None]           # identity: every row holds itself ...
+            if self._shared_prefix is not None:         # ... except the prompt, cached once per batch element in row b
+                self.b_kv_rows[0][:, : self._S] = (rows // nb)[:, None]
             self._kv_rows = self.b_kv_rows
         else:
             self._kv_rows = None

@@ -187,7 +187,10 @@ class UnifiedVoice:
             if force_stop is not None or return_logits:
                 raise NotImplementedError("force_stop / return_logits are measurement aids of the num_beams=1 loop")
             sp["length_penalty"] = length_penalty
-            self.engine.prefill(emb.repeat_interleave(num_beams, dim=0), pad.repeat_interleave(num_beams), max_new)
+            if self.engine.beam_kv == "table":   # prompt computed and cached once per batch element (row table)
+                self.engine.prefill(emb, pad, max_new, beams=num_beams)
+            else:
+                self.engine.prefill(emb.repeat_interleave(num_beams, dim=0), pad.repeat_interleave(num_beams), max_new)
             return self.engine.decode_beam(max_new, sp, num_beams)
         self.engine.prefill(emb, pad, max_new)
         out = self.engine.decode(max_new, sp, force_stop=force_stop, return_logits=return_logits)

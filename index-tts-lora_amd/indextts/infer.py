@@ -582,7 +582,10 @@ class IndexTTS:
             if force_stop is not None:
                 raise NotImplementedError("force_stop is a measurement aid of the num_beams=1 loop")
             sp["length_penalty"] = float(gen.get("length_penalty", 0.0))
-            g.engine.prefill(emb.repeat_interleave(nb, dim=0), pad.repeat_interleave(nb), max_mel_tokens)
+            if g.engine.beam_kv == "table":    # the prompt is computed and cached once per batch element (row table)
+                g.engine.prefill(emb, pad, max_mel_tokens, beams=nb)
+            else:                              # generate() expands every row to num_beams copies before the first forward
+                g.engine.prefill(emb.repeat_interleave(nb, dim=0), pad.repeat_interleave(nb), max_mel_tokens)
             self._mark(phase_events, "prefilled")
             codes = g.engine.decode_beam(max_mel_tokens, sp, nb)
         else:

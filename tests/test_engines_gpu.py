@@ -249,6 +249,19 @@ def test_beam_decode_matches_host_driven_oracle(gpt_small_fp32, do_sample):
             assert np.array_equal(got[:, :w], want[:, :w]), (kv, use_graph, got, want)
             assert (got[:, w:] == 8193).all() and (want[:, w:] == 8193).all()
     eng.beam_kv = "table"
+    # shared prefix: the prompt computed and cached ONCE per batch element, all its beams' table entries point at it
+    for use_graph in (False, True):
+        eng.prefill(emb, pad, max_new, beams=nb)
+        got = eng.decode_beam(max_new, sp, nb, use_graph=use_graph, check_every=4).cpu().numpy()
+        w = min(got.shape[1], want.shape[1])
+        assert np.array_equal(got[:, :w], want[:, :w]), ("shared", use_graph, got, want)
+    with pytest.raises(ValueError):
+        eng.prefill(emb, pad, max_new, beams=nb)
+        eng.decode_beam(max_new, sp, nb + 1)
+    eng.beam_kv = "copy"
+    with pytest.raises(ValueError):
+        eng.prefill(emb, pad, max_new, beams=nb)      # sharing the prompt needs the table
+    eng.beam_kv = "table"
     # the reference-API entry point takes the same route
     codes = m.inference_speech(cond_mel, text, do_sample=do_sample, num_beams=nb, top_k=30, top_p=0.8, temperature=1.0,
                                repetition_penalty=10.0, length_penalty=0.0, max_generate_length=max_new, seed=5)

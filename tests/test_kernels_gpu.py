@@ -700,6 +700,36 @@ def test_attn_decode_row_table_equals_permuted_cache(nat, dtype):
     assert not torch.equal(kc, kc2)   # the table form never moved a cache row
 
 
+@pytest.mark.parametrize("nb", [2, 3, 5])
+def test_attn_decode_row_table_shared_prefix(nat, nb):
+    """Table entries of several rows naming ONE physical row (the prompt cached once per batch element, prefill(beams=n),
+    plus partly shared generated positions) against a gather of the cache into private rows: same bits, ragged padding, a
+    context that is not a multiple of the chunk."""
+    dtype = torch.bfloat16
+    B, H, smax, S, ctx = 3, 3, 320, 150, 301
+    R, D = B * nb, H * 64
+    kc, vc = rnd(R, H, smax, 64, seed=310).to(dtype), rnd(R, H, smax, 64, seed=311).to(dtype)
+    pad = torch.tensor([0, 17, 149], dtype=torch.int32, device=DEV).repeat_interleave(nb)
+    g = torch.Generator().manual_seed(5)
+    rows = torch.arange(R, dtype=torch.int32)
+    first = (rows // nb) * nb
+    t1 = rows[:, None].repeat(1, smax)
+    t1[:, :S] = (rows // nb)[:, None]                            # the prompt: cached once, in row b
+    anc = first[:, None] + torch.randint(0, nb, (R, smax), generator=g, dtype=torch.int32)
+    common = first[:, None] + torch.randint(0, nb, (B, smax), generator=g, dtype=torch.int32).repeat_interleave(nb, 0)
+    mix = torch.where(torch.rand(R, smax, generator=g) < 0.3, anc, common)   # 30 % private ancestors
+    t1[:, S:ctx - 1] = mix[:, S:ctx - 1]
+    tbl = torch.stack([torch.zeros_like(t1), t1]).to(DEV)
+    step = torch.tensor([1], dtype=torch.int32, device=DEV)       # parity 1
+    pos = torch.tensor([ctx - 1], dtype=torch.int32, device=DEV)
+    q = rnd(R, D, seed=312).to(dtype)
+    out_t, out_g = torch.empty(R, D, dtype=dtype, device=DEV), torch.empty(R, D, dtype=dtype, device=DEV)
+    nat.attn_decode(q, kc, vc, out_t, pad, pos, R, H, smax, kv_rows=tbl, kv_step=step)
+    idx = tbl[1].long()[:, None, :, None].expand(R, H, smax, 64)  # private copies: row r position j <- row tbl[r][j]
+    nat.attn_decode(q, torch.gather(kc, 0, idx), torch.gather(vc, 0, idx), out_g, pad, pos, R, H, smax)
+    assert torch.isfinite(out_t.float()).all() and torch.equal(out_t, out_g)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_attn_prefill_packed_equals_left_padded(nat, dtype):
     """Packed rows (no padding rows at all) give the attention outputs and the KV cache contents of the left-padded form
