@@ -181,6 +181,10 @@ CONV_CASES = [
     (1, 5, 96, 96, 3, 3),
     # narrow persistent kernel: tile tails, several batch rows, every (k, dilation) class of the AMP blocks
     (3, 777, 48, 48, 7, 3), (2, 1030, 48, 48, 11, 1), (3, 257, 24, 24, 3, 5), (1, 4100, 24, 24, 7, 1), (2, 3, 48, 48, 11, 5),
+    # persistent grid of the tiled kernel (N % 64 / N % 96 tiles): more tiles than resident workgroups (each workgroup walks
+    # 2-3 tiles with the next tile's rows prefetched under the epilogue), tile counts that are not a multiple of the grid,
+    # a ragged last row tile; and the 4-wave side-by-side tile (N % 128) over several batch elements and column blocks
+    (5, 20011, 96, 96, 7, 1), (3, 17003, 192, 192, 3, 5), (7, 1111, 96, 192, 7, 3), (5, 1301, 384, 256, 3, 1),
 ]
 
 
