@@ -520,11 +520,19 @@ static int launch_conv(const ConvParams& p, hipStream_t s) {
   // second round.  Otherwise one workgroup per tile, dispatched by the hardware as CUs free up.
   int64_t g = total;
   if (PERSIST || (ITTS_CONV_EXP(q) & 32)) {
-    int per_cu = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gemm_conv_kernel<T, WM, WN, TM, TN, CK, HALO>,
-                                                     WM * WN * 64, ldsb) != hipSuccess || per_cu < 1)
-      per_cu = 1;
-    (void)hipGetLastError();
+    // one occupancy query per (instantiation, LDS size) and thread: a vocoder pass launches ~100 of these
+    static thread_local size_t occ_lds = ~(size_t)0;
+    static thread_local int occ_wgs = 1;
+    if (occ_lds != ldsb) {
+      int q_wgs = 1;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q_wgs, (const void*)gemm_conv_kernel<T, WM, WN, TM, TN, CK, HALO>,
+                                                       WM * WN * 64, ldsb) != hipSuccess || q_wgs < 1)
+        q_wgs = 1;
+      (void)hipGetLastError();
+      occ_lds = ldsb;
+      occ_wgs = q_wgs;
+    }
+    const int per_cu = occ_wgs;
     g = (int64_t)conv_num_cus() * per_cu;
     if (g > total) g = total;
   }

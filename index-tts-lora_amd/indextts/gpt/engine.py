@@ -414,6 +414,8 @@ class GPTEngine:
         """Run the sampling loop after prefill().  Returns codes int64 [B, n] padded with the stop token
         (HF generate semantics: rows that emitted EOS keep emitting pad = EOS)."""
         B = self._B
+        if self._shared_prefix is not None:
+            raise ValueError("decode(): prefill(beams=n) cached the prompt once per batch element; only decode_beam() can follow it")
         if self._S + max_new + 1 > self._cap_s:
             raise ValueError("decode(): max_new exceeds the capacity reserved by prefill()")
         if force_stop is None:
