@@ -714,10 +714,17 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(ConvParams p) {
   const int g = lane >> 4, r = lane & 15;
   constexpr unsigned OOB = 0xFFFFFFFFu;
 
+#if ITTS_STAMPS
+  __shared__ unsigned long long st_[16];   // [0] start [1] weights staged; tiles 0 / 1 of wave 0: [2,3,4] / [6,7,8] = start, taps done, epilogue issued; [5] end; [9] tiles
+  if (tid < 16) st_[tid] = 0;
+  int ntile_ = 0;
+#endif
+  CSTAMP(0);
   // weights -> LDS (same block order as in memory: ((tap*NT + nt)*KT + ks) KiB)
   const int wbytes = p.taps * NT * KT * 1024;
   for (int off = tid * 16; off < wbytes; off += 256 * 16) st16(lds + off, ld16<frag>((const unsigned char*)p.wp + off));
   __syncthreads();
+  CSTAMP(1);
 
   const int ntiles = p.MB * p.B;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -755,6 +762,10 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(ConvParams p) {
         }
     };
     frag a0[TM][KT], a1[TM][KT];
+#if ITTS_STAMPS
+    if (ntile_ == 0) CSTAMP(2);
+    if (ntile_ == 1) CSTAMP(6);
+#endif
     load_a(a0, 0);
     for (int j = 0; j < p.taps; j += 2) {
       load_a(a1, j + 1);            // past the last tap: out-of-range offsets, no memory traffic
@@ -762,8 +773,31 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(ConvParams p) {
       load_a(a0, j + 2);
       if (j + 1 < p.taps) mma_tap(a1, j + 1);
     }
+#if ITTS_STAMPS
+    asm volatile("" ::"v"(acc[0][0]));
+    if (ntile_ == 0) CSTAMP(3);
+    if (ntile_ == 1) CSTAMP(7);
+#endif
     conv_epilogue<T, TM, NT>(p, acc, b, row0, 0, g, r);
+#if ITTS_STAMPS
+    if (ntile_ == 0) CSTAMP(4);
+    if (ntile_ == 1) CSTAMP(8);
+    ++ntile_;
+#endif
   }
+#if ITTS_STAMPS
+  if (p.stamps != nullptr && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long te_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te_)::"memory");
+    st_[5] = te_;
+    st_[9] = (unsigned long long)ntile_;
+    st_[14] = 1;
+    st_[15] = 2;
+  }
+  __syncthreads();
+  if (p.stamps != nullptr && tid < 16) p.stamps[(size_t)blockIdx.x * 16 + tid] = st_[tid];
+#endif
 }
 
 template <typename T, int KT, int NT>
@@ -782,7 +816,9 @@ static int launch_narrow(const ConvParams& p, hipStream_t s) {
   if (grid > tiles) grid = tiles;
   static std::once_flag attr;
   std::call_once(attr, [] {
-    (void)hipFuncSetAttribute((const void*)conv_narrow_kernel<T, KT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_narrow_kernel<T, KT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024 - 256);   // minus the diagnostic build's static stamp block
+    (void)hipGetLastError();
   });
   hipLaunchKernelGGL((conv_narrow_kernel<T, KT, NT>), dim3((unsigned)grid), dim3(256), ldsb, s, q);
   return check_launch("itts_gemm_conv");
