@@ -705,7 +705,7 @@ static int launch_plain(const ConvParams& p, hipStream_t s) {
 //     row loop; the next tap's fragments are requested before the current tap is multiplied.
 // -------------------------------------------------------------------------------------------------------------------
 template <typename T, int KT, int NT>
-__global__ __launch_bounds__(256) void conv_narrow_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, (KT * NT <= 1 ? 4 : (KT * NT <= 6 ? 3 : 2))) void conv_narrow_kernel(ConvParams p) {
   typedef Elem<T> EL;
   typedef typename EL::frag frag;
   constexpr int E = EL::E, KS = EL::KS, TM = 4, BM = 4 * TM * 16;
@@ -810,16 +810,27 @@ static int launch_narrow(const ConvParams& p, hipStream_t s) {
   const int64_t tiles = (int64_t)q.MB * p.B;
   const size_t ldsb = (size_t)p.taps * NT * KT * 1024;
   // persistent grid: as many workgroups as stay resident (LDS- and register-bound), each walking tiles with stride grid
-  int per_cu = (int)((160 * 1024) / (ldsb > 0 ? ldsb : 1));
-  per_cu = per_cu < 1 ? 1 : (per_cu > 6 ? 6 : per_cu);
-  int64_t grid = 256 * (int64_t)per_cu;
-  if (grid > tiles) grid = tiles;
   static std::once_flag attr;
   std::call_once(attr, [] {
     (void)hipFuncSetAttribute((const void*)conv_narrow_kernel<T, KT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024 - 256);   // minus the diagnostic build's static stamp block
     (void)hipGetLastError();
   });
+  // persistent grid = the workgroups that are actually resident (registers and LDS both limit them; the first version
+  // asked for up to 6 per CU by LDS alone and ran in rounds: tools/timeline_narrow.py)
+  static thread_local size_t occ_lds = ~(size_t)0;
+  static thread_local int occ_wgs = 1;
+  if (occ_lds != ldsb) {
+    int q_wgs = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q_wgs, (const void*)conv_narrow_kernel<T, KT, NT>, 256, ldsb) != hipSuccess ||
+        q_wgs < 1)
+      q_wgs = 1;
+    (void)hipGetLastError();
+    occ_lds = ldsb;
+    occ_wgs = q_wgs;
+  }
+  int64_t grid = (int64_t)conv_num_cus() * occ_wgs;
+  if (grid > tiles) grid = tiles;
   hipLaunchKernelGGL((conv_narrow_kernel<T, KT, NT>), dim3((unsigned)grid), dim3(256), ldsb, s, q);
   return check_launch("itts_gemm_conv");
 }
