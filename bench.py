@@ -687,6 +687,26 @@ def main():
                                     "frac": round(frames * 3.01e9 / voc_s / 1e12 / PEAK_MFMA_TFLOPS, 4)},
                            "hbm": {"achieved": round(frames * 9.7e6 / voc_s / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": round(frames * 9.7e6 / voc_s / 1e9 / PEAK_HBM_GBS, 4)}}
+        # per-stage achieved TFLOP/s and GB/s of one more vocoder pass over a step's latents (events at the stage boundaries)
+        try:
+            lat_b = torch.randn(BATCH, int(force[0]), 1280, device=cond_mel.device)
+            spk_b = tts._spk(cond_mel)
+            tts.bigvgan(lat_b, speaker_embedding=spk_b)            # warm
+            prof = []
+            tts.bigvgan(lat_b, speaker_embedding=spk_b, profile=prof)
+            torch.cuda.synchronize()
+            stages = []
+            for (n0, e0, _, _), (n1, e1, fl, by) in zip(prof[:-1], prof[1:]):
+                ms_ = e0.elapsed_time(e1)
+                stages.append({"stage": n1, "ms": round(ms_, 3), "GFLOP": round(fl / 1e9, 1), "MB": round(by / 1e6, 1),
+                               "TFLOPs": round(fl / ms_ / 1e9, 1), "GBps": round(by / ms_ / 1e6, 1),
+                               "frac_mfma": round(fl / ms_ / 1e9 / PEAK_MFMA_TFLOPS, 4),
+                               "frac_hbm": round(by / ms_ / 1e6 / PEAK_HBM_GBS, 4)})
+            roof["vocoder"]["stages"] = stages
+            roof["vocoder"]["stages_note"] = (f"one extra pass over [{BATCH}, {int(force[0])}, 1280] random latents; FLOP = the "
+                                              "convolutions' 2*rows*Cout*Cin*taps, bytes = every launch's operands in fp16")
+        except Exception as e:   # a measurement aid must not take the line down
+            roof["vocoder"]["stages_error"] = repr(e)
         result["roofline"] = roof
         result["kernel_breakdown"] = breakdown
         result["event_pair_overhead_us"] = round(1e3 * kt.overhead_ms, 2)

@@ -183,11 +183,29 @@ class BigVGAN:
         return nat.aa_snake(x, ab[0], ab[1], P["up_f"], P["down_f"], layout=0, out=out)
 
     def forward(self, x: torch.Tensor, mel_ref: torch.Tensor = None, lens=None, speaker_embedding: torch.Tensor = None,
-                taps: dict | None = None):
-        """x: GPT latent [B,T,gpt_dim]; mel_ref [B,Tref,100] (or a precomputed speaker_embedding [B,1,512])."""
+                taps: dict | None = None, profile: list | None = None):
+        """x: GPT latent [B,T,gpt_dim]; mel_ref [B,Tref,100] (or a precomputed speaker_embedding [B,1,512]).
+        profile (measurement aid, bench.py): a list that receives one [name, cuda event, FLOP, algorithmic bytes] entry per
+        stage boundary -- FLOP = 2 * rows * Cout * Cin * taps of the convolutions launched since the previous entry, bytes =
+        every launch's input + output (+ residual / accumulate operand) elements in the storage type."""
         self._build()
         P, T, dev = self._built, self.dtype, self.device
         B, Tn, _ = x.shape
+        es = torch.empty((), dtype=T).element_size()
+        work = [0.0, 0.0]
+
+        def conv_work(rows, cin, cout, k, extra_ops=0):
+            work[0] += 2.0 * B * rows * cin * cout * k
+            work[1] += B * rows * (cin + cout * (1 + extra_ops)) * es
+
+        def mark(name):
+            if profile is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                profile.append([name, ev, work[0], work[1]])
+                work[0] = work[1] = 0.0
+
+        mark("start")
         x = x.to(dev, T).contiguous()
         spk = speaker_embedding if speaker_embedding is not None else self.speaker_embedding(mel_ref)
         spk = spk.to(dev, torch.float32).reshape(spk.shape[0], -1)
@@ -197,6 +215,8 @@ class BigVGAN:
         cond = F.linear(spk, P["cond0"][0], P["cond0"][1]).contiguous()
         cur = torch.empty(B, Tn, c, dtype=T, device=dev)
         nat.gemm_conv(T, B, Tn, Tn, self.gpt_dim, c, P["pre_w"], x, cur, taps=7, off0=-3, dil=1, bias=P["pre_b"], bias2=cond)
+        conv_work(Tn, self.gpt_dim, c, 7)
+        mark("conditioning linear + conv_pre")
         if taps is not None:
             taps["conv_pre_cond"] = cur
         nk = len(self.res_k)
@@ -210,6 +230,7 @@ class BigVGAN:
             rows = Tn + 1 if up["taps"] == 2 else Tn
             nat.gemm_conv(T, B, Tn, rows, up["cin"], u * c, up["w"], cur, xu, taps=up["taps"], off0=up["off0"], dil=1,
                           bias=up["b"], bias2=b2, y_bstride=Tu * c, y_shift=up["shift"], y_limit=Tu * c)
+            conv_work(rows, up["cin"], u * c, up["taps"])
             if taps is not None:
                 taps[f"up{i}_cond"] = xu
             xs = torch.empty_like(xu)
@@ -221,6 +242,9 @@ class BigVGAN:
                 xc = xu
                 nd = len(blk["dil"])
                 for n, d in enumerate(blk["dil"]):
+                    work[1] += 4 * B * Tu * c * es          # two activations: read + write each
+                    conv_work(Tu, c, c, k)
+                    conv_work(Tu, c, c, k, extra_ops=1 if (n + 1 < nd or j == 0) else 2)   # + residual (+ accumulate)
                     self._act(xc, blk["act"][2 * n], out=ba)
                     nat.gemm_conv(T, B, Tu, Tu, c, c, blk["c1"][n][0], ba, bb, taps=k, off0=-((k * d - d) // 2), dil=d,
                                   bias=blk["c1"][n][1])
@@ -233,6 +257,7 @@ class BigVGAN:
                         nat.gemm_conv(T, B, Tu, Tu, c, c, blk["c2"][n][0], ba, xs, taps=k, off0=-((k - 1) // 2), dil=1,
                                       bias=blk["c2"][n][1], resid=xc, accumulate=(j > 0), scale=1.0 / nk)
             cur, Tn = xs, Tu
+            mark(f"stage {i}: x{u} upsampler + {nk} AMP blocks at C = {c}, T = {Tu}")
             if taps is not None:
                 taps[f"stage{i}"] = cur
         a = self._act(cur, P["act_post"])
@@ -240,6 +265,9 @@ class BigVGAN:
         nat.gemm_conv(T, B, Tn, Tn, c, 1, P["post_w"], a, y, taps=7, off0=-3, dil=1, bias=P["post_b"])
         wav = torch.empty(B, 1, Tn, dtype=torch.float32, device=dev)
         nat.tanh_pcm(y, wav=wav, pcm=None, apply_tanh=True)
+        work[1] += 2 * B * Tn * c * es + B * Tn * 4
+        conv_work(Tn, c, 1, 7)
+        mark("activation + conv_post + tanh")
         return wav, None
 
     __call__ = forward
