@@ -173,6 +173,19 @@ def test_bigvgan_half_tracks_fp32(dtype, tol):
     w, _ = v(torch.from_numpy(g["latent8"]).to(DEV), torch.from_numpy(g["melref"]).to(DEV))
     rms = (w.cpu() - torch.from_numpy(g["wav8"])).pow(2).mean().sqrt().item()
     assert rms < tol, rms
+    # the measurement hook of bench.py's per-stage roofline: one entry per stage boundary, the same waveform, and the work
+    # it accounts for is the generator's 3.01 GFLOP per frame within the halo rows of the 2-tap upsamplers
+    prof = []
+    lat = torch.from_numpy(g["latent8"]).to(DEV)
+    w2, _ = v(lat, torch.from_numpy(g["melref"]).to(DEV), profile=prof)
+    assert torch.equal(w, w2)
+    assert [e[0] for e in prof][0] == "start" and len(prof) == 2 + len(v.rates) + 1
+    torch.cuda.synchronize()
+    assert all(a[1].elapsed_time(b[1]) >= 0.0 for a, b in zip(prof[:-1], prof[1:]))
+    frames = lat.shape[0] * lat.shape[1]
+    gflop_per_frame = sum(e[2] for e in prof) / frames / 1e9
+    assert 2.9 < gflop_per_frame < 3.4, gflop_per_frame
+    assert all(e[3] > 0 for e in prof[1:])
 
 
 def test_batch_pipeline_equals_serial_infer_batch():
