@@ -74,9 +74,12 @@ int64_t itts_packed_bytes(int taps, int K, int N, int dtype);
  *   replicate-pad 5 | x2 zero-stuffed 12-tap FIR (gain 2) | x + sin^2(x e^alpha)/(e^beta + 1e-9) | replicate-pad 5/6
  *   | 12-tap stride-2 FIR.   alpha/beta are the log-scale per-channel parameters; fp32 accumulation.
  * layout 0: x,y are [B][T][C] (channels-last, product path);  layout 1: [B][C][T] (the reference op's layout).
+ * valid_rows (layout 0 only, NULL = all T rows): int32 [B] on the device, the length of each batch element's sequence --
+ * the filters' replicate padding clamps there, as if the element were processed alone; rows past it are not written.
  * ------------------------------------------------------------------------------------------------------------------ */
 int itts_aa_snake_fwd(const void* x, void* y, const float* alpha_log, const float* beta_log, const float* up_filter12,
-                      const float* down_filter12, int B, int T, int C, int dtype, int layout, void* stream);
+                      const float* down_filter12, int B, int T, int C, int dtype, int layout, const int32_t* valid_rows,
+                      void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Packed activation layout of the decode step (optional, per operand).  A T-typed activation matrix X[M][K] that a skinny
@@ -173,6 +176,10 @@ typedef struct itts_conv_args {
   const void* resid; /* same mapping as y, or NULL */
   int accumulate;
   float scale;
+  /* ragged batches (NULL = every batch element has Tin valid rows): int32 [B] on the device; input rows >= valid_rows[b]
+   * of batch element b read as zeros -- the convolution's own zero padding, so each element equals a run on its own --
+   * and output tiles that only see that padding are not computed (their rows of y are left untouched). */
+  const int32_t* valid_rows;
 } itts_conv_args;
 int itts_gemm_conv(const itts_conv_args* a, void* stream);
 

@@ -28,7 +28,8 @@ namespace itts {
 template <typename T, int CS>
 __global__ __launch_bounds__(256) void aa_snake_btc_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                             const float* __restrict__ alpha_log,
-                                                            const float* __restrict__ beta_log, Fir24 f, int T_len, int C) {
+                                                            const float* __restrict__ beta_log, Fir24 f, int T_full, int C,
+                                                            const int32_t* __restrict__ valid_rows) {
   constexpr int TT = AaTile<CS>::TT;
   typedef AaShape<CS, TT> SH;
   typedef T t4 __attribute__((ext_vector_type(4)));
@@ -40,8 +41,13 @@ __global__ __launch_bounds__(256) void aa_snake_btc_kernel(const T* __restrict__
   const int c0 = blockIdx.y * CS;
   const int b = blockIdx.z;
   const int tid = threadIdx.x;
-  const T* xb = x + (int64_t)b * T_len * C + c0;
-  T* yb = y + (int64_t)b * T_len * C + c0;
+  // ragged batches: this batch element's sequence ends at valid_rows[b] -- the replicate padding of the two filters clamps
+  // there, exactly as if the element were processed alone; tiles past its end are not computed
+  const int T_len = valid_rows != nullptr ? min(max(valid_rows[b], 0), T_full) : T_full;
+  if (t0 >= T_len) return;
+  // batch stride below uses T_full
+  const T* xb = x + (int64_t)b * T_full * C + c0;
+  T* yb = y + (int64_t)b * T_full * C + c0;
   if (tid < CS) {
     ca[tid] = expf(alpha_log[c0 + tid]);
     cb[tid] = 1.0f / (expf(beta_log[c0 + tid]) + 1e-9f);
@@ -418,7 +424,8 @@ using namespace itts;
 
 extern "C" int itts_aa_snake_fwd(const void* x, void* y, const float* alpha_log, const float* beta_log,
                                  const float* up_filter12, const float* down_filter12, int B, int T, int C, int dtype,
-                                 int layout, void* stream) {
+                                 int layout, const int32_t* valid_rows, void* stream) {
+  ITTS_REQUIRE(valid_rows == nullptr || layout == 0, "itts_aa_snake_fwd: valid_rows needs the channels-last layout (0)");
   ITTS_REQUIRE(x && y && alpha_log && beta_log && up_filter12 && down_filter12, "itts_aa_snake_fwd: null pointer");
   ITTS_REQUIRE(B >= 0 && T >= 0 && C > 0, "itts_aa_snake_fwd: bad shape B=%d T=%d C=%d", B, T, C);
   if (B == 0 || T == 0) return ITTS_OK;
@@ -436,7 +443,7 @@ extern "C" int itts_aa_snake_fwd(const void* x, void* y, const float* alpha_log,
     dim3 grid((T + tt - 1) / tt, C / CS, B), block(256);
     ITTS_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "itts_aa_snake_fwd: grid too large");
 #define ITTS_AA_LAUNCH(TT_, CS_) \
-  hipLaunchKernelGGL((aa_snake_btc_kernel<TT_, CS_>), grid, block, 0, s, (const TT_*)x, (TT_*)y, alpha_log, beta_log, f, T, C)
+  hipLaunchKernelGGL((aa_snake_btc_kernel<TT_, CS_>), grid, block, 0, s, (const TT_*)x, (TT_*)y, alpha_log, beta_log, f, T, C, valid_rows)
 #define ITTS_AA_BY_CS(TT_)                         \
   switch (CS) {                                    \
     case 64: ITTS_AA_LAUNCH(TT_, 64); break;       \

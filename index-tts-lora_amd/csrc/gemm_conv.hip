@@ -35,6 +35,7 @@ struct ConvParams {
   float scale;
   int NT, KT;
   int MB, NB, GM;  // m-blocks per batch element, n-blocks, m-blocks per L2 group (XCD-aware tile order)
+  const int32_t* valid_rows;   // [B] or null: input rows >= valid_rows[b] read as zeros, tiles wholly beyond are skipped
   int exp;         // diagnostic build only (itts_debug_set key 5): ablation switches of the tiled kernel, 0 in the product
 #if ITTS_STAMPS
   unsigned long long* stamps;   // diagnostic build: 16 x u64 per workgroup (itts_debug_stamps_conv)
@@ -63,6 +64,11 @@ int g_conv_exp = 0;
 #else
 #define ITTS_CONV_EXP(p) 0
 #endif
+
+// Ragged batches: valid input rows of batch element b (the rest is the convolution's zero padding)
+__device__ __forceinline__ int conv_valid_rows(const ConvParams& p, int b) {
+  return p.valid_rows != nullptr ? min(max(p.valid_rows[b], 0), p.Tin) : p.Tin;
+}
 
 // XCD-aware tile order (speed only): workgroups are dealt round-robin to the 8 XCDs, so give each XCD a CONTIGUOUS
 // run of the tile sequence, and order the sequence so that 32 consecutive tiles form a compact GM x (32/GM) patch of
@@ -282,19 +288,32 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
   const unsigned w_lane = (unsigned)lane * 16;
 
   struct Tile {
-    int b, t0, nt0;
+    int b, t0, nt0, vrows;
   };
   auto tile_at = [&](int L) {
     int mblk, nblk, b;
     tile_of_workgroup(p, L, total, mblk, nblk, b);
-    return Tile{b, mblk * BM, nblk * (BN / 16) + wn * TN};
+    return Tile{b, mblk * BM, nblk * (BN / 16) + wn * TN, conv_valid_rows(p, b)};
+  };
+  // ragged batches: a tile whose every tap reads only the zero padding past its batch element's valid rows is not computed
+  // (its output rows are left as they are: nobody reads them).  next_from(L) = the first tile at or after L, in this
+  // workgroup's stride, that has to be computed.
+  auto next_from = [&](int L) {
+    if (p.valid_rows != nullptr) {
+      while (L < total) {
+        const Tile t = tile_at(L);
+        if (t.t0 + p.off0 < t.vrows) break;
+        L += gridDim.x;
+      }
+    }
+    return L;
   };
 
   f32x4 acc[TM][TN];
   frag stg[MAXST];
   auto prefetch_a = [&](int c, const Tile& tl) {
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T*>((const T*)p.x + (int64_t)tl.b * p.x_bstride), 0, (int)((int64_t)p.Tin * p.Cin * (int)sizeof(T)), 0x00020000);
+        const_cast<T*>((const T*)p.x + (int64_t)tl.b * p.x_bstride), 0, (int)((int64_t)tl.vrows * p.Cin * (int)sizeof(T)), 0x00020000);
 #pragma unroll
     for (int q = 0; q < MAXST; ++q) {
       int idx = tid + q * NTH;
@@ -340,7 +359,7 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
         fc = 0;
         w_off = 0;
         if (f_next < total) w_tile(tile_at(f_next).nt0);
-        f_next += gridDim.x;
+        f_next = next_from(f_next + gridDim.x);
       }
     }
   };
@@ -384,25 +403,29 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
     }
   };
 
-  int L = blockIdx.x;
+  int L = next_from(blockIdx.x);
   if (L >= total) return;
   Tile cur = tile_at(L);
   w_tile(cur.nt0);
-  f_next = L + gridDim.x;
+  f_next = next_from(L + gridDim.x);
   fetch_b(bA);
   prefetch_a(0, cur);
   CSTAMP(1);
-  for (; L < total; L += gridDim.x) {
-    const bool has_next = L + (int)gridDim.x < total;
+#if ITTS_STAMPS
+  bool first_ = true;
+#endif
+  while (L < total) {
+    const int Ln = next_from(L + gridDim.x);
+    const bool has_next = Ln < total;
     Tile nxt = cur;
-    if (has_next) nxt = tile_at(L + gridDim.x);
+    if (has_next) nxt = tile_at(Ln);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int c = 0; c < NC; ++c) {
 #if ITTS_STAMPS
-      const bool stc = (c == 1 && L == (int)blockIdx.x);   // one steady-state chunk of the first tile, decomposed
+      const bool stc = (c == 1 && first_);   // one steady-state chunk of the first tile, decomposed
       if (stc) CSTAMP(6);
 #endif
       // Raw barriers with an LDS-only wait: __syncthreads() would also drain vmcnt, i.e. wait for the weight fragments of the
@@ -411,7 +434,7 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
       commit_a();
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #if ITTS_STAMPS
-      if (c == 0 && L == (int)blockIdx.x) CSTAMP(2);
+      if (c == 0 && first_) CSTAMP(2);
       if (stc) CSTAMP(8);
 #endif
       if (c + 1 < NC) prefetch_a(c + 1, cur);
@@ -462,13 +485,15 @@ __global__ __launch_bounds__(WM * WN * 64, (ConvOcc<WM, WN, TM, TN>::WPS)) void 
       }
     }
 #if ITTS_STAMPS
-    if (L == (int)blockIdx.x) CSTAMP(3);
+    if (first_) CSTAMP(3);
 #endif
     conv_epilogue<T, TM, TN>(p, acc, cur.b, cur.t0 + wm * TM * 16, cur.nt0, g, r);
 #if ITTS_STAMPS
-    if (L == (int)blockIdx.x) CSTAMP(4);
+    if (first_) CSTAMP(4);
+    first_ = false;
 #endif
     cur = nxt;
+    L = Ln;
   }
 #if ITTS_STAMPS
   if (p.stamps != nullptr && tid == 0) {
@@ -571,8 +596,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_plain_kernel(ConvParams 
   const int t0 = mblk * BM;
   const int nt0 = nblk * (BN / 16) + wn * TN;
   const int NC = (p.KT + CK - 1) / CK;
+  const int vrows = conv_valid_rows(p, b);
+  if (t0 + p.off0 >= vrows) return;   // ragged batch: the whole tile lies in this batch element's padding
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T*>((const T*)p.x + (int64_t)b * p.x_bstride), 0, (int)((int64_t)p.Tin * p.Cin * (int)sizeof(T)), 0x00020000);
+      const_cast<T*>((const T*)p.x + (int64_t)b * p.x_bstride), 0, (int)((int64_t)vrows * p.Cin * (int)sizeof(T)), 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.wp), 0, (int)((int64_t)p.NT * p.KT * 1024), 0x00020000);
   constexpr unsigned OOB = 0xFFFFFFFFu;
@@ -592,7 +619,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_plain_kernel(ConvParams 
     int idx = tid + q * NTH;
     int i = idx / SEGS, seg = idx - i * SEGS;
     int tin = t0 + p.off0 + i;
-    bool ok = (i < BM) && (tin >= 0) && (tin < p.Tin);
+    bool ok = (i < BM) && (tin >= 0) && (tin < vrows);
     st_col[q] = seg * E;
     st_goff[q] = ok ? (unsigned)((tin * p.Cin + seg * E) * (int)sizeof(T)) : OOB;
     st_lds[q] = (i < BM) ? i * ROWB + seg * 16 : -1;
@@ -705,7 +732,7 @@ static int launch_plain(const ConvParams& p, hipStream_t s) {
 //     row loop; the next tap's fragments are requested before the current tap is multiplied.
 // -------------------------------------------------------------------------------------------------------------------
 template <typename T, int KT, int NT>
-__global__ __launch_bounds__(256, (KT * NT <= 1 ? 4 : (KT * NT <= 6 ? 3 : 2))) void conv_narrow_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, (KT * NT <= 1 ? 4 : (KT * NT <= 4 ? 3 : 2))) void conv_narrow_kernel(ConvParams p) {
   typedef Elem<T> EL;
   typedef typename EL::frag frag;
   constexpr int E = EL::E, KS = EL::KS, TM = 4, BM = 4 * TM * 16;
@@ -730,8 +757,10 @@ __global__ __launch_bounds__(256, (KT * NT <= 1 ? 4 : (KT * NT <= 6 ? 3 : 2))) v
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int b = tile / p.MB, mblk = tile - b * p.MB;
     const int row0 = mblk * BM + wave * (TM * 16);
+    const int vrows = conv_valid_rows(p, b);
+    if (row0 + p.off0 >= vrows) continue;   // ragged batch: this wave's rows lie in the batch element's padding (no barrier in the loop)
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T*>((const T*)p.x + (int64_t)b * p.x_bstride), 0, (int)((int64_t)p.Tin * p.Cin * (int)sizeof(T)), 0x00020000);
+        const_cast<T*>((const T*)p.x + (int64_t)b * p.x_bstride), 0, (int)((int64_t)vrows * p.Cin * (int)sizeof(T)), 0x00020000);
     f32x4 acc[TM][NT];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -744,7 +773,7 @@ __global__ __launch_bounds__(256, (KT * NT <= 1 ? 4 : (KT * NT <= 6 ? 3 : 2))) v
 #pragma unroll
         for (int ks = 0; ks < KT; ++ks) {
           const int col = ks * KS + g * E;
-          const bool ok = (j < p.taps) && (tin >= 0) && (tin < p.Tin) && (col < p.Cin);
+          const bool ok = (j < p.taps) && (tin >= 0) && (tin < vrows) && (col < p.Cin);
           const unsigned off = ok ? (unsigned)((tin * p.Cin + col) * (int)sizeof(T)) : OOB;
           af[tm][ks] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
         }
@@ -916,6 +945,7 @@ static int conv_params_from_args(const itts_conv_args* a, ConvParams& p, const c
   }
   p.B = a->B;
   p.Tin = a->Tin;
+  p.valid_rows = a->valid_rows;
   p.Tout = a->Tout;
   p.Cin = a->Cin;
   p.N = a->N;

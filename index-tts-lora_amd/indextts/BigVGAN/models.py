@@ -178,19 +178,30 @@ class BigVGAN:
         self._build()
         return ecapa_embed(self._built["spk"], mel_ref.to(self.device, torch.float32))
 
-    def _act(self, x, ab, out=None):
+    def _act(self, x, ab, out=None, valid=None):
         P = self._built
-        return nat.aa_snake(x, ab[0], ab[1], P["up_f"], P["down_f"], layout=0, out=out)
+        return nat.aa_snake(x, ab[0], ab[1], P["up_f"], P["down_f"], layout=0, out=out, valid_rows=valid)
 
     def forward(self, x: torch.Tensor, mel_ref: torch.Tensor = None, lens=None, speaker_embedding: torch.Tensor = None,
                 taps: dict | None = None, profile: list | None = None):
         """x: GPT latent [B,T,gpt_dim]; mel_ref [B,Tref,100] (or a precomputed speaker_embedding [B,1,512]).
         profile (measurement aid, bench.py): a list that receives one [name, cuda event, FLOP, algorithmic bytes] entry per
         stage boundary -- FLOP = 2 * rows * Cout * Cin * taps of the convolutions launched since the previous entry, bytes =
-        every launch's input + output (+ residual / accumulate operand) elements in the storage type."""
+        every launch's input + output (+ residual / accumulate operand) elements in the storage type.
+        lens (ints or an int tensor [B], frames per batch element, <= T): RAGGED batch -- every layer treats element b as a
+        sequence of lens[b] * (upsampling so far) rows: convolutions read zeros past it (their own zero padding), the
+        anti-aliased activation's replicate padding clamps there, tiles past it are not computed.  Samples
+        [0, lens[b] * hop) of row b then equal, bit for bit, what vocoding that element alone returns; the rest of the row
+        is unspecified."""
         self._build()
         P, T, dev = self._built, self.dtype, self.device
         B, Tn, _ = x.shape
+        vr = None       # valid rows at the current stage (int32 [B] on the device) or None
+        if lens is not None:
+            lens_t = torch.as_tensor(lens, dtype=torch.int32).reshape(-1)
+            if lens_t.numel() != B or int(lens_t.max()) > Tn or int(lens_t.min()) < 0:
+                raise ValueError("lens must hold one length in [0, T] per batch element")
+            vr = lens_t.to(dev)
         es = torch.empty((), dtype=T).element_size()
         work = [0.0, 0.0]
 
@@ -214,7 +225,8 @@ class BigVGAN:
         c = self.c0
         cond = F.linear(spk, P["cond0"][0], P["cond0"][1]).contiguous()
         cur = torch.empty(B, Tn, c, dtype=T, device=dev)
-        nat.gemm_conv(T, B, Tn, Tn, self.gpt_dim, c, P["pre_w"], x, cur, taps=7, off0=-3, dil=1, bias=P["pre_b"], bias2=cond)
+        nat.gemm_conv(T, B, Tn, Tn, self.gpt_dim, c, P["pre_w"], x, cur, taps=7, off0=-3, dil=1, bias=P["pre_b"], bias2=cond,
+                      valid_rows=vr)
         conv_work(Tn, self.gpt_dim, c, 7)
         mark("conditioning linear + conv_pre")
         if taps is not None:
@@ -229,8 +241,10 @@ class BigVGAN:
             xu = torch.empty(B, Tu, c, dtype=T, device=dev)
             rows = Tn + 1 if up["taps"] == 2 else Tn
             nat.gemm_conv(T, B, Tn, rows, up["cin"], u * c, up["w"], cur, xu, taps=up["taps"], off0=up["off0"], dil=1,
-                          bias=up["b"], bias2=b2, y_bstride=Tu * c, y_shift=up["shift"], y_limit=Tu * c)
+                          bias=up["b"], bias2=b2, y_bstride=Tu * c, y_shift=up["shift"], y_limit=Tu * c, valid_rows=vr)
             conv_work(rows, up["cin"], u * c, up["taps"])
+            if vr is not None:
+                vr = vr * u
             if taps is not None:
                 taps[f"up{i}_cond"] = xu
             xs = torch.empty_like(xu)
@@ -245,24 +259,24 @@ class BigVGAN:
                     work[1] += 4 * B * Tu * c * es          # two activations: read + write each
                     conv_work(Tu, c, c, k)
                     conv_work(Tu, c, c, k, extra_ops=1 if (n + 1 < nd or j == 0) else 2)   # + residual (+ accumulate)
-                    self._act(xc, blk["act"][2 * n], out=ba)
+                    self._act(xc, blk["act"][2 * n], out=ba, valid=vr)
                     nat.gemm_conv(T, B, Tu, Tu, c, c, blk["c1"][n][0], ba, bb, taps=k, off0=-((k * d - d) // 2), dil=d,
-                                  bias=blk["c1"][n][1])
-                    self._act(bb, blk["act"][2 * n + 1], out=ba)
+                                  bias=blk["c1"][n][1], valid_rows=vr)
+                    self._act(bb, blk["act"][2 * n + 1], out=ba, valid=vr)
                     if n + 1 < nd:
                         nat.gemm_conv(T, B, Tu, Tu, c, c, blk["c2"][n][0], ba, pp[n % 2], taps=k, off0=-((k - 1) // 2), dil=1,
-                                      bias=blk["c2"][n][1], resid=xc)
+                                      bias=blk["c2"][n][1], resid=xc, valid_rows=vr)
                         xc = pp[n % 2]
                     else:  # last conv of the block: + residual, then the 1/3 mean over the three AMP blocks
                         nat.gemm_conv(T, B, Tu, Tu, c, c, blk["c2"][n][0], ba, xs, taps=k, off0=-((k - 1) // 2), dil=1,
-                                      bias=blk["c2"][n][1], resid=xc, accumulate=(j > 0), scale=1.0 / nk)
+                                      bias=blk["c2"][n][1], resid=xc, accumulate=(j > 0), scale=1.0 / nk, valid_rows=vr)
             cur, Tn = xs, Tu
             mark(f"stage {i}: x{u} upsampler + {nk} AMP blocks at C = {c}, T = {Tu}")
             if taps is not None:
                 taps[f"stage{i}"] = cur
-        a = self._act(cur, P["act_post"])
+        a = self._act(cur, P["act_post"], valid=vr)
         y = torch.empty(B, Tn, 1, dtype=T, device=dev)
-        nat.gemm_conv(T, B, Tn, Tn, c, 1, P["post_w"], a, y, taps=7, off0=-3, dil=1, bias=P["post_b"])
+        nat.gemm_conv(T, B, Tn, Tn, c, 1, P["post_w"], a, y, taps=7, off0=-3, dil=1, bias=P["post_b"], valid_rows=vr)
         wav = torch.empty(B, 1, Tn, dtype=torch.float32, device=dev)
         nat.tanh_pcm(y, wav=wav, pcm=None, apply_tanh=True)
         work[1] += 2 * B * Tn * c * es + B * Tn * 4

@@ -47,7 +47,7 @@ class ConvArgs(C.Structure):
                 ("x_bstride", C.c_int64), ("wp", C.c_void_p), ("bias", C.c_void_p), ("bias2", C.c_void_p),
                 ("act", C.c_int), ("y", C.c_void_p), ("y_f32", C.c_int), ("y_bstride", C.c_int64),
                 ("y_shift", C.c_int64), ("y_limit", C.c_int64), ("resid", C.c_void_p), ("accumulate", C.c_int),
-                ("scale", C.c_float)]
+                ("scale", C.c_float), ("valid_rows", C.c_void_p)]
 
 
 class SampleArgs(C.Structure):
@@ -79,7 +79,7 @@ _SIGNATURES = {
     "itts_packed_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "itts_pack_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_aa_snake_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "itts_gemm_skinny": (C.c_int, [C.POINTER(SkinnyArgs), C.c_void_p]),
     "itts_skinny_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "itts_gemm_conv": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
@@ -183,8 +183,9 @@ def pack_weight(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def aa_snake(x, alpha_log, beta_log, up_f, down_f, layout=0, out=None):
-    """x [B,T,C] (layout 0) or [B,C,T] (layout 1); filters are HOST float32 tensors/arrays of 12 taps."""
+def aa_snake(x, alpha_log, beta_log, up_f, down_f, layout=0, out=None, valid_rows=None):
+    """x [B,T,C] (layout 0) or [B,C,T] (layout 1); filters are HOST float32 tensors/arrays of 12 taps.
+    valid_rows int32 [B] (layout 0): per-element sequence lengths of a ragged batch (rows past them are not written)."""
     _dev(x, alpha_log, beta_log)
     if layout == 0:
         B, T, Cn = x.shape
@@ -194,7 +195,7 @@ def aa_snake(x, alpha_log, beta_log, up_f, down_f, layout=0, out=None):
     uf = (C.c_float * 12)(*[float(v) for v in up_f])
     df = (C.c_float * 12)(*[float(v) for v in down_f])
     _check(lib().itts_aa_snake_fwd(_p(x), _p(y), _p(alpha_log), _p(beta_log), C.cast(uf, C.c_void_p),
-                                   C.cast(df, C.c_void_p), B, T, Cn, dt(x.dtype), layout, _stream()),
+                                   C.cast(df, C.c_void_p), B, T, Cn, dt(x.dtype), layout, _p(valid_rows), _stream()),
            "itts_aa_snake_fwd")
     return y
 
@@ -252,7 +253,9 @@ def skinny_plan(dtype, M, N, K, ksplit=1) -> dict:
 
 
 def gemm_conv(dtype, B, Tin, Tout, Cin, N, wp, x, y, taps=1, off0=0, dil=1, x_bstride=None, bias=None, bias2=None,
-              act=0, y_f32=False, y_bstride=None, y_shift=0, y_limit=None, resid=None, accumulate=False, scale=1.0):
+              act=0, y_f32=False, y_bstride=None, y_shift=0, y_limit=None, resid=None, accumulate=False, scale=1.0,
+              valid_rows=None):
+    """valid_rows int32 [B]: ragged batch -- input rows >= valid_rows[b] read as zeros, tiles that only see them are skipped."""
     a = ConvArgs()
     a.dtype, a.B, a.Tin, a.Tout, a.Cin, a.N = dt(dtype), B, Tin, Tout, Cin, N
     a.taps, a.off0, a.dil = taps, off0, dil
@@ -263,6 +266,7 @@ def gemm_conv(dtype, B, Tin, Tout, Cin, N, wp, x, y, taps=1, off0=0, dil=1, x_bs
     a.y_shift = y_shift
     a.y_limit = Tout * N if y_limit is None else y_limit
     a.resid, a.accumulate, a.scale = _p(resid), int(accumulate), float(scale)
+    a.valid_rows = _p(valid_rows)
     _check(lib().itts_gemm_conv(C.byref(a), _stream()), "itts_gemm_conv")
 
 

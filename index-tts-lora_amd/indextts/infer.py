@@ -433,9 +433,45 @@ class IndexTTS:
             return output_path
         return (sampling_rate, wav.type(torch.int16).numpy().T)
 
-    def _vocode(self, latent, spk):
-        wav, _ = self.bigvgan(latent, speaker_embedding=spk)
+    def _vocode(self, latent, spk, lens=None):
+        wav, _ = self.bigvgan(latent, speaker_embedding=spk, lens=lens)
         return torch.clamp(32767 * wav.squeeze(1), -32767.0, 32767.0)
+
+    # utterances whose lengths are within this ratio share one (ragged) vocoder batch; the padding rows of the shorter ones
+    # cost nothing (tiles past a row's end are not computed) but the batch allocates for the longest
+    VOCODER_BUCKET_RATIO = 2.0
+
+    def _vocode_ragged(self, lat, spk):
+        """lat: list of [T_i, D] latents of one speaker.  Returns the list of waveforms [T_i * hop], each bit-identical to
+        vocoding that utterance alone (BigVGAN.forward(lens=...)): utterances are sorted by length and vocoded in
+        buckets of similar length -- one launch sequence per bucket instead of one per distinct length."""
+        outs = [None] * len(lat)
+        order = sorted(range(len(lat)), key=lambda i: int(lat[i].shape[0]))
+        k = 0
+        while k < len(order):
+            t_min = int(lat[order[k]].shape[0])
+            if t_min == 0:
+                outs[order[k]] = torch.zeros(0, device=self.device)
+                k += 1
+                continue
+            e = k
+            while e < len(order) and int(lat[order[e]].shape[0]) <= self.VOCODER_BUCKET_RATIO * t_min:
+                e += 1
+            idx = order[k:e]
+            lens = [int(lat[i].shape[0]) for i in idx]
+            t_max = lens[-1]
+            if lens[0] == t_max:
+                wav = self._vocode(torch.stack([lat[i] for i in idx], 0), spk)
+            else:
+                x = torch.zeros(len(idx), t_max, lat[idx[0]].shape[1], dtype=lat[idx[0]].dtype, device=lat[idx[0]].device)
+                for j, i in enumerate(idx):
+                    x[j, : lens[j]] = lat[i]
+                wav = self._vocode(x, spk, lens=lens)
+            hop = wav.shape[1] // t_max
+            for j, i in enumerate(idx):
+                outs[i] = wav[j, : lens[j] * hop]
+            k = e
+        return outs
 
     # ------------------------------------------------------------------------------------------------ public API
     def infer(self, audio_prompt, text, output_path, verbose=False, max_text_tokens_per_sentence=120, speaker_id=None,
@@ -604,18 +640,7 @@ class IndexTTS:
         conds, spk = st["conds"], st["spk"]
         lat = self._latents(conds, st["texts"], st["rows"])
         self._mark(phase_events, "latents")
-        outs = [None] * len(lat)
-        groups: Dict[int, List[int]] = {}
-        for i, x in enumerate(lat):
-            groups.setdefault(int(x.shape[0]), []).append(i)
-        for T, idx in groups.items():
-            if T == 0:
-                for i in idx:
-                    outs[i] = torch.zeros(0, device=self.device)
-                continue
-            wav = self._vocode(torch.stack([lat[i] for i in idx], 0), spk)
-            for j, i in enumerate(idx):
-                outs[i] = wav[j]
+        outs = self._vocode_ragged(lat, spk)
         self._mark(phase_events, "vocoded")
         return outs
 

@@ -188,6 +188,26 @@ def test_bigvgan_half_tracks_fp32(dtype, tol):
     assert all(e[3] > 0 for e in prof[1:])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_bigvgan_ragged_batch_equals_single_runs(dtype):
+    """BigVGAN.forward(lens=...): utterances of different lengths in one batch give, sample for sample, what vocoding
+    each of them alone gives (the reference vocodes them one by one, infer.py:885-899)."""
+    g = np.load(os.path.join(G, "bigvgan.npz"))
+    v = make_vocoder(dtype)
+    lat = torch.from_numpy(g["latent8"]).to(DEV)             # [B, 8, D]
+    lat = torch.cat([lat, lat.flip(1), lat * 0.5], 0)[:5]
+    mel = torch.from_numpy(g["melref"]).to(DEV)
+    spk = v.speaker_embedding(mel[:1])
+    lens = [8, 3, 1, 5, 8][: lat.shape[0]]
+    wav, _ = v(lat, speaker_embedding=spk, lens=lens)
+    hop = wav.shape[-1] // lat.shape[1]
+    for b, n in enumerate(lens):
+        w1, _ = v(lat[b:b + 1, :n].contiguous(), speaker_embedding=spk)
+        assert torch.equal(wav[b, :, : n * hop], w1[0]), (b, n)
+    with pytest.raises(ValueError):
+        v(lat, speaker_embedding=spk, lens=[9] * lat.shape[0])
+
+
 def test_batch_pipeline_equals_serial_infer_batch():
     """BatchPipeline (stage B on a second stream beside the next batch's token loop) returns exactly what
     infer_batch returns batch by batch: same kernels, same inputs, no shared mutable state between the stages."""

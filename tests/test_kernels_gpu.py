@@ -213,6 +213,63 @@ def test_gemm_conv_conv1d(nat, dtype, case):
     assert (y2.float() - ref2).abs().max().item() < 2 * tol
 
 
+RAGGED = [
+    # (T, Cin, Cout, k, dil, lens): every kernel class of the vocoder -- side-by-side tile, persistent 64 / 96-column tiles
+    # (several tiles per workgroup, skipped ones in between), narrow kernel, plain GEMM (k = 1)
+    (300, 256, 128, 7, 3, [300, 1, 129, 0, 257]), (2500, 64, 192, 11, 1, [2500, 700, 1, 2499]),
+    (9000, 96, 96, 7, 5, [17, 9000, 4097, 0, 5000, 129]), (1200, 48, 48, 7, 3, [1200, 255, 256, 257, 5]),
+    (3000, 24, 24, 11, 5, [1, 3000, 64, 1000]), (700, 384, 256, 1, 1, [700, 130, 0, 129]),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("case", RAGGED)
+def test_gemm_conv_ragged_batch_equals_single_runs(nat, dtype, case):
+    """valid_rows: a batch of sequences of different lengths (padded to T) gives, on each element's valid rows, the bits
+    that running that element alone at its own length gives -- input rows past the end are the convolution's zero padding --
+    with and without the residual / accumulate epilogue; rows past the end are left alone where a whole tile is skipped."""
+    T, Cin, Cout, k, dil, lens = case
+    B = len(lens)
+    x = rnd(B, T, Cin, seed=60).to(dtype)
+    w = (rnd(Cout, Cin, k, seed=61) * (1.0 / (Cin * k) ** 0.5)).to(dtype)
+    bias, resid = rnd(Cout, seed=62), rnd(B, T, Cout, seed=63).to(dtype)
+    pad = (k * dil - dil) // 2
+    wp = nat.pack_weight(w.permute(2, 1, 0).contiguous())
+    vr = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    for epi in (False, True):
+        y = torch.full((B, T, Cout), 7.0, dtype=dtype, device=DEV)
+        kw = dict(resid=resid, accumulate=True, scale=0.5) if epi else {}
+        nat.gemm_conv(dtype, B, T, T, Cin, Cout, wp, x, y, taps=k, off0=-pad, dil=dil, bias=bias, valid_rows=vr, **kw)
+        for b, n in enumerate(lens):
+            if n == 0:
+                continue
+            y1 = torch.full((1, n, Cout), 7.0, dtype=dtype, device=DEV)
+            kw1 = dict(resid=resid[b:b + 1, :n].contiguous(), accumulate=True, scale=0.5) if epi else {}
+            nat.gemm_conv(dtype, 1, n, n, Cin, Cout, wp, x[b:b + 1, :n].contiguous(), y1, taps=k, off0=-pad, dil=dil, bias=bias, **kw1)
+            assert torch.equal(y[b, :n], y1[0]), (epi, b, n)
+        if not epi:   # far past an element's end nothing was written
+            for b, n in enumerate(lens):
+                if n + 1024 + pad < T:
+                    assert (y[b, n + 1024 + pad:] == 7.0).all(), b
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("C", [24, 48, 96, 128])
+def test_aa_snake_ragged_batch_equals_single_runs(nat, dtype, C):
+    from indextts.BigVGAN.models import kaiser_sinc_filter
+    f = kaiser_sinc_filter()
+    lens = [1, 777, 0, 76, 77, 500, 13]
+    B, T = len(lens), 777
+    x = rnd(B, T, C, seed=70).to(dtype)
+    al, be = rnd(C, seed=71) * 0.3, rnd(C, seed=72) * 0.3
+    vr = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    y = nat.aa_snake(x, al, be, f, f, valid_rows=vr)
+    for b, n in enumerate(lens):
+        if n:
+            y1 = nat.aa_snake(x[b:b + 1, :n].contiguous(), al, be, f, f)
+            assert torch.equal(y[b, :n], y1[0]), (b, n)
+
+
 UPS = [(1, 9, 1536, 768, 8, 4), (2, 33, 768, 384, 8, 4), (1, 100, 384, 192, 4, 4), (2, 130, 192, 96, 4, 4),
        (1, 500, 96, 48, 4, 2), (2, 700, 48, 24, 4, 2)]
 
