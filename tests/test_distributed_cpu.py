@@ -33,7 +33,11 @@ def _worker(rank, world, port, q):
     done = torch.zeros(len(lens), dtype=torch.int64)
     done[mine] = rank + 1
     dist.all_reduce(done)  # bookkeeping only (not on the data path)
-    q.put((rank, {k: v.clone() for k, v in out.items()}, done.tolist()))
+    # plain bytes through the queue: tensors would travel as shared-memory handles that die with this process (a race
+    # that failed the test now and then)
+    wire = {k: (str(v.dtype).replace("torch.", ""), tuple(v.shape), v.contiguous().reshape(-1).view(torch.uint8).numpy().tobytes()
+                if v.dtype != torch.bool else v.to(torch.uint8).numpy().tobytes()) for k, v in out.items()}
+    q.put((rank, wire, done.tolist()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -49,7 +53,16 @@ def test_broadcast_and_sharding_two_ranks():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    def unwire(w):
+        out = {}
+        for k, (dt, shape, raw) in w.items():
+            tdt = getattr(torch, dt)
+            t = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+            out[k] = (t.to(torch.bool) if tdt == torch.bool else t.view(tdt)).reshape(shape)
+        return out
+
     (_, sd0, done0), (_, sd1, done1) = res
+    sd0, sd1 = unwire(sd0), unwire(sd1)
     # the source tensors, rebuilt here: every rank must hold them bit for bit, in their own dtypes
     g = torch.Generator().manual_seed(0)
     src = {"a.weight": torch.randn(5, 7, generator=g), "b.bias": torch.randn(3, generator=g).half(),
