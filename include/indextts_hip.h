@@ -231,10 +231,12 @@ int itts_embed_step(const int32_t* tokens, const float* table, const float* pos_
  * kv_rows / kv_step (both or neither): beam search without cache copies -- position j of logical row b is read from
  * physical cache row kv_rows[(*kv_step & 1)][b][j] (int32 [2][B][smax], maintained by itts_beam_kv_rows).
  * Entries of different rows may name the SAME physical row (the beams of a batch element share their prompt and common
- * history; the engine caches the prompt once per batch element). */
+ * history; the engine caches the prompt once per batch element).
+ * skip_rows (int32 [B] on the device or NULL): rows with a nonzero entry are left out (out[b] keeps its old contents) --
+ * the decode loop passes its `finished` flags, a finished row's logits no longer matter. */
 int itts_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, const int32_t* pad,
                      const int32_t* pos, int B, int H, int smax, int dtype, int out_packed, const int32_t* kv_rows,
-                     const int32_t* kv_step, void* stream);
+                     const int32_t* kv_step, const int32_t* skip_rows, void* stream);
 
 /* Causal self-attention over a whole (left-padded) sequence.  qkv: T [B][S][3*H*64] (q|k|v); out: T [B][S][H*64];
  * query i sees key j iff pad[b] <= j <= i; rows with no visible key produce zeros.  If kcache/vcache are non-NULL the

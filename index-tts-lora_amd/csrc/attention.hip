@@ -34,11 +34,13 @@ __global__ __launch_bounds__(NWV * 64) void attn_decode_kernel(const T* __restri
                                                            const T* __restrict__ vc, T* __restrict__ out,
                                                            const int32_t* __restrict__ pad, const int32_t* __restrict__ pos,
                                                            int H, int smax, int out_mtp, const int32_t* __restrict__ kv_rows,
-                                                           const int32_t* __restrict__ kv_step, int rows_total) {
+                                                           const int32_t* __restrict__ kv_step, int rows_total,
+                                                           const int32_t* __restrict__ skip_rows) {
   typedef Elem<T> EL;
   typedef typename EL::frag frag;
   constexpr int E = EL::E;
   constexpr int LPR = HD / E;        // lanes per row: 8 (16-bit) / 16 (fp32)
+
   constexpr int RPW = 64 / LPR;      // rows per wave-load: 8 / 4
   constexpr int CH = AD_CH * 4 / NWV;   // chunks per wave: a workgroup pass always covers 4 * RPW * AD_CH keys
   __shared__ float w_m[NWV], w_l[NWV];
@@ -48,6 +50,11 @@ __global__ __launch_bounds__(NWV * 64) void attn_decode_kernel(const T* __restri
   const int part = lane % LPR, rg = lane / LPR;
   const int j0 = pad[b];
   const int ctx = pos[0] + 1;  // keys [j0, ctx)
+  // rows that already emitted their stop token keep decoding only formally (the sampler pads them with the stop token
+  // whatever their logits are): their attention -- the one stage whose cost grows with the rows -- is left out.  The flag
+  // is requested together with pad / pos (one round trip, not one more in front of the kernel).
+  const int skip = skip_rows != nullptr ? skip_rows[b] : 0;
+  if (skip != 0) return;
   const T* kb = kc + ((int64_t)b * H + h) * smax * HD + part * E;
   const T* vb = vc + ((int64_t)b * H + h) * smax * HD + part * E;
   const int32_t* tab = nullptr;
@@ -311,7 +318,7 @@ namespace itts { constexpr int g_attn_waves = 4; }  // measured equal to 8; the 
 
 extern "C" int itts_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, const int32_t* pad,
                                 const int32_t* pos, int B, int H, int smax, int dtype, int out_packed, const int32_t* kv_rows,
-                                const int32_t* kv_step, void* stream) {
+                                const int32_t* kv_step, const int32_t* skip_rows, void* stream) {
   const int out_mtp = out_packed ? (B + 15) / 16 : 0;
   ITTS_REQUIRE(q && kcache && vcache && out && pad && pos, "itts_attn_decode: null pointer");
   ITTS_REQUIRE(B > 0 && H > 0 && smax > 0 && smax <= AD_MAXCTX, "itts_attn_decode: bad shape B=%d H=%d smax=%d (max %d)", B, H,
@@ -322,7 +329,7 @@ extern "C" int itts_attn_decode(const void* q, const void* kcache, const void* v
   const bool ind = kv_rows != nullptr;
 #define ITTS_AD(TT_, NW_, IND_)                                                                                             \
   hipLaunchKernelGGL((attn_decode_kernel<TT_, NW_, IND_>), grid, block, 0, s, (const TT_*)q, (const TT_*)kcache,           \
-                     (const TT_*)vcache, (TT_*)out, pad, pos, H, smax, out_mtp, kv_rows, kv_step, B)
+                     (const TT_*)vcache, (TT_*)out, pad, pos, H, smax, out_mtp, kv_rows, kv_step, B, skip_rows)
 #define ITTS_AD_T(TT_)                                                            \
   do {                                                                            \
     if (g_attn_waves == 8) { if (ind) ITTS_AD(TT_, 8, true); else ITTS_AD(TT_, 8, false); } \

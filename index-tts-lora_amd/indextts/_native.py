@@ -89,7 +89,7 @@ _SIGNATURES = {
     "itts_embed_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                   C.c_int, C.c_void_p, C.c_void_p]),
     "itts_attn_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "itts_attn_prefill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_attn_prefill_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -306,10 +306,11 @@ def embed_step(tokens, table, pos_table, step, pos_add, h, epoch=None):
            "itts_embed_step")
 
 
-def attn_decode(q, kcache, vcache, out, pad, pos, B, H, smax, out_packed=False, kv_rows=None, kv_step=None):
-    """kv_rows int32 [2][B][smax] + kv_step (device word): beam-search row table instead of permuted cache rows."""
+def attn_decode(q, kcache, vcache, out, pad, pos, B, H, smax, out_packed=False, kv_rows=None, kv_step=None, skip_rows=None):
+    """kv_rows int32 [2][B][smax] + kv_step (device word): beam-search row table instead of permuted cache rows.
+    skip_rows int32 [B]: rows with a nonzero entry are left out (their slice of `out` is not written)."""
     _check(lib().itts_attn_decode(_p(q), _p(kcache), _p(vcache), _p(out), _p(pad), _p(pos), B, H, smax, dt(q.dtype),
-                                  int(bool(out_packed)), _p(kv_rows), _p(kv_step), _stream()), "itts_attn_decode")
+                                  int(bool(out_packed)), _p(kv_rows), _p(kv_step), _p(skip_rows), _stream()), "itts_attn_decode")
 
 
 def attn_prefill(qkv, out, kcache, vcache, pad, B, S, H, smax):

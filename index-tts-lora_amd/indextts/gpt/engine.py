@@ -333,7 +333,8 @@ class GPTEngine:
             nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv"], l["b_qkv"], x=xn, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
                             vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s, x_packed=pa)
             nat.attn_decode(self.q, self.kc[i], self.vc[i], self.a, self.pad, pos, B, H, self._cap_s, out_packed=pa,
-                            kv_rows=self._kv_rows, kv_step=step if self._kv_rows is not None else None)
+                            kv_rows=self._kv_rows, kv_step=step if self._kv_rows is not None else None,
+                            skip_rows=self.finished if self._kv_rows is None else None)
             last = i + 1 == self.L
             nxt = self.ln_f if last else self.layers[i + 1]["ln1"]
             nxt2 = self.final_norm if last else None
