@@ -24,6 +24,8 @@
 // indextts/gpt/model.py:163-193.
 #include "common.h"
 #include "ln_math.h"
+#include "prefetch.h"
+#include <type_traits>
 
 #ifndef ITTS_NT_WEIGHTS
 #define ITTS_NT_WEIGHTS 0   // build-time A/B: non-temporal policy for the once-read weight blocks (measured neutral)
@@ -65,6 +67,7 @@ struct SkinnyParams {
   int t_acquire;
   int x_pa, y_pa, t_y_pa;  // packed-activation layout for x / y (STORE, GELU_STORE) / the tail's y
   int mtp, row0;           // row tiles of the WHOLE operand, first row of this launch (a multiple of 16)
+  PfParams pf;             // L2 run-ahead for a later launch's weights (prefetch.h)
 #if ITTS_STAMPS
   unsigned long long* stamps;
 #endif
@@ -193,15 +196,29 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
   const char* bp = (const char*)p.wp + ((int64_t)nt0 * KT * 64 + lane) * 16;  // tile t of this workgroup: + t*KT*1024
   const T* X = (const T*)p.x;
 
-  // epilogue operands of the first output unit of this wave are requested now: their latency overlaps the weight stream
-  f32x4 bias_pre = {0.f, 0.f, 0.f, 0.f};
+  // Epilogue operands of this wave's output units are requested now: their latency overlaps the weight stream, and no
+  // load is issued after the run-ahead requests below (vmcnt returns in order: a later load would wait for those to land).
+  // UPRE units per wave cover every launch with 8 waves; launches with fewer waves (tiny K) finish in a second loop.
+  constexpr int UPRE = (NTB * MT + 7) / 8;
+  f32x4 bias_pre[UPRE];
   int pos_pre = 0;
   unsigned epoch_pre = 0;
-  if (wave < NTB * MT) {
-    const int col0 = (nt0 + wave / MT) * 16 + g * 4;
-    if (p.bias != nullptr && ks == 0 && col0 < p.N) bias_pre = load4f(p.bias + col0, p.N - col0);
-    if (p.epi == ITTS_EPI_QKV_CACHE) pos_pre = p.pos[0];
+  {
+    // range-checked dword loads: a null bias, another K slice, columns past N (the 8194-column head) read zeros -- no branch,
+    // so no join at which the compiler would wait for this round trip before the weight requests go out
+    const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.bias), 0, p.bias != nullptr ? p.N * 4 : 0, 0x00020000);
+#pragma unroll
+    for (int ui = 0; ui < UPRE; ++ui) {
+      const int u = wave + ui * NW;
+      const int col0 = (nt0 + u / MT) * 16 + g * 4;
+      const unsigned boff = (u < NTB * MT && ks == 0) ? (unsigned)col0 * 4u : 0x80000000u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        bias_pre[ui][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, boff + 4u * e, 0, 0));
+    }
   }
+  if (wave < NTB * MT && p.epi == ITTS_EPI_QKV_CACHE) pos_pre = p.pos[0];
   if constexpr (TAIL) epoch_pre = (unsigned)p.t_epoch[0];
 
   f32x4 acc[NTB][MT];
@@ -210,7 +227,17 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int base = s_begin; base < s_end; base += SPW) {
+  // L2 run-ahead (prefetch.h): requested right behind this wave's own first loads -- vmcnt returns in order, so the
+  // wave's operands are never queued behind them -- and never waited for (s_endpgm waits for the memory system)
+  PfRegs pfr;
+#pragma unroll
+  for (int i = 0; i < PF_SLOTS; ++i) pfr.v[i] = 0;
+  const unsigned pf_lin = blockIdx.y * gridDim.x + blockIdx.x, pf_nblk = gridDim.x * gridDim.y;
+
+  // one pass over SPW k-steps from `base`; the FIRST pass always runs (a wave without a K share requests nothing and adds
+  // zeros) so that every wave executes one straight line: operand requests -> run-ahead requests -> counted wait -> MFMAs
+  auto k_pass = [&](const int base, auto first_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
     frag bf[NTB][SPW];
 #pragma unroll
     for (int t = 0; t < NTB; ++t)
@@ -232,6 +259,11 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
           else
             af[i][mt] = (s < s_end && row < p.M) ? ld16<frag>(X + (int64_t)row * p.K + s * KS + g * E) : zero_frag<frag>();
         }
+      }
+      if constexpr (FIRST && !TAIL) {   // (the reducer-tail instantiations have no registers to spare for it)
+        __builtin_amdgcn_sched_barrier(0);   // pinned: behind the operand requests, ahead of the wait for them
+        pf_issue(p.pf, pf_lin, pf_nblk, wave, NW, lane, pfr);
+        __builtin_amdgcn_sched_barrier(0);
       }
       ITTS_STAMP(1);
 #if ITTS_STAMPS
@@ -261,6 +293,13 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
           else
             af[i] = (s < s_end && row < p.M) ? ld16<frag>(X + (int64_t)row * p.K + s * KS + g * E) : zero_frag<frag>();
         }
+        if constexpr (FIRST && !TAIL) {
+          if (mt == MT - 1) {   // behind the LAST row tile's requests (earlier ones would queue the later tiles behind it)
+            __builtin_amdgcn_sched_barrier(0);
+            pf_issue(p.pf, pf_lin, pf_nblk, wave, NW, lane, pfr);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
 #pragma unroll
         for (int i = 0; i < SPW; ++i)
 #pragma unroll
@@ -268,7 +307,9 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
       }
       ITTS_STAMP(2);
     }
-  }
+  };
+  k_pass(s_begin, std::true_type{});
+  for (int base = s_begin + SPW; base < s_end; base += SPW) k_pass(base, std::false_type{});
   ITTS_STAMP(3);
 
   // ---- cross-wave reduction, fixed order.  Lane (g, r) of a tile holds Y[row = mt*16 + r][col = tile*16 + 4g .. 4g+3].
@@ -276,20 +317,21 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
   for (int t = 0; t < NTB; ++t)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) st16(red + (((wave * NTB + t) * MT + mt) * 64 + lane) * 4, acc[t][mt]);
-  __syncthreads();
+  // LDS-only wait + raw barrier: __syncthreads() would also drain vmcnt, i.e. wait for the run-ahead requests to land
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
   ITTS_STAMP(4);
   const __amdgpu_buffer_rsrc_t rslab = __builtin_amdgcn_make_buffer_rsrc(
       p.yf, 0, TAIL ? (int)((int64_t)p.ksplit * p.slab_rows * p.N * 4) : 0, 0x00020000);
-  for (int u = wave; u < NTB * MT; u += NW) {
+  // one output unit (column tile t, row tile mt): sum the waves' partial tiles, add the bias, apply the epilogue
+  auto unit = [&](const int u, const f32x4 bs) {
     const int t = u / MT, mt = u - t * MT;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     for (int w = 0; w < NW; ++w) v += ld16<f32x4>(red + (((w * NTB + t) * MT + mt) * 64 + lane) * 4);
     const int row = mt * 16 + r, col0 = (nt0 + t) * 16 + g * 4;
-    if (row >= p.M || col0 >= p.N) continue;
+    if (row >= p.M || col0 >= p.N) return;
     const int nval = min(4, p.N - col0);
-    f32x4 bs = {0.f, 0.f, 0.f, 0.f};
-    if (u == wave) bs = bias_pre;
-    else if (p.bias != nullptr && ks == 0) bs = load4f(p.bias + col0, nval);
     v += bs;
     switch (p.epi) {
       case ITTS_EPI_STORE:
@@ -326,11 +368,21 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
           T* cache = (T*)(cc < D ? p.kcache : p.vcache);
           if (cc >= D) cc -= D;
           const int hh = cc >> 6, dd = cc & 63;
-          const int pos = (u == wave) ? pos_pre : p.pos[0];
-          store4<T>(cache + (((int64_t)row * p.heads + hh) * p.smax + pos) * 64 + dd, v, nval);
+          store4<T>(cache + (((int64_t)row * p.heads + hh) * p.smax + pos_pre) * 64 + dd, v, nval);
         }
       } break;
     }
+  };
+#pragma unroll
+  for (int ui = 0; ui < UPRE; ++ui) {
+    const int u = wave + ui * NW;
+    if (u < NTB * MT) unit(u, bias_pre[ui]);
+  }
+  for (int u = wave + UPRE * NW; u < NTB * MT; u += NW) {   // fewer than 8 waves (tiny K): the remaining units
+    f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+    const int col0 = (nt0 + u / MT) * 16 + g * 4;
+    if (p.bias != nullptr && ks == 0 && col0 < p.N) bs = load4f(p.bias + col0, p.N - col0);
+    unit(u, bs);
   }
   ITTS_STAMP(5);
 
@@ -373,6 +425,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
       ITTS_STAMP(9);
     }
   }
+  pf_keep(pfr);
 #if ITTS_STAMPS
   if (p.stamps != nullptr && threadIdx.x == 0) {
     ITTS_STAMP_DRAIN();
@@ -535,6 +588,10 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
     p.t_epoch = a->tail_epoch;
     p.t_err = a->tail_err;
     p.t_acquire = a->tail_acquire;
+    {
+      const int prc = itts_make_prefetch(a->pf, &p.pf);
+      if (prc != ITTS_OK) return prc;
+    }
 #if ITTS_STAMPS
     p.stamps = g_stamp_buf;
 #endif

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Microseconds per decode token of the GPT engine alone (BASELINE config 3 shape: 24 layers, bf16, 32 rows, ~72-position
+prompt, 140 tokens, graph replay) for a list of ITTS_PREFETCH settings / decode modes.  Appends to gpurun_out/token_time.txt.
+usage: decode_token_time.py [setting ...]   e.g.  "" ofp qofp     (a setting is the ITTS_PREFETCH letter string)"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "index-tts-lora_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+import weights  # noqa: E402
+from indextts.gpt.engine import GPTEngine  # noqa: E402
+
+torch.set_grad_enabled(False)
+settings = sys.argv[1:] or ["", "ofp"]
+B, P, NEW = 32, 72, 140
+gsd = weights.gpt_state_dict(24)
+eng = GPTEngine(gsd, 24, 1280, 20, dtype=torch.bfloat16, device="cuda")
+g = torch.Generator().manual_seed(1)
+prefix = torch.randn(B, P, 1280, generator=g) * 0.1
+pad = torch.zeros(B, dtype=torch.int32)
+sp = dict(do_sample=True, top_k=30, top_p=0.8, temperature=1.0, repetition_penalty=10.0, seed=7)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+out = open(os.path.join(ROOT, "gpurun_out", "token_time.txt"), "a")
+ref = None
+for rep in range(2):
+    for st in settings:
+        eng.prefetch = st
+        eng._graphs.clear()
+        eng.prefill(prefix, pad, NEW + 2)
+        codes = eng.decode(NEW, sp, force_stop=[NEW - 1] * B)   # warm-up + capture
+        eng.prefill(prefix, pad, NEW + 2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        codes = eng.decode(NEW, sp, force_stop=[NEW - 1] * B)
+        torch.cuda.synchronize()
+        us = 1e6 * (time.perf_counter() - t0) / NEW
+        if ref is None:
+            ref = codes.clone()
+        same = bool((codes == ref).all())
+        line = f"prefetch={st!r:8s} {us:8.1f} us/token  codes_equal_to_first={same}"
+        print(line, flush=True)
+        out.write(line + "\n")
+        out.flush()
