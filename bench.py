@@ -537,6 +537,8 @@ def main():
                    "gpt_dtype": "bf16", "vocoder_dtype": "fp16", "parallelism": f"dp{world} (utterance sharding, no collectives)",
                    "audio_seconds_per_step_per_gpu": round(audio_s_step, 3),
                    "audio_seconds_per_step_job": round(audio_s_job, 3),
+                   "prompt_features": ("conditioning latents + speaker embedding kept per prompt tensor: computed in the first "
+                                       "(warm-up) step, reused by the later steps of the same prompt; first_token_ms recomputes them"),
                    "schedule": ("2-stage batch pipeline: latent pass + vocoder of batch i on a second HIP stream beside "
                                 "the token loop of batch i+1; all steps complete inside the timed region")
                    if pipe is not None else (f"concurrent: {len(pool.instances)} independent batch-32 requests in flight (one "

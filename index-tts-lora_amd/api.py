@@ -67,14 +67,30 @@ def _parse_multipart(body: bytes, content_type: str):
     return out
 
 
+def _inside(path: str, roots) -> bool:
+    """True when `path` (symlinks resolved) lies in one of the directories `roots`."""
+    real = os.path.realpath(path)
+    for r in roots:
+        rr = os.path.realpath(r)
+        if real == rr or real.startswith(rr.rstrip(os.sep) + os.sep):
+            return True
+    return False
+
+
 def create_app(tts=None, model_dir="checkpoints", config_path="checkpoints/config.yaml", device=None, use_fp16=True,
-               finetune_dir=os.path.join("finetune_models", "checkpoints"), output_dir=os.path.join("outputs", "api")):
-    """`tts`: a ready IndexTTS (tests, embedding) or None to build one from model_dir / config_path on first use."""
+               finetune_dir=os.path.join("finetune_models", "checkpoints"), output_dir=os.path.join("outputs", "api"),
+               prompt_dir="prompts"):
+    """`tts`: a ready IndexTTS (tests, embedding) or None to build one from model_dir / config_path on first use.
+    Server-side paths a client may name are confined (the reference opens whatever it is given, api.py:125-134, :218-226):
+    /model/reload only loads files inside model_dir / finetune_dir, /tts prompt_audio_path only reads files inside
+    prompt_dir / model_dir; anything else answers 403."""
     from indextts.infer import IndexTTS, set_seed
 
     app = FastAPI(title="IndexTTS API (MI355X build)", version="1.0.0")
     state = {"tts": tts}
     lock = threading.Lock()
+    model_roots = [model_dir, finetune_dir]
+    prompt_roots = [prompt_dir, model_dir]
 
     def engine():
         if state["tts"] is None:
@@ -107,6 +123,8 @@ def create_app(tts=None, model_dir="checkpoints", config_path="checkpoints/confi
                 raise HTTPException(status_code=404, detail=f"model file {model_path} does not exist")
         elif not os.path.exists(model_path):
             raise HTTPException(status_code=404, detail=f"model file {model_path} does not exist")
+        if not _inside(model_path, model_roots):
+            raise HTTPException(status_code=403, detail="model files are only loaded from the model / fine-tune directories")
         try:
             with lock:
                 engine().reload_gpt(model_path)
@@ -153,6 +171,8 @@ def create_app(tts=None, model_dir="checkpoints", config_path="checkpoints/confi
             else:
                 if not os.path.exists(req.prompt_audio_path):
                     raise HTTPException(status_code=404, detail=f"reference audio {req.prompt_audio_path} does not exist")
+                if not _inside(req.prompt_audio_path, prompt_roots):
+                    raise HTTPException(status_code=403, detail="server-side prompts are only read from the prompt directory")
                 prompt = req.prompt_audio_path
             os.makedirs(output_dir, exist_ok=True)
             name = f"gen_{int(time.time())}_{os.urandom(2).hex()}.wav"
@@ -189,12 +209,14 @@ def create_app(tts=None, model_dir="checkpoints", config_path="checkpoints/confi
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser(description="IndexTTS API server (MI355X build)")
-    ap.add_argument("--host", type=str, default="0.0.0.0")
+    ap.add_argument("--host", type=str, default="127.0.0.1",
+                    help="bind address (the reference binds 0.0.0.0; opt in explicitly: this server loads checkpoints)")
     ap.add_argument("--port", type=int, default=7859)
     ap.add_argument("--model_dir", type=str, default="checkpoints")
     ap.add_argument("--config", type=str, default="checkpoints/config.yaml")
     ap.add_argument("--device", type=str, default=None)
     ap.add_argument("--no-fp16", action="store_true")
+    ap.add_argument("--prompt_dir", type=str, default="prompts", help="directory /tts prompt_audio_path may read from")
     a = ap.parse_args()
     import uvicorn
-    uvicorn.run(create_app(None, a.model_dir, a.config, a.device, not a.no_fp16), host=a.host, port=a.port)
+    uvicorn.run(create_app(None, a.model_dir, a.config, a.device, not a.no_fp16, prompt_dir=a.prompt_dir), host=a.host, port=a.port)

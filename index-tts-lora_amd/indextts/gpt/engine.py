@@ -63,7 +63,11 @@ class GPTEngine:
         # L2 run-ahead (include/indextts_hip.h, itts_prefetch): which launches of a block touch a later GEMM's weights.
         # Letters: q = the QKV GEMM touches the out-projection's, o = out-projection -> FC, f = FC -> FC2,
         # p = FC2 -> the next block's QKV (the last block: the mel head).  Same bits with any setting.
-        self.prefetch = os.environ.get("ITTS_PREFETCH", "ofp")
+        self.prefetch = os.environ.get("ITTS_PREFETCH", "qofp")
+        # Rows that have emitted their stop token are left out of the decode attention (the sampler pads them with the stop
+        # token whatever their logits are).  Their logits -- decode(return_logits=True) -- are then UNDEFINED from the step
+        # after their stop on; every other row is untouched (all later stages are per row).  False: compute them anyway.
+        self.skip_finished = True
         self._W = W          # kept (by reference) for attach_lora: the engine itself only holds packed copies
         self.lora = False
         self.layers = []
@@ -121,11 +125,13 @@ class GPTEngine:
         def packed(w):
             return nat.pack_weight(w.to(T).contiguous())
 
+        self.detach_lora()   # every attach starts from the base weights: nothing of an earlier adapter set survives
         for i, l in enumerate(self.layers):
             p = f"gpt.h.{i}."
             for name, wkey in (("attn.c_attn", "w_qkv"), ("mlp.c_fc", "w_fc")):
                 if p + name in adapters:
                     A, Bm = (t.detach().to(dev, torch.float32) for t in adapters[p + name])
+                    l[wkey + "_base"] = l[wkey]
                     l[wkey] = packed(f32(p + name + ".weight") + (A.t() @ Bm.t()) * scaling)
             for name, wkey, tag in (("attn.c_proj", "w_o", "o"), ("mlp.c_proj", "w_pr", "pr")):
                 if p + name not in adapters:
@@ -148,11 +154,25 @@ class GPTEngine:
         if hasattr(self, "slab") and self.slab.shape[2] < D + 64:
             self._cap_b = self._cap_s = 0   # the slabs need room for the extra columns: reallocate on the next prefill
 
+    def detach_lora(self):
+        """Back to the base weights: drops every adapter-derived entry (extra-column projections, merged copies, B factors)
+        and the graphs captured over them.  Only this engine changes: a fork holds its own layer dicts."""
+        for l in self.layers:
+            for k in [k for k in l if k.endswith("_lora") or k.endswith("_merged") or k.startswith("lora_")]:
+                del l[k]
+            for wkey in ("w_qkv", "w_fc"):
+                if wkey + "_base" in l:
+                    l[wkey] = l.pop(wkey + "_base")
+        self.lora = False
+        self._graphs.clear()
+
     def fork(self) -> "GPTEngine":
-        """A second engine over the SAME packed weights (read-only, shared) with its own KV cache, scratch buffers, loop
-        state and captured graphs: what a concurrent request needs (infer.RequestPool)."""
+        """A second engine over the SAME packed weights (read-only, shared tensors) with its own KV cache, scratch buffers,
+        loop state, captured graphs and per-layer dicts: what a concurrent request needs (infer.RequestPool).  A fork keeps
+        the adapter state it was forked with; attach_lora / detach_lora on one engine never changes another."""
         import copy
         e = copy.copy(self)
+        e.layers = [dict(l) for l in self.layers]
         e._cap_b = e._cap_s = 0
         e._graphs = {}
         e._beam_cap = (0, 0, 0)
@@ -349,7 +369,7 @@ class GPTEngine:
                             pf=pf("q", w_o if not tail else l["w_o"], n_o if not tail else D, D, KS))
             nat.attn_decode(self.q, self.kc[i], self.vc[i], self.a, self.pad, pos, B, H, self._cap_s, out_packed=pa,
                             kv_rows=self._kv_rows, kv_step=step if self._kv_rows is not None else None,
-                            skip_rows=self.finished if self._kv_rows is None else None)
+                            skip_rows=self.finished if self._kv_rows is None and self.skip_finished else None)
             nxt = self.ln_f if last else self.layers[i + 1]["ln1"]
             nxt2 = self.final_norm if last else None
             pf_next = pf("p", self.w_head, self.V, D) if last else pf("p", self.layers[i + 1]["w_qkv"], 3 * D, D)

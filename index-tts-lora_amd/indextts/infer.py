@@ -107,6 +107,7 @@ class IndexTTS:
 
         self._cache_conds = None
         self._feat_graphs = {}
+        self._batch_feat = None   # (prompt tensor, its version counter, conds, spk) of the last infer_batch prompt
         self.gpt = UnifiedVoice(**self.cfg.gpt)
         if _weights is None:
             load_checkpoint(self.gpt, self.gpt_path)
@@ -162,6 +163,7 @@ class IndexTTS:
         self._gpt = module
         self._cache_conds = None
         self._feat_graphs = {}
+        self._batch_feat = None
 
     @gpt.deleter
     def gpt(self):   # `del tts.gpt` before the swap (api.py:160)
@@ -193,7 +195,7 @@ class IndexTTS:
         import copy
         r = copy.copy(self)
         r.gpt = self.gpt.replica()
-        r.cache_audio_prompt = r.cache_cond_mel = r._cache_conds = r._cache_spk = None
+        r.cache_audio_prompt = r.cache_cond_mel = r._cache_conds = r._cache_spk = r._batch_feat = None
         return r
 
     # ------------------------------------------------------------------------------------------------ helpers
@@ -596,7 +598,15 @@ class IndexTTS:
         here is latency-bound small launches; it ends with the codes on the host, as infer.py:848-861 does."""
         gen, _ = self._gen_kwargs(generation_kwargs)
         self._mark(phase_events, "start")
-        conds, spk = self._prompt_features(cond_mel)
+        # One prompt serves many batches (one speaker, a stream of texts): its conditioning latents and speaker embedding are
+        # kept per prompt TENSOR -- the same object with an unchanged version counter is the same prompt, as infer() keeps
+        # them per prompt path (the cache holds a reference, so the storage cannot be recycled under it).
+        bf = self._batch_feat
+        if bf is not None and bf[0] is cond_mel and bf[1] == cond_mel._version:
+            conds, spk = bf[2], bf[3]
+        else:
+            conds, spk = self._prompt_features(cond_mel)
+            self._batch_feat = (cond_mel, cond_mel._version, conds, spk)
         L = max(int(t.numel()) for t in text_token_rows)
         stop = self.cfg.gpt.stop_text_token
         batch_h = torch.full((len(text_token_rows), L), stop, dtype=torch.int32)

@@ -13,8 +13,34 @@ import yaml
 logger = logging.getLogger("indextts")
 
 
+def _safe_load(model_pth: str):
+    """torch.load restricted to tensors, containers and the numpy arrays of `speaker_conditions` (weights_only unpickler
+    with an allowlist): a checkpoint file cannot run code.  ITTS_TRUST_CHECKPOINTS=1 restores the reference's unrestricted
+    pickle load (checkpoint.py:25) for files that carry other Python objects and that the operator trusts."""
+    if os.environ.get("ITTS_TRUST_CHECKPOINTS") == "1":
+        return torch.load(model_pth, map_location="cpu", weights_only=False)
+    import numpy as np
+    allow = [np.ndarray, np.dtype]
+    for mod, name in (("numpy._core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "_reconstruct"),
+                      ("numpy._core.multiarray", "scalar"), ("numpy.core.multiarray", "scalar")):
+        try:
+            allow.append(getattr(__import__(mod, fromlist=[name]), name))
+        except Exception:  # noqa: BLE001  (module layout differs between numpy 1.x and 2.x)
+            pass
+    for name in ("Float32DType", "Float64DType", "Float16DType", "Int64DType", "Int32DType"):
+        t = getattr(getattr(np, "dtypes", None), name, None)
+        if t is not None:
+            allow.append(t)
+    try:
+        with torch.serialization.safe_globals(allow):
+            return torch.load(model_pth, map_location="cpu", weights_only=True)
+    except Exception as e:  # noqa: BLE001
+        raise RuntimeError(f"{model_pth}: refused by the restricted checkpoint loader ({e}); set ITTS_TRUST_CHECKPOINTS=1 "
+                           f"to load a trusted file with the unrestricted pickle loader") from e
+
+
 def load_checkpoint(model, model_pth: str) -> dict:
-    ckpt = torch.load(model_pth, map_location="cpu", weights_only=False)
+    ckpt = _safe_load(model_pth)
     if isinstance(ckpt, dict) and "speaker_conditions" in ckpt:
         for sid, arr in ckpt["speaker_conditions"].items():
             t = torch.as_tensor(arr).float()

@@ -128,6 +128,49 @@ def test_sampling_loop_is_reproducible_and_stops(gpt_small_fp32):
         assert (row[:stop] != 8193).all() and (row[stop:] == 8193).all()
 
 
+def test_finished_rows_left_out_of_attention_change_nothing_else(gpt_small_fp32):
+    """Rows past their stop token are skipped by the decode attention (engine.skip_finished, commit 4cc617f).  With and
+    without the skip: identical codes for every row, identical logits for every row up to and including the step that
+    produces its stop token; later logits of a finished row are documented as undefined."""
+    m = gpt_small_fp32
+    g = np.load(os.path.join(G, "gpt_small.npz"))
+    cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
+    text = torch.from_numpy(g["text"]).to(DEV)
+    stops = [6, 14, 21]
+    kw = dict(do_sample=True, top_p=0.8, top_k=30, temperature=1.0, num_beams=1, repetition_penalty=10.0,
+              max_generate_length=24, force_stop=stops, seed=5, return_logits=True)
+    outs = []
+    for skip in (True, False):
+        m.engine.skip_finished = skip
+        m.engine._graphs.clear()
+        outs.append(m.inference_speech(cond_mel, text, **kw))
+    m.engine.skip_finished = True
+    m.engine._graphs.clear()
+    (c0, l0), (c1, l1) = outs
+    assert torch.equal(c0, c1)
+    for r, stop in enumerate(stops):
+        assert torch.equal(l0[: stop + 1, r], l1[: stop + 1, r]), f"row {r}: logits before its stop must not depend on the skip"
+    assert not torch.equal(l0[stops[0] + 2:, 0], l1[stops[0] + 2:, 0]), "the skip must actually have been taken"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_l2_run_ahead_changes_no_bit(dtype):
+    """itts_prefetch (the decode GEMMs touch a later GEMM's weight bytes): any schedule gives the same logits and codes as
+    none, graph replay and eager launches alike -- the touched values are never used."""
+    m = make_gpt(2, dtype)
+    g = np.load(os.path.join(G, "gpt_small.npz"))
+    cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
+    text = torch.from_numpy(g["text"]).to(DEV)
+    kw = dict(do_sample=False, num_beams=1, repetition_penalty=10.0, max_generate_length=12, return_logits=True)
+    outs = []
+    for pf in ("", "qofp", "f", "op"):
+        m.engine.prefetch = pf
+        m.engine._graphs.clear()
+        outs.append(m.inference_speech(cond_mel, text, **kw))
+    for c, l in outs[1:]:
+        assert torch.equal(c, outs[0][0]) and torch.equal(l, outs[0][1])
+
+
 def test_gpt_bf16_tracks_fp32():
     g = np.load(os.path.join(G, "gpt_small.npz"))
     m = make_gpt(2, torch.bfloat16)
@@ -466,3 +509,20 @@ def test_runtime_lora_equals_merged_checkpoint():
     base.to(DEV).to(torch.float32).post_init_gpt2_config(kv_cache=True)
     cb, lbase = base.inference_speech(cond_mel, text, **kw)
     assert (lbase - l0).abs().max().item() > 1e-2, "the adapters must actually change the logits"
+    # attach / detach are per engine: a fork taken BEFORE the attach keeps speaking with the base weights, a
+    # second attach that names fewer modules starts from the base weights again, detach restores the base bits
+    fork = base.replica()
+    base.attach_lora(adapters, scaling)
+    assert base.engine.lora and not fork.engine.lora and "w_o_lora" not in fork.engine.layers[0]
+    assert torch.equal(fork.inference_speech(cond_mel, text, **kw)[1], lbase)
+    assert torch.equal(base.inference_speech(cond_mel, text, **kw)[1], l1)
+    only_proj = {k: v for k, v in adapters.items() if k.endswith("c_proj")}
+    base.attach_lora(only_proj, scaling)
+    assert "w_qkv_base" not in base.engine.layers[0] and "w_o_lora" in base.engine.layers[0]
+    m2 = UnifiedVoice(**cfg)
+    m2.load_state_dict(sd)
+    m2.to(DEV).to(torch.float32).post_init_gpt2_config(kv_cache=True)
+    m2.attach_lora(only_proj, scaling)
+    assert torch.equal(base.inference_speech(cond_mel, text, **kw)[1], m2.inference_speech(cond_mel, text, **kw)[1])
+    base.engine.detach_lora()
+    assert torch.equal(base.inference_speech(cond_mel, text, **kw)[1], lbase)

@@ -123,6 +123,17 @@ def test_config_and_checkpoint_formats(tmp_path):
     m2 = M()
     assert load_checkpoint(m2, str(tmp_path / "bare.pt")) == {} and list(m2.sd) == ["a.weight"]
 
+    # a checkpoint file must not be able to run code (the REST /model/reload hands client-named files to this loader)
+    marker = tmp_path / "pwned"
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, (f"touch {marker}",))
+    torch.save({"model": {"a.weight": torch.ones(1)}, "extra": Evil()}, tmp_path / "evil.pth")
+    with pytest.raises(RuntimeError, match="restricted checkpoint loader"):
+        load_checkpoint(M(), str(tmp_path / "evil.pth"))
+    assert not marker.exists()
+
 
 def test_weight_norm_fold_and_filters():
     g = np.load(os.path.join(G, "act1d.npz"))
