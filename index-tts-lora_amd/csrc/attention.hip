@@ -4,6 +4,7 @@
 // Semantics follow HF GPT2Attention as driven by indextts/gpt/model.py:169-182: scores = q.k/sqrt(64), keys visible
 // iff causal and attention_mask == 1 (left padding, model.py:643-649); softmax in fp32.
 #include "common.h"
+#include <type_traits>
 
 namespace itts {
 
@@ -48,46 +49,61 @@ __global__ __launch_bounds__(NWV * 64) void attn_decode_kernel(const T* __restri
   const int h = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int part = lane % LPR, rg = lane / LPR;
+  // Two memory round trips, not four: the query fragment and the three device scalars (left padding, cache position, the
+  // row's stop flag) are requested together -- nothing here depends on a loaded value -- and the K / V requests follow as
+  // soon as the scalars are back; the query is converted only after those have been issued.  (The first version read the
+  // stop flag, branched, read pad / pos, waited for q and only then requested K / V: in-kernel latency chain of ~4 trips.)
+  const frag qv = ld16<frag>(q + ((int64_t)b * H + h) * HD + part * E);
+  const int32_t* skip_ptr = skip_rows != nullptr ? skip_rows + b : pos;   // a readable word either way: no branch around the load
+  const int skip_raw = *skip_ptr;
   const int j0 = pad[b];
-  const int ctx = pos[0] + 1;  // keys [j0, ctx)
   // rows that already emitted their stop token keep decoding only formally (the sampler pads them with the stop token
-  // whatever their logits are): their attention -- the one stage whose cost grows with the rows -- is left out.  The flag
-  // is requested together with pad / pos (one round trip, not one more in front of the kernel).
-  const int skip = skip_rows != nullptr ? skip_rows[b] : 0;
-  if (skip != 0) return;
+  // whatever their logits are): their attention -- the one stage whose cost grows with the rows -- is left out: no keys, no
+  // requests, no store.  A select, not an early return: a branch here makes the compiler sink the other scalar loads (and the
+  // query load) below it, one more round trip each.
+  const bool skipped = skip_rows != nullptr && skip_raw != 0;
+  int pos0 = pos[0];
+  asm volatile("" : "+s"(pos0));              // (keeps the load here: the compiler would otherwise load it only for rows that need it)
+  const int ctx = skipped ? j0 : pos0 + 1;    // keys [j0, ctx)
   const T* kb = kc + ((int64_t)b * H + h) * smax * HD + part * E;
   const T* vb = vc + ((int64_t)b * H + h) * smax * HD + part * E;
   const int32_t* tab = nullptr;
   if constexpr (IND) tab = kv_rows + ((int64_t)(kv_step[0] & 1) * rows_total + b) * smax;
 
   float qf[E];
-  {
-    frag qv = ld16<frag>(q + ((int64_t)b * H + h) * HD + part * E);
-#pragma unroll
-    for (int e = 0; e < E; ++e) qf[e] = EL::to_f(qv[e]) * 0.125f;
-  }
   float m = -INFINITY, l = 0.f, o[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) o[e] = 0.f;
 
-  for (int base = j0; base < ctx; base += 4 * RPW * AD_CH) {
+  // one pass over 4 * RPW * AD_CH keys; the FIRST pass (typical contexts need no other) converts the query behind its K / V
+  // requests -- written as a separate instance so that the compiler cannot hoist that conversion, and with it the wait for
+  // the query, in front of the requests
+  auto key_pass = [&](const int base, auto first_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
     frag kf[CH], vf[CH];
     int prow[CH];
+    // Positions past the context are CLAMPED onto its last key (same cache lines; their scores are forced to -inf below)
+    // instead of being skipped: a conditional load is a branch, and a join makes the compiler drain the memory queue.
     if constexpr (IND) {
 #pragma unroll
       for (int i = 0; i < CH; ++i) {   // the rows of this chunk's keys, all requested before the first K/V load
-        int j = base + (i * NWV + wave) * RPW + rg;
-        prow[i] = j < ctx ? tab[j] : b;
+        int j = min(base + (i * NWV + wave) * RPW + rg, ctx - 1);
+        prow[i] = tab[j];
       }
     }
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-      int j = base + (i * NWV + wave) * RPW + rg;
-      bool ok = j < ctx;
+      int j = min(base + (i * NWV + wave) * RPW + rg, ctx - 1);
       int64_t ro = (int64_t)j * HD;
       if constexpr (IND) ro += (int64_t)(prow[i] - b) * H * smax * HD;   // same head, same position, another row
-      kf[i] = ok ? ld16<frag>(kb + ro) : zero_frag<frag>();
-      vf[i] = ok ? ld16<frag>(vb + ro) : zero_frag<frag>();
+      kf[i] = ld16<frag>(kb + ro);
+      vf[i] = ld16<frag>(vb + ro);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // every K AND V request of the pass is out before anything waits
+    if constexpr (FIRST) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) qf[e] = EL::to_f(qv[e]) * 0.125f;
+      __builtin_amdgcn_sched_barrier(0);
     }
     float sc[CH];
     float cmax = -INFINITY;
@@ -102,21 +118,29 @@ __global__ __launch_bounds__(NWV * 64) void attn_decode_kernel(const T* __restri
       sc[i] = (j < ctx) ? d : -INFINITY;
       cmax = fmaxf(cmax, sc[i]);
     }
-    if (cmax > -INFINITY) {
-      float M = fmaxf(m, cmax);
-      float corr = (m == -INFINITY) ? 0.f : __expf(m - M);
+    {
+      // no branch on "this lane saw a key" (the V fragments would be sunk into it and requested a round trip late): a lane
+      // without keys keeps m = -inf and adds zeros
+      const float M = fmaxf(m, cmax);
+      const float Ms = (M == -INFINITY) ? 0.f : M;
+      const float corr = (m == -INFINITY) ? 0.f : __expf(m - Ms);
       l *= corr;
 #pragma unroll
       for (int e = 0; e < E; ++e) o[e] *= corr;
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
-        float pv = __expf(sc[i] - M);  // -inf -> 0
+        float pv = __expf(sc[i] - Ms);  // -inf -> 0
         l += pv;
 #pragma unroll
         for (int e = 0; e < E; ++e) o[e] = fmaf(pv, EL::to_f(vf[i][e]), o[e]);
       }
       m = M;
     }
+  };
+  constexpr int PASS = 4 * RPW * AD_CH;
+  if (j0 < ctx) {
+    key_pass(j0, std::true_type{});
+    for (int base = j0 + PASS; base < ctx; base += PASS) key_pass(base, std::false_type{});
   }
   // merge across the row groups of the wave (lanes that share `part`)
 #pragma unroll
@@ -139,7 +163,7 @@ __global__ __launch_bounds__(NWV * 64) void attn_decode_kernel(const T* __restri
     }
   }
   __syncthreads();
-  if (tid < HD) {
+  if (tid < HD && !skipped) {
     float M = w_m[0];
 #pragma unroll
     for (int w = 1; w < NWV; ++w) M = fmaxf(M, w_m[w]);
