@@ -44,13 +44,14 @@ def compact_bigvgan_state_dict(sd: Dict[str, torch.Tensor], dtype: torch.dtype) 
     return out
 
 
-def broadcast_state_dict(sd: Dict[str, torch.Tensor] | None, src: int = 0, device="cpu") -> Dict[str, torch.Tensor]:
+def broadcast_state_dict(sd: Dict[str, torch.Tensor] | None, src: int = 0, device="cpu",
+                         force_collectives: bool = False) -> Dict[str, torch.Tensor]:
     """Rank `src` passes a state dict, the others pass None; everyone returns the same tensors, dtypes preserved, on
     `device`.  One flat arena and one collective PER DTYPE present (typically fp32 + bf16/fp16 + int64): nothing is
     widened for the wire, integers travel as integers."""
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return {k: v.to(device) for k, v in sd.items()}
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collectives):
+        return {k: v.to(device) for k, v in sd.items()}   # (force_collectives: run the collectives with one rank, a rehearsal)
     rank = dist.get_rank()
     meta = [None]
     if rank == src:
