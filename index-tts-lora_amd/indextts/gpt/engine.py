@@ -518,11 +518,14 @@ class GPTEngine:
         self._step_transformer(B * nb)
         self._beam_select(B, nb, sp)
 
-    def decode_beam(self, max_new: int, sp: dict, num_beams: int, use_graph=True, check_every=16):
+    def decode_beam(self, max_new: int, sp: dict, num_beams: int, use_graph=True, check_every=16, num_return_sequences=1):
         """Beam search / beam-sample after prefill() of B*num_beams rows (row = b*num_beams + beam, the beams of a batch
-        element start as copies).  HF 4.44.2 semantics (oracle/beam_ref.py); returns int64 [B, n] best hypotheses,
+        element start as copies).  HF 4.44.2 semantics (oracle/beam_ref.py); returns int64 [B * num_return_sequences, n]: the
+        num_return_sequences best hypotheses of every element, best first (row = b * num_return_sequences + rank),
         right-padded with the stop token."""
         nb = int(num_beams)
+        if not 1 <= int(num_return_sequences) <= nb:
+            raise ValueError("num_return_sequences has to be in [1, num_beams]")   # generate() raises the same
         R = self._B
         if self._shared_prefix is not None and self._shared_prefix[1] != nb:
             raise ValueError("decode_beam(): prefill(beams=...) was given another beam count")
@@ -548,11 +551,11 @@ class GPTEngine:
         else:
             self._kv_rows = None
         try:
-            return self._decode_beam_loop(B, nb, max_new, sp, use_graph, check_every)
+            return self._decode_beam_loop(B, nb, max_new, sp, use_graph, check_every, int(num_return_sequences))
         finally:
             self._kv_rows = None
 
-    def _decode_beam_loop(self, B, nb, max_new, sp, use_graph, check_every):
+    def _decode_beam_loop(self, B, nb, max_new, sp, use_graph, check_every, num_return=1):
         sp = self._seed_to_state(sp)
         self._beam_select(B, nb, sp)  # token 1 from the prefill logits
         n = 1
@@ -572,11 +575,12 @@ class GPTEngine:
             if n % check_every == 0 and self._poll() >= B:
                 break
         self._poll()
-        return self._beam_finalize(B, nb, n, float(sp.get("length_penalty", 0.0)), max_new)
+        return self._beam_finalize(B, nb, n, float(sp.get("length_penalty", 0.0)), max_new, num_return)
 
-    def _beam_finalize(self, B, nb, n, length_penalty, max_new):
+    def _beam_finalize(self, B, nb, n, length_penalty, max_new, num_return=1):
         """BeamSearchScorer.finalize on the host: running beams of unfinished batch elements become hypotheses (score =
-        sum_logprobs / generated_len**length_penalty), the best hypothesis of each element is returned."""
+        sum_logprobs / generated_len**length_penalty), the num_return best hypotheses of each element are returned, best
+        first (num_beam_hyps_to_keep = num_return_sequences; the device store already holds num_beams per element)."""
         hs = self.b_hyp_score.cpu().numpy()
         hl = self.b_hyp_len.cpu().numpy()
         ht = self.b_hyp_tok.cpu().numpy()
@@ -596,9 +600,10 @@ class GPTEngine:
                         if len(hyps) > nb:
                             hyps.remove(min(hyps, key=lambda h: (h[0], h[1])))
                         worst = min(h[0] for h in hyps)
-            best.append(max(hyps, key=lambda h: (h[0], h[1]))[2])
+            ranked = sorted(hyps, key=lambda h: (h[0], h[1]), reverse=True)
+            best.extend(h[2] for h in ranked[:num_return])
         width = min(max(len(t) for t in best) + 1, max_new)  # sent_max_len = min(longest + 1, max_length)
-        out = torch.full((B, width), self.stop_mel, dtype=torch.int64)
+        out = torch.full((len(best), width), self.stop_mel, dtype=torch.int64)
         for b, t in enumerate(best):
             out[b, : min(len(t), width)] = torch.tensor(t[:width], dtype=torch.int64)
         return out.to(self.device)

@@ -160,12 +160,19 @@ class UnifiedVoice:
                          num_return_sequences=1, max_generate_length=None, typical_sampling=False, typical_mass=.9,
                          speaker_ids=None, force_stop=None, seed=None, return_logits=False, **hf):
         """model.py:669-720.  Accepted generate() keywords: do_sample, top_p, top_k, temperature, repetition_penalty,
-        num_beams, length_penalty.  Returns codes [B, n] (stop-token padded), like `output[:, trunc_index:]`."""
+        num_beams, length_penalty.  Returns codes [B * num_return_sequences, n] (stop-token padded), like
+        `output[:, trunc_index:]`: with beams the num_return_sequences best hypotheses of each element, best first; with
+        sampling that many independent draws per element."""
         if self.engine is None:
             raise RuntimeError("call post_init_gpt2_config() first")
-        if input_tokens is not None or typical_sampling or num_return_sequences != 1:
-            raise NotImplementedError("input_tokens / typical_sampling / num_return_sequences>1 are off the infer.py path")
+        if input_tokens is not None or typical_sampling:
+            raise NotImplementedError("input_tokens / typical_sampling are off the infer.py path")
         num_beams = int(hf.pop("num_beams", 1))
+        nrs = int(num_return_sequences)
+        if nrs < 1 or (num_beams > 1 and nrs > num_beams):
+            raise ValueError("num_return_sequences has to be in [1, num_beams]")
+        if nrs > 1 and num_beams == 1 and not bool(hf.get("do_sample", False)):
+            raise ValueError("greedy decoding returns one sequence: num_return_sequences > 1 needs do_sample=True or num_beams > 1")
         length_penalty = float(hf.pop("length_penalty", 1.0))  # HF default 1.0; infer.py passes 0.0
         sp = dict(do_sample=bool(hf.pop("do_sample", False)), top_p=float(hf.pop("top_p", 1.0)),
                   top_k=int(hf.pop("top_k", 50)), temperature=float(hf.pop("temperature", 1.0)),
@@ -191,7 +198,13 @@ class UnifiedVoice:
                 self.engine.prefill(emb, pad, max_new, beams=num_beams)
             else:
                 self.engine.prefill(emb.repeat_interleave(num_beams, dim=0), pad.repeat_interleave(num_beams), max_new)
-            return self.engine.decode_beam(max_new, sp, num_beams)
+            return self.engine.decode_beam(max_new, sp, num_beams, num_return_sequences=nrs)
+        if nrs > 1:
+            # sampling: generate() expands every row to num_return_sequences copies before the first forward
+            # (_expand_inputs_for_generation); row b * nrs + j is the j-th independent draw of element b
+            emb, pad = emb.repeat_interleave(nrs, dim=0), pad.repeat_interleave(nrs)
+            if force_stop is not None:
+                force_stop = [v for v in force_stop for _ in range(nrs)]
         self.engine.prefill(emb, pad, max_new)
         out = self.engine.decode(max_new, sp, force_stop=force_stop, return_logits=return_logits)
         return out

@@ -197,20 +197,27 @@ class BeamSearch:
     def all_done(self):
         return all(self.done)
 
-    def finalize(self):
-        """Best hypothesis per batch element -> int64 [B, n] right-padded with EOS (generated part only)."""
+    def finalize(self, num_return=1):
+        """The num_return best hypotheses per batch element, best first (BeamSearchScorer.finalize with
+        num_beam_hyps_to_keep = num_return_sequences: sorted by score, popped from the top) -> int64 [B * num_return, n]
+        right-padded with EOS (generated part only); row = b * num_return + rank."""
+        if not 1 <= num_return <= self.nb:
+            raise ValueError("num_return_sequences has to be in [1, num_beams]")
+        import copy
         best = []
         for b in range(self.B):
+            hyps = copy.deepcopy(self.hyps[b])      # finalize may be called more than once: the search state stays as it is
             if not self.done[b]:
                 gen_len = len(self.hist[b][0]) - self.plen
                 for k in range(self.nb):
-                    self.hyps[b].add(self.hist[b][k][self.plen:], self.scores[b, k], gen_len)
-            order = sorted(range(len(self.hyps[b].beams)), key=lambda i: (self.hyps[b].beams[i][0], i))
-            best.append(self.hyps[b].beams[order[-1]][1])
+                    hyps.add(self.hist[b][k][self.plen:], self.scores[b, k], gen_len)
+            order = sorted(range(len(hyps.beams)), key=lambda i: (hyps.beams[i][0], i))
+            for j in range(num_return):
+                best.append(hyps.beams[order[-1 - j]][1])
         # HF finalize: width = longest hypothesis + 1 (capped by max_length by the caller); pad = EOS, and every
         # hypothesis shorter than the width is closed by one EOS -- with pad == EOS that is plain EOS padding
         n = max(len(t) for t in best)
-        out = np.full((self.B, n + 1), self.eos, dtype=np.int64)
+        out = np.full((len(best), n + 1), self.eos, dtype=np.int64)
         for b, t in enumerate(best):
             out[b, : len(t)] = t
         return out

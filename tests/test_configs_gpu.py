@@ -521,6 +521,44 @@ def test_rest_api_and_model_hot_swap(tmp_path):
         assert c.post("/tts", json=body).content == r1.content, "swapping back restores the original voice bit for bit"
 
 
+def test_config1_literal_reference_prompt_and_vocabulary(gsd24, tmp_path):
+    """BASELINE config 1 taken literally, on the GPU build: the reference's tests/sample_prompt.wav (stereo 44.1 kHz) ->
+    mono -> 24 kHz -> log-mel -> conditioner; a 10-character text of the reference's tests/cases.jsonl -> normaliser ->
+    tokenizer with the reference's id map (tests/vocab_model.py, rebuilt from its vocab.txt) -> 24-layer decoder, greedy,
+    num_beams = 1 -> latent pass -> vocoder -> a 24 kHz PCM16 file whose length is 1024 samples per acoustic token.
+    Greedy is deterministic: a second call gives the same file; pinyin in the text arrives as pinyin pieces (8473..10200)."""
+    import warnings
+    import wave
+
+    import vocab_model
+    from indextts.infer import IndexTTS
+    from indextts.utils.front import TextTokenizer
+    G = os.path.join(HERE, "golden")
+    cases = json.load(open(os.path.join(G, "cases.json"), encoding="utf-8"))
+    text = cases[1]["text"][:10]                      # "大家好，我現在正在b" -> ten characters of the reference's second case
+    assert len(text) == 10
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tts = IndexTTS.from_weights(weights.reference_config(), gsd24, weights.bigvgan_state_dict(), device="cuda:0", is_fp16=True)
+        tts.tokenizer = TextTokenizer(vocab_model.write_model(str(tmp_path / "bpe.model")), tts.normalizer)
+        toks = tts.tokenizer.tokenize(text)
+        ids = tts.tokenizer.convert_tokens_to_ids(toks)
+        assert 2 not in ids and len(ids) >= 10 and max(ids) < 12000
+        pin = tts.tokenizer.convert_tokens_to_ids(tts.tokenizer.tokenize(cases[3]["text"]))   # "最zhong4要的是：不要chong2蹈覆轍"
+        assert sum(8473 <= i <= 10200 for i in pin) == 2
+        kw = dict(do_sample=False, num_beams=1, repetition_penalty=10.0, max_mel_tokens=48)
+        prompt = os.path.join(G, "sample_prompt.wav")
+        out1 = tts.infer(prompt, text, str(tmp_path / "a.wav"), **kw)
+        assert tuple(tts.cache_cond_mel.shape) == (1, 100, 511)      # 5.44 s of prompt at 24 kHz / 256
+        out2 = tts.infer(prompt, text, str(tmp_path / "b.wav"), **kw)
+    with wave.open(out1, "rb") as w:
+        assert (w.getframerate(), w.getnchannels(), w.getsampwidth()) == (24000, 1, 2)
+        n = w.getnframes()
+        pcm = np.frombuffer(w.readframes(n), dtype="<i2")
+    assert n % 1024 == 0 and 1 <= n // 1024 <= 48 and np.abs(pcm).max() > 0
+    assert open(out1, "rb").read() == open(out2, "rb").read(), "greedy decode must be reproducible"
+
+
 # ------------------------------------------------------------------------------------------------------- multi-GPU path
 def test_rccl_executes_once_single_rank_bench_body(tmp_path):
     """The N > 1 path of bench.py has only ever run over gloo (no 8-GPU node in the build loop).  Here the REAL rank body runs

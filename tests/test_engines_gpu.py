@@ -342,6 +342,27 @@ def test_beam_decode_matches_host_driven_oracle(gpt_small_fp32, do_sample):
     codes = m.inference_speech(cond_mel, text, do_sample=do_sample, num_beams=nb, top_k=30, top_p=0.8, temperature=1.0,
                                repetition_penalty=10.0, length_penalty=0.0, max_generate_length=max_new, seed=5)
     assert np.array_equal(codes.cpu().numpy()[:, :w], want[:, :w])
+    # num_return_sequences > 1 (model.py:669, :711-714): the k best hypotheses of every element, best first, from the device
+    # hypothesis store -- against the oracle's finalize(num_return=k), itself pinned against transformers' generate()
+    for k in (2, 3):
+        wk = ref.finalize(num_return=k)
+        ck = m.inference_speech(cond_mel, text, do_sample=do_sample, num_beams=nb, top_k=30, top_p=0.8, temperature=1.0,
+                                repetition_penalty=10.0, length_penalty=0.0, max_generate_length=max_new, seed=5,
+                                num_return_sequences=k).cpu().numpy()
+        assert ck.shape[0] == B * k
+        ww = min(ck.shape[1], wk.shape[1])
+        assert np.array_equal(ck[:, :ww], wk[:, :ww]) and (ck[:, ww:] == 8193).all() and (wk[:, ww:] == 8193).all()
+        assert np.array_equal(ck[::k, :w], want[:, :w])          # rank 0 is the single-sequence answer
+    with pytest.raises(ValueError):
+        m.inference_speech(cond_mel, text, num_beams=nb, num_return_sequences=nb + 1, max_generate_length=4)
+    with pytest.raises(ValueError):
+        m.inference_speech(cond_mel, text, do_sample=False, num_beams=1, num_return_sequences=2, max_generate_length=4)
+    if do_sample:   # plain sampling: k independent draws per element (rows expanded before the first forward)
+        one = m.inference_speech(cond_mel, text.repeat_interleave(2, 0), do_sample=True, num_beams=1, top_k=30, top_p=0.8,
+                                 repetition_penalty=10.0, max_generate_length=8, seed=9)
+        two = m.inference_speech(cond_mel, text, do_sample=True, num_beams=1, top_k=30, top_p=0.8, repetition_penalty=10.0,
+                                 max_generate_length=8, seed=9, num_return_sequences=2)
+        assert two.shape[0] == 4 and torch.equal(one, two) and not torch.equal(two[0], two[1])
 
 
 def test_public_api_infer_and_infer_fast_write_wavs(tmp_path):

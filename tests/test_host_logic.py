@@ -1,5 +1,6 @@
 """CPU tests of the host logic around the hot path: silence trimming, bucketing/padding, tokenizer glue, config and
 checkpoint formats, weight-norm folding, transposed-conv rewrite, mel front-end, WAV I/O, sharding."""
+import json
 import os
 import warnings
 
@@ -191,6 +192,129 @@ def test_mel_frontend_properties(tmp_path):
     write_pcm16(str(tmp_path / "a.wav"), pcm, 24000)
     a, sr2 = read_audio(str(tmp_path / "a.wav"))
     assert sr2 == 24000 and np.array_equal((a * 32768).round().astype(np.int16), pcm)
+
+
+def test_mel_frontend_independent_numeric_checks():
+    """The mel / resample front-end cannot be run against torchaudio here (PARITY UNPINNED).  These checks
+    are independent restatements, not a pin: (a) the HTK filterbank from a separately written scalar formula; (b) a bin-centred
+    sine through STFT -> mel -> log against the closed form (periodic Hann: |X[k0]| = A N / 4, |X[k0 +- 1]| = A N / 8, no
+    normalisation, magnitude not power); (c) resampler: unit DC gain, flat pass band, half amplitude at the 0.99 x 12 kHz
+    cut-off (the symmetry of a windowed sinc), stop band above the new Nyquist frequency."""
+    sr, n_fft, n_mels = 24000, 1024, 100
+    fb = mel_filterbank(n_fft // 2 + 1, 0.0, sr / 2, n_mels, sr).double().numpy()
+
+    def hz2mel(f):
+        return 2595.0 * np.log10(1.0 + f / 700.0)
+
+    def mel2hz(m):
+        return 700.0 * (10.0 ** (m / 2595.0) - 1.0)
+    edges = [mel2hz(hz2mel(0.0) + (hz2mel(sr / 2) - hz2mel(0.0)) * i / (n_mels + 1)) for i in range(n_mels + 2)]
+    want = np.zeros_like(fb)
+    for k in range(n_fft // 2 + 1):
+        f = k * (sr / 2) / (n_fft // 2)
+        for m in range(n_mels):
+            lo, mid, hi = edges[m], edges[m + 1], edges[m + 2]
+            want[k, m] = max(0.0, min((f - lo) / (mid - lo), (hi - f) / (hi - mid)))
+    np.testing.assert_allclose(fb, want, atol=2e-5)
+    # (b) closed form of a bin-centred tone
+    A, k0 = 0.25, 64                                    # 1500 Hz exactly on bin 64
+    n = torch.arange(sr)
+    tone = (A * torch.sin(2 * np.pi * k0 * n / n_fft))[None]
+    mel = MelSpectrogramFeatures()(tone)[0].double().numpy()
+    mag = np.zeros(n_fft // 2 + 1)
+    mag[k0], mag[k0 - 1], mag[k0 + 1] = A * n_fft / 4, A * n_fft / 8, A * n_fft / 8
+    expect = np.log(np.clip(want.T @ mag, 1e-7, None))
+    band = np.where(want.T @ mag > 1e-3)[0]
+    assert len(band) >= 2
+    mid = mel[:, 20:-20]
+    np.testing.assert_allclose(mid[band].mean(1), expect[band], atol=2e-3)
+    assert np.abs(mid[band] - expect[band][:, None]).max() < 5e-3          # stationary: every interior frame the same
+    far = [m for m in range(n_mels) if abs(m - band.mean()) > 12]
+    assert mid[far].max() < expect[band].max() - 8.0                        # far from the tone: > 3 decades down (fp32 STFT floor)
+    # (c) resampler 44.1 kHz -> 24 kHz
+    src = 44100
+    dc = resample(torch.ones(1, src), src, sr)
+    assert (dc[0, 50:-50] - 1.0).abs().max() < 1e-3
+    t = torch.arange(src) / src
+
+    def amp(freq):
+        y = resample(torch.sin(2 * np.pi * freq * t)[None], src, sr)[0, 400:-400]
+        return float(y.pow(2).mean().sqrt() * np.sqrt(2))
+    # a Hann-windowed sinc is a half-band-symmetric low-pass: flat pass band, amplitude 1/2 AT the cut-off
+    # (rolloff 0.99 x 12 kHz = 11.88 kHz), stop band beyond the transition (width 6 zero crossings: ~ +-2 kHz)
+    assert abs(amp(1000.0) - 1.0) < 2e-3 and abs(amp(8000.0) - 1.0) < 0.01
+    assert abs(amp(11880.0) - 0.5) < 0.03
+    assert amp(14000.0) < 0.1 and amp(16000.0) < 0.01
+
+
+def test_reference_prompt_wav_through_the_front_end():
+    """BASELINE config 1's prompt, tests/sample_prompt.wav of the reference (data fixture: stereo, 44.1 kHz, 16 bit, 5.44 s),
+    through infer.py:789-800: decode -> mean over channels -> 24 kHz -> log-mel [1, 100, T]."""
+    import wave
+    path = os.path.join(G, "sample_prompt.wav")
+    a, sr0 = read_audio(path)
+    with wave.open(path, "rb") as w:
+        assert (w.getnchannels(), w.getframerate(), w.getsampwidth(), w.getnframes()) == (2, 44100, 2, 239904)
+        raw = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").reshape(-1, 2)
+    assert sr0 == 44100 and a.shape == (239904, 2)
+    np.testing.assert_array_equal((a * 32768.0).round().astype(np.int16), raw)
+    mono = torch.from_numpy(a.T).float().mean(0, keepdim=True)
+    y = resample(mono, sr0, 24000)
+    assert y.shape == (1, int(np.ceil(239904 * 24000 / 44100)))
+    assert float(y.abs().max()) <= float(mono.abs().max()) * 1.1 and abs(float(y.mean())) < 1e-2
+    mel = MelSpectrogramFeatures()(y)
+    T = y.shape[-1] // 256 + 1
+    assert mel.shape == (1, 100, T) and torch.isfinite(mel).all() and T == 511
+    assert mel.min() >= np.log(1e-7) - 1e-6 and mel.max() < np.log(512.0)   # |X| <= N/2 for |x| <= 1 under a Hann window
+    # speech: the low bands carry far more energy than the top ones
+    assert mel[0, :40].exp().mean() > 2 * mel[0, 80:].exp().mean()
+
+
+def test_reference_vocabulary_and_cases():
+    """vocab.txt of the reference (id -> piece dump of bpe.model; tests/golden/vocab_pieces.json) and tests/cases.jsonl
+    through this build's text front-end, as front.py:470-520 exercises them: every piece 8474..10200 is a pinyin syllable
+    with a tone digit under TextNormalizer.PINYIN_TONE_PATTERN and the non-pinyin look-alikes are not; the sentence
+    punctuation tokens exist (no <unk>); pinyin written in the text reaches the tokenizer as ONE piece of that id range;
+    the long cases split into sentences that respect the token budget and bucket without losing a token."""
+    import re
+    import warnings
+
+    import vocab_model
+    from indextts.infer import IndexTTS
+    from indextts.utils.front import TextNormalizer, TextTokenizer
+    pieces = vocab_model.pieces()
+    assert len(pieces) == 12000 and pieces[:3] == ["<s>", "</s>", "<unk>"] and pieces[3:7] == ["▁[ZH]", "▁[EN]", "▁[JA]", "▁[KO]"]
+    for i in range(8474, 10201):
+        assert re.match(TextNormalizer.PINYIN_TONE_PATTERN, pieces[i], re.IGNORECASE), (i, pieces[i])
+    for bad in ["beta1", "better1", "voice2", "bala2", "babala2", "hunger2"]:
+        assert re.match(TextNormalizer.PINYIN_TONE_PATTERN, bad, re.IGNORECASE) is None, bad
+    import tempfile
+    with tempfile.TemporaryDirectory() as d, warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tok = TextTokenizer(vocab_model.write_model(os.path.join(d, "bpe.model")), TextNormalizer())
+        assert tok.vocab_size == 12000
+        # front.py:502-506 checks these for <unk>; "▁..." is not a piece of the dumped vocabulary ("..." is), so it is the one
+        # token of that list the reference's own check would report
+        for t in set([*TextTokenizer.punctuation_marks_tokens, ",", "▁,", "-", "..."]) - {"▁..."}:
+            assert tok.sp_model.PieceToId(t) != 2, t
+        cases = json.load(open(os.path.join(G, "cases.json"), encoding="utf-8"))
+        assert len(cases) == 9 and all(c["prompt_audio"] == "sample_prompt.wav" for c in cases)
+        ids = tok.encode(cases[2]["text"])                     # "暈XUAN4是一種GAN3覺": XUAN4 is corrected to XVAN4 (front.py:114-124)
+        pin = [pieces[i] for i in ids if 8473 <= i <= 10200]
+        assert pin == ["XVAN4", "GAN3"] and 2 not in ids
+        ids = tok.encode(cases[4]["text"])                     # a sentence written entirely in pinyin
+        syll = [i for i in ids if 8473 <= i <= 10200]
+        assert len(syll) >= 12 and 2 not in ids
+        assert [pieces[i] for i in syll[:6]] == ["NI3", "DAO4", "DI3", "XING2", "BU5", "XING2"]
+        for c in cases[5:]:                                    # the long zh / en / mixed paragraphs (infer_mode 1)
+            toks = tok.tokenize(c["text"])
+            sents = tok.split_sentences(toks, 100)
+            # (the splitter may re-attach a punctuation token when it has to cut inside a sentence: the reference's own
+            # behaviour, pinned by tests/golden/host_logic.json -- so the count may move by at most one per sentence)
+            assert abs(sum(len(s) for s in sents) - len(toks)) <= len(sents) and max(len(s) for s in sents) <= 100
+            holder = type("H", (), {})()
+            buckets = IndexTTS.bucket_sentences(holder, [{"idx": i, "sent": s, "len": len(s)} for i, s in enumerate(sents)], 4)
+            assert sorted(x["idx"] for b in buckets for x in b) == list(range(len(sents)))
 
 
 def test_shard_utterances():
