@@ -664,7 +664,7 @@ def main():
         # separate FETCH_SIZE / WRITE_SIZE passes over exactly these launches (tools/pmc_decode_gemm.py) is reported.
         traffic, traffic_src = None, None
         here = os.path.dirname(os.path.abspath(__file__))
-        for name in ("r02_pmc_gemm_skinny.json", "r01_pmc_gemm_skinny.json"):
+        for name in ("r03_pmc_gemm_skinny.json", "r02_pmc_gemm_skinny.json", "r01_pmc_gemm_skinny.json"):
             pmc = os.path.join(here, "profiles", name)
             if os.path.exists(pmc):
                 traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")

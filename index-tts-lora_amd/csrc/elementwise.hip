@@ -372,6 +372,10 @@ static int launch_ln_reduce(const itts_ln_reduce_args& a, hipStream_t s) {
   } while (0)
   if (nslab == 0) {
     if (two) ITTS_LNR(0, true); else ITTS_LNR(0, false);
+  } else if (nslab == 6) {
+    if (two) ITTS_LNR(6, true); else ITTS_LNR(6, false);
+  } else if (nslab == 5) {
+    if (two) ITTS_LNR(5, true); else ITTS_LNR(5, false);
   } else if (nslab == 4) {
     if (two) ITTS_LNR(4, true); else ITTS_LNR(4, false);
   } else if (nslab == 3) {
@@ -381,7 +385,7 @@ static int launch_ln_reduce(const itts_ln_reduce_args& a, hipStream_t s) {
   } else if (nslab == 1) {
     if (two) ITTS_LNR(1, true); else ITTS_LNR(1, false);
   } else {
-    set_error("itts_ln_reduce: nslab must be 0..4 (got %d)", nslab);
+    set_error("itts_ln_reduce: nslab must be 0..6 (got %d)", nslab);
     return ITTS_ERR_INVALID;
   }
 #undef ITTS_LNR

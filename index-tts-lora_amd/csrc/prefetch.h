@@ -47,7 +47,9 @@ __device__ __forceinline__ void pf_issue(const PfParams& pf, unsigned lin, unsig
     const int tl = (int)(((float)q + 0.5f) * pf.inv_pp);
     const int p = q - tl * pf.pp;
     const int lb = r + 8 * m;                          // consumer workgroup
-    const int ks = (lb >= pf.gx) + (lb >= 2 * pf.gx) + (lb >= 3 * pf.gx);   // gy <= 4; no branch (a join would drain vmcnt)
+    int ks = 0;   // gy <= 8; sums of compares, no branch (a join would drain vmcnt)
+#pragma unroll
+    for (int i = 1; i < 8; ++i) ks += (lb >= i * pf.gx);
     const int bx = lb - ks * pf.gx;
     const int t = bx * pf.ntb + tl;
     const int kbeg = ks * pf.SB;
@@ -81,7 +83,7 @@ static inline int itts_make_prefetch(const itts_prefetch& a, itts::PfParams* o) 
   const int rc = itts_skinny_plan(a.dtype, a.M, a.N, a.K, ksplit, q);
   if (rc != ITTS_OK) return rc;
   const int kstep = a.dtype == ITTS_F32 ? 16 : 32;
-  ITTS_REQUIRE(a.K % kstep == 0 && ksplit <= 4, "itts_prefetch: bad consumer shape N=%d K=%d ksplit=%d", a.N, a.K, ksplit);
+  ITTS_REQUIRE(a.K % kstep == 0 && ksplit <= 8, "itts_prefetch: bad consumer shape N=%d K=%d ksplit=%d", a.N, a.K, ksplit);
   const int KT = a.K / kstep, NT = (a.N + 15) / 16;
   const int64_t bytes = (int64_t)NT * KT * 1024;
   ITTS_REQUIRE(bytes < ((int64_t)1 << 31), "itts_prefetch: packed weight too large");

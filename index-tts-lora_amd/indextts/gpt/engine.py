@@ -94,7 +94,9 @@ class GPTEngine:
         self.extra_ids = torch.tensor([1, start_mel_token], dtype=torch.int32, device=dev)  # fake prefix ids (model.py:658-667)
         self._cap_b = self._cap_s = 0
         self._graphs = {}
-        self.KSPLIT = 3  # split-K of the two N=1280 GEMMs of a block: 80 column tiles x 3 = 240 workgroups (one round of 256 CUs)
+        # split-K of the two N=1280 GEMMs of a block (80 column tiles): 3 -> 80 x 3 = 240 workgroups of one tile; 6 -> 40 x 6 = 240
+        # workgroups of TWO tiles, whose waves fetch each activation fragment once for both (a third less load traffic per CU)
+        self.KSPLIT = int(os.environ.get("ITTS_KSPLIT", "3"))
         self.force_eager = False  # measurement aid: launch every kernel eagerly
         self.steps_per_graph = int(os.environ.get("ITTS_STEPS_PER_GRAPH", "1"))  # decode tokens per CUDA-graph replay; measured 1 > 2 > 4 > 8 (1297 / 1319 / 1342 / 1368 us per token)
         self._sink = torch.zeros(4, dtype=torch.int32, device=dev)
@@ -126,6 +128,8 @@ class GPTEngine:
             return nat.pack_weight(w.to(T).contiguous())
 
         self.detach_lora()   # every attach starts from the base weights: nothing of an earlier adapter set survives
+        if not adapters:     # attach_lora(None) = detach
+            return
         for i, l in enumerate(self.layers):
             p = f"gpt.h.{i}."
             for name, wkey in (("attn.c_attn", "w_qkv"), ("mlp.c_fc", "w_fc")):

@@ -209,8 +209,8 @@ class UnifiedVoice:
         out = self.engine.decode(max_new, sp, force_stop=force_stop, return_logits=return_logits)
         return out
 
-    def attach_lora(self, adapters: dict, scaling: float):
-        """Unmerged LoRA adapters at run time (peft tensors of the Conv1D targets attn.c_attn / attn.c_proj / mlp.c_fc /
+    def attach_lora(self, adapters: dict | None, scaling: float = 1.0):
+        """Unmerged LoRA adapters at run time (None detaches; peft tensors of the Conv1D targets attn.c_attn / attn.c_proj / mlp.c_fc /
         mlp.c_proj, train.py:555-563): see GPTEngine.attach_lora.  The reference itself only ever loads merged weights."""
         if self.engine is None:
             raise RuntimeError("call post_init_gpt2_config() first")

@@ -406,7 +406,9 @@ def test_request_pool_matches_serial_infer_batch():
     first = IndexTTS.from_weights(cfg, weights.gpt_state_dict(2), weights.bigvgan_state_dict(), device="cuda:0",
                                   precision_config={"gpt": "bf16", "vocoder": "fp16"})
     insts = [first, first.replica()]          # shared weights, private KV cache / state / graphs
-    assert insts[1].gpt.engine.layers is first.gpt.engine.layers and insts[1].gpt.engine is not first.gpt.engine
+    e0, e1 = first.gpt.engine, insts[1].gpt.engine
+    assert e1 is not e0 and e1.layers is not e0.layers                 # own per-layer dicts (adapter state is per engine) ...
+    assert all(a[k] is b[k] for a, b in zip(e0.layers, e1.layers) for k in a)   # ... over the SAME weight tensors
     cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
     rng = np.random.default_rng(9)
     batches = [[torch.from_numpy(rng.integers(2, 12000, size=int(n))).to(torch.int32) for n in rng.integers(5, 20, size=4)]

@@ -1,8 +1,9 @@
 set -o pipefail
+R=${R:-r03}   # round tag of the output files
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_beam -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-concurrency --no-roofline > gpurun_out/prof_beam.json 2> gpurun_out/prof_beam.log || { tail -20 gpurun_out/prof_beam.log; exit 1; }
-python3 - <<'PY'
+R=$R python3 - <<'PY'
 import csv, glob
 f=[x for x in glob.glob("gpurun_out/prof_beam/**/*kernel_stats.csv", recursive=True)]
 rows=list(csv.DictReader(open(f[0])))
