@@ -171,6 +171,42 @@ def test_l2_run_ahead_changes_no_bit(dtype):
         assert torch.equal(c, outs[0][0]) and torch.equal(l, outs[0][1])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_latent_pass_reuses_the_cached_prompt(dtype):
+    """GPTEngine.latent_mel_rows (only the mel rows recomputed, the prompt's keys / values taken from the KV cache the decode
+    loop leaves behind) against the full teacher-forced pass over cond | text | mel: the SAME bits, for a left-padded batch of
+    mixed text and code lengths, after a real decode (which appends behind the prompt), and through IndexTTS._latents."""
+    from indextts.infer import IndexTTS
+    cfg = weights.reference_config()
+    cfg["gpt"]["layers"] = 2
+    tts = IndexTTS.from_weights(cfg, weights.gpt_state_dict(2), weights.bigvgan_state_dict(), device="cuda:0",
+                                precision_config={"gpt": "fp32" if dtype == torch.float32 else "bf16", "vocoder": "fp16"})
+    cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
+    rng = np.random.default_rng(4)
+    texts = [torch.from_numpy(rng.integers(2, 12000, size=int(n))).to(torch.int32) for n in (5, 17, 9, 12)]
+    gen = dict(do_sample=True, top_k=30, top_p=0.8, temperature=1.0, repetition_penalty=10.0, num_beams=1)
+    st = tts._batch_tokens(cond_mel, texts, max_mel_tokens=14, force_stop=[13, 7, 10, 4], seed=3, **gen)
+    assert [int(r.numel()) for r in st["rows"]] == [13, 7, 10, 4]
+    full = tts._latents(st["conds"], st["texts"], st["rows"], reuse_prefix=False)
+    fast = tts._latents(st["conds"], st["texts"], st["rows"], reuse_prefix=True)
+    assert len(full) == len(fast) == 4
+    for a, b in zip(full, fast):
+        assert a.shape == b.shape and torch.equal(a, b)
+    # beams: the prompt is cached once per element (row table) or in every beam's row (copy): both are found
+    for kv in ("table", "copy"):
+        tts.gpt.engine.beam_kv = kv
+        stb = tts._batch_tokens(cond_mel, texts[:2], max_mel_tokens=8, seed=3, **dict(gen, num_beams=3))
+        fb = tts._latents(stb["conds"], stb["texts"], stb["rows"], reuse_prefix=False)
+        rb = tts._latents(stb["conds"], stb["texts"], stb["rows"], reuse_prefix=True, cache_rows=stb["cache_rows"])
+        for a, b in zip(fb, rb):
+            assert torch.equal(a, b), kv
+    tts.gpt.engine.beam_kv = "table"
+    # the switch: with reuse off the same call takes the full pass
+    tts.reuse_prompt_kv = False
+    off = tts._latents(st["conds"], st["texts"], st["rows"], reuse_prefix=True)
+    assert all(torch.equal(a, b) for a, b in zip(full, off))
+
+
 def test_gpt_bf16_tracks_fp32():
     g = np.load(os.path.join(G, "gpt_small.npz"))
     m = make_gpt(2, torch.bfloat16)
