@@ -864,11 +864,133 @@ static int launch_narrow(const ConvParams& p, hipStream_t s) {
   return check_launch("itts_gemm_conv");
 }
 
+// Second form of the narrow kernel (round 3) for the layers that dominate the last two vocoder stages (Cin = N = 24 / 48,
+// taps 3 / 7 / 11): per-wave tiles of TM x 16 rows and EVERY tap's activation fragments of a tile requested before the first
+// MFMA (in one or two groups).  The first form walks the taps with one tap of look-ahead: a 64-row tile pays 4-6 dependent
+// L1 / L2 round trips (tools/timeline_narrow.py: 4.1-6.3 us in the taps against 0.4 us of MFMA time).  Here a tile pays one
+// or two, and the smaller register footprint lets more waves share a SIMD.  Same arithmetic in the same order (taps outer,
+// column tiles, k-steps inner): bit-identical to the first form.
+// taps per request group: at most 16 activation fragments (64 VGPRs) in flight per lane, so that 3-4 waves share a SIMD
+// (measured at C = 48, k = 7: one group of 7 taps at 2 waves per SIMD 195 us, at 3 waves per SIMD 174 us)
+template <int TM, int KT, int TAPS>
+struct NarrowGroup {
+  static constexpr int CAP = 28 / (TM * KT) < 1 ? 1 : 28 / (TM * KT);
+  static constexpr int G = TAPS < CAP ? TAPS : CAP;
+};
+
+template <typename T, int KT, int NT, int TAPS, int TM, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 3))
+void conv_narrow_taps_kernel(ConvParams p) {
+  typedef Elem<T> EL;
+  typedef typename EL::frag frag;
+  constexpr int E = EL::E, KS = EL::KS, BM = NW * TM * 16, NTH = NW * 64;
+  constexpr int G = NarrowGroup<TM, KT, TAPS>::G;   // taps per request group
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the tile bookkeeping stays in SGPRs
+  const int g = lane >> 4, r = lane & 15;
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  const int wbytes = TAPS * NT * KT * 1024;
+  for (int off = tid * 16; off < wbytes; off += NTH * 16) st16(lds + off, ld16<frag>((const unsigned char*)p.wp + off));
+  __syncthreads();
+  const int ntiles = p.MB * p.B;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / p.MB, mblk = tile - b * p.MB;
+    const int row0 = mblk * BM + wave * (TM * 16);
+    const int vrows = conv_valid_rows(p, b);
+    if (row0 + p.off0 >= vrows) continue;   // ragged batch: this wave's rows lie in the batch element's padding (no barrier in the loop)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>((const T*)p.x + (int64_t)b * p.x_bstride), 0, (int)((int64_t)vrows * p.Cin * (int)sizeof(T)), 0x00020000);
+    f32x4 acc[TM][NT];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j0 = 0; j0 < TAPS; j0 += G) {
+      frag af[G][TM][KT];
+#pragma unroll
+      for (int jj = 0; jj < G; ++jj)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const int tin = row0 + tm * 16 + r + p.off0 + (j0 + jj) * p.dil;
+#pragma unroll
+          for (int ks = 0; ks < KT; ++ks) {
+            const int col = ks * KS + g * E;
+            const bool ok = (j0 + jj < TAPS) && (tin >= 0) && (tin < vrows) && (col < p.Cin);
+            const unsigned off = ok ? (unsigned)((tin * p.Cin + col) * (int)sizeof(T)) : OOB;
+            af[jj][tm][ks] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+          }
+        }
+#pragma unroll
+      for (int jj = 0; jj < G; ++jj) {
+        if (j0 + jj < TAPS) {
+          const unsigned char* wb = lds + (size_t)(j0 + jj) * NT * KT * 1024 + lane * 16;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < KT; ++ks) {
+              const frag bf = ld16<frag>(wb + (nt * KT + ks) * 1024);
+#pragma unroll
+              for (int tm = 0; tm < TM; ++tm) acc[tm][nt] = EL::mma(bf, af[jj][tm][ks], acc[tm][nt]);  // weights as A: transposed tile
+            }
+        }
+      }
+    }
+    conv_epilogue<T, TM, NT>(p, acc, b, row0, 0, g, r);
+  }
+}
+
+template <typename T, int KT, int NT, int TAPS, int TM, int NW>
+static int launch_narrow_taps(const ConvParams& p, hipStream_t s) {
+  constexpr int BM = NW * TM * 16;
+  ConvParams q = p;
+  q.MB = (p.Tout + BM - 1) / BM;
+  q.NB = 1;
+  q.GM = 1;
+  const int64_t tiles = (int64_t)q.MB * p.B;
+  const size_t ldsb = (size_t)TAPS * NT * KT * 1024;
+  static std::once_flag attr;
+  static int per_cu = 1;
+  std::call_once(attr, [] {
+    constexpr size_t ldsb = (size_t)TAPS * NT * KT * 1024;
+    (void)hipFuncSetAttribute((const void*)conv_narrow_taps_kernel<T, KT, NT, TAPS, TM, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024 - 256);
+    int q_wgs = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q_wgs, (const void*)conv_narrow_taps_kernel<T, KT, NT, TAPS, TM, NW>, NW * 64, ldsb) !=
+            hipSuccess || q_wgs < 1)
+      q_wgs = 1;
+    (void)hipGetLastError();
+    per_cu = q_wgs;
+  });
+  int64_t grid = (int64_t)conv_num_cus() * per_cu;
+  if (grid > tiles) grid = tiles;
+  hipLaunchKernelGGL((conv_narrow_taps_kernel<T, KT, NT, TAPS, TM, NW>), dim3((unsigned)grid), dim3(NW * 64), ldsb, s, q);
+  return check_launch("itts_gemm_conv");
+}
+
+#if ITTS_DIAG
+int g_conv_cfg = 0;  // diagnostic build: itts_debug_set(3, id) kernel override for A/B measurements (0 = default)
+#else
+constexpr int g_conv_cfg = 0;  // product build: the heuristic below, no mutable state (the override branches fold away)
+#endif
+
 // (k-steps, column tiles) pairs built for the narrow kernel; everything else takes the tiled kernel
 template <typename T>
 static int dispatch_narrow(const ConvParams& p, hipStream_t s, bool& handled) {
   handled = true;
   const int kt = p.KT, nt = p.NT;
+  if (g_conv_cfg != 30) {   // (diagnostic build: cfg 30 = the first form everywhere, for A/B runs)
+#define ITTS_NT_CASE(KT_, NT_, TM_, NW_)                                                               \
+    if (kt == KT_ && nt == NT_ && p.taps == 3) return launch_narrow_taps<T, KT_, NT_, 3, TM_, NW_>(p, s);   \
+    if (kt == KT_ && nt == NT_ && p.taps == 7) return launch_narrow_taps<T, KT_, NT_, 7, TM_, NW_>(p, s);   \
+    if (kt == KT_ && nt == NT_ && p.taps == 11) return launch_narrow_taps<T, KT_, NT_, 11, TM_, NW_>(p, s);
+    // measured on MI355X (fp16, batch 32, k = 7; first form 211 / 184 us at C = 48 / 24): C = 48: 2 row tiles per wave, 4 waves
+    // 177-181 us (8 waves 197, 1 row tile x 8 waves 176 with spills); C = 24: 4 row tiles per wave 144-148 us (2 tiles 154-162)
+    ITTS_NT_CASE(1, 2, 4, 4)
+    ITTS_NT_CASE(2, 3, 2, 4)
+#undef ITTS_NT_CASE
+  }
   if (kt == 1 && nt == 1) return launch_narrow<T, 1, 1>(p, s);
   if (kt == 1 && nt == 2) return launch_narrow<T, 1, 2>(p, s);
   if (kt == 2 && nt == 1) return launch_narrow<T, 2, 1>(p, s);
@@ -878,12 +1000,6 @@ static int dispatch_narrow(const ConvParams& p, hipStream_t s, bool& handled) {
   handled = false;
   return ITTS_OK;
 }
-
-#if ITTS_DIAG
-int g_conv_cfg = 0;  // diagnostic build: itts_debug_set(3, id) kernel override for A/B measurements (0 = default)
-#else
-constexpr int g_conv_cfg = 0;  // product build: the heuristic below, no mutable state (the override branches fold away)
-#endif
 
 template <typename T>
 static int dispatch_conv(const ConvParams& p, hipStream_t s) {

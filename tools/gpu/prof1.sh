@@ -15,4 +15,5 @@ for r in rows[:45]:
     print(f'{float(r["TotalDurationNs"])/1e6:9.2f} ms {100*float(r["TotalDurationNs"])/tot:5.1f}% n={r["Calls"]:>7} avg={float(r["AverageNs"])/1e3:8.2f} us  {r["Name"][:150]}')
 PY
 cp "$(find gpurun_out/prof_${R} -name "*kernel_stats.csv" | head -1)" gpurun_out/${R}_bench_kernel_stats.csv
+rm -rf gpurun_out/prof_${R}   # the per-dispatch trace is > 64 MiB: only the stats summary travels back
 echo ALLDONE
