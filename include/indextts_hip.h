@@ -48,7 +48,7 @@ extern "C" {
 #define ITTS_BF16 1
 #define ITTS_F16 2
 
-#define ITTS_ABI_VERSION 5
+#define ITTS_ABI_VERSION 5 /* 5: same struct layouts as 4; itts_ln_reduce takes up to 6 slabs (4: <= 4) */
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -89,24 +89,6 @@ int itts_aa_snake_fwd(const void* x, void* y, const float* alpha_log, const floa
  * The GEMM then reads a fragment as one contiguous 1-KiB wave-load instead of 16 rows x 64 bytes.  Producers that can
  * write it: itts_ln_reduce (y_packed), itts_attn_decode (out_packed), itts_gemm_skinny (y_packed, tail_y_packed).
  * ------------------------------------------------------------------------------------------------------------------ */
-
-/* ------------------------------------------------------------------------------------------------------------------
- * L2 run-ahead for the decode step (optional member of the decode launches' argument structs; wp == NULL = off).
- * The token loop is a chain of ~170 dependent launches, each of which finds its weights cold in HBM.  A launch that is
- * given an itts_prefetch TOUCHES (one dword per 64 bytes, results discarded) the packed weight bytes that a LATER
- * itts_gemm_skinny launch {dtype, M, N, K, ksplit} will stream, so that they sit in L2 when that launch starts; the HBM
- * fetch then overlaps this launch's own dependent work instead of heading the consumer's critical path.  L2 is per XCD and
- * workgroups are dealt round-robin over the 8 XCDs (measured: block b of every launch of a graph lands on XCD
- * (b + c) % 8 with one c): workgroup b of this launch touches exactly the bytes the consumer's workgroups b' = b (mod 8)
- * will read (the consumer's geometry is derived as itts_skinny_plan does).  A different placement only makes the
- * consumer's reads L2 misses again -- speed, never correctness: the touched values are never used.
- * part / parts: this launch touches share `part` of `parts` (0 / 0 or 1 = all of it), so two launches can split a weight.
- * ------------------------------------------------------------------------------------------------------------------ */
-typedef struct itts_prefetch {
-  const void* wp; /* packed weight of the consumer GEMM (NULL: nothing is touched) */
-  int dtype, M, N, K, ksplit;
-  int part, parts;
-} itts_prefetch;
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Skinny GEMM for the decode step: Y[M][N] = epi( X[M][K] @ W[K][N] + bias ), up to 96 rows (bf16/f16; 16 in fp32) per
@@ -163,7 +145,6 @@ typedef struct itts_skinny_args {
   /* Packed-activation layout (see "Packed activation layout" above): x_packed -- x is packed [K/KS][ceil(M/16)][64][E];
    * y_packed -- y (ITTS_EPI_STORE / ITTS_EPI_GELU_STORE, N % KS == 0) is written packed; tail_y_packed -- the tail's y. */
   int x_packed, y_packed, tail_y_packed;
-  itts_prefetch pf; /* L2 run-ahead for a later launch's weights (see itts_prefetch) */
 } itts_skinny_args;
 int itts_gemm_skinny(const itts_skinny_args* a, void* stream);
 /* launch geometry itts_gemm_skinny would use: out6 = {grid.x, grid.y, waves per workgroup, column tiles per workgroup,
@@ -212,7 +193,7 @@ int itts_layernorm(const float* h, const float* w, const float* b, const float* 
  *   if (nslab > 0)  h[m][:] += bias[:] + slab[0][m][:] + ... + slab[nslab-1][m][:]      (fixed order; h updated in place)
  *                   [+ runtime LoRA, below]
  *   y[m][:] = LN(h[m][:]; w, b)   (then LN(.; w2, b2) if w2 != NULL),  y is T [M][D].
- * slab is fp32 [nslab][M][slab_stride] as written by itts_gemm_skinny(ITTS_EPI_SLAB_F32) with N = slab_stride (0 = D).
+ * nslab <= 6.  slab is fp32 [nslab][M][slab_stride] as written by itts_gemm_skinny(ITTS_EPI_SLAB_F32) with N = slab_stride (0 = D).
  * y_packed != 0 (needs D % 256 == 0): y is written in the packed activation layout.
  * state_bump (int32[2] device words or NULL): both words are incremented once by this launch -- the decode loop's step
  * counter and cache position, advanced here (a launch that reads neither) instead of by the sampling kernel.

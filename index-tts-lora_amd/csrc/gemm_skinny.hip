@@ -24,8 +24,6 @@
 // indextts/gpt/model.py:163-193.
 #include "common.h"
 #include "ln_math.h"
-#include "prefetch.h"
-#include <type_traits>
 
 #ifndef ITTS_NT_WEIGHTS
 #define ITTS_NT_WEIGHTS 0   // build-time A/B: non-temporal policy for the once-read weight blocks (measured neutral)
@@ -67,7 +65,6 @@ struct SkinnyParams {
   int t_acquire;
   int x_pa, y_pa, t_y_pa;  // packed-activation layout for x / y (STORE, GELU_STORE) / the tail's y
   int mtp, row0;           // row tiles of the WHOLE operand, first row of this launch (a multiple of 16)
-  PfParams pf;             // L2 run-ahead for a later launch's weights (prefetch.h)
 #if ITTS_STAMPS
   unsigned long long* stamps;
 #endif
@@ -196,8 +193,8 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
   const char* bp = (const char*)p.wp + ((int64_t)nt0 * KT * 64 + lane) * 16;  // tile t of this workgroup: + t*KT*1024
   const T* X = (const T*)p.x;
 
-  // Epilogue operands of this wave's output units are requested now: their latency overlaps the weight stream, and no
-  // load is issued after the run-ahead requests below (vmcnt returns in order: a later load would wait for those to land).
+  // Epilogue operands of this wave's output units are requested now, in front of the weight stream: their latency overlaps it
+  // and the epilogue issues no load of its own.
   // UPRE units per wave cover every launch with 8 waves; launches with fewer waves (tiny K) finish in a second loop.
   constexpr int UPRE = (NTB * MT + 7) / 8;
   f32x4 bias_pre[UPRE];
@@ -227,17 +224,11 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // L2 run-ahead (prefetch.h): requested right behind this wave's own first loads -- vmcnt returns in order, so the
-  // wave's operands are never queued behind them -- and never waited for (s_endpgm waits for the memory system)
-  PfRegs pfr;
-#pragma unroll
-  for (int i = 0; i < PF_SLOTS; ++i) pfr.v[i] = 0;
-  const unsigned pf_lin = blockIdx.y * gridDim.x + blockIdx.x, pf_nblk = gridDim.x * gridDim.y;
-
-  // one pass over SPW k-steps from `base`; the FIRST pass always runs (a wave without a K share requests nothing and adds
-  // zeros) so that every wave executes one straight line: operand requests -> run-ahead requests -> counted wait -> MFMAs
-  auto k_pass = [&](const int base, auto first_tag) {
-    constexpr bool FIRST = decltype(first_tag)::value;
+  // One pass over SPW k-steps from `base`.  The FIRST pass always runs (a wave without a K share requests nothing and adds
+  // zeros): every wave executes one straight line -- operand requests, one wait, MFMAs -- with no join in front of the
+  // requests (round 3: together with the branch-free bias preload and the LDS-only barrier, 5.65 -> 5.29 us per launch
+  // over a block's four GEMMs against the round-2 kernel on the same box, tools/probes/ab_r02_gemm.py).
+  auto k_pass = [&](const int base) {
     frag bf[NTB][SPW];
 #pragma unroll
     for (int t = 0; t < NTB; ++t)
@@ -259,11 +250,6 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
           else
             af[i][mt] = (s < s_end && row < p.M) ? ld16<frag>(X + (int64_t)row * p.K + s * KS + g * E) : zero_frag<frag>();
         }
-      }
-      if constexpr (FIRST && !TAIL) {   // (the reducer-tail instantiations have no registers to spare for it)
-        __builtin_amdgcn_sched_barrier(0);   // pinned: behind the operand requests, ahead of the wait for them
-        pf_issue(p.pf, pf_lin, pf_nblk, wave, NW, lane, pfr);
-        __builtin_amdgcn_sched_barrier(0);
       }
       ITTS_STAMP(1);
 #if ITTS_STAMPS
@@ -293,13 +279,6 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
           else
             af[i] = (s < s_end && row < p.M) ? ld16<frag>(X + (int64_t)row * p.K + s * KS + g * E) : zero_frag<frag>();
         }
-        if constexpr (FIRST && !TAIL) {
-          if (mt == MT - 1) {   // behind the LAST row tile's requests (earlier ones would queue the later tiles behind it)
-            __builtin_amdgcn_sched_barrier(0);
-            pf_issue(p.pf, pf_lin, pf_nblk, wave, NW, lane, pfr);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
 #pragma unroll
         for (int i = 0; i < SPW; ++i)
 #pragma unroll
@@ -308,8 +287,8 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
       ITTS_STAMP(2);
     }
   };
-  k_pass(s_begin, std::true_type{});
-  for (int base = s_begin + SPW; base < s_end; base += SPW) k_pass(base, std::false_type{});
+  k_pass(s_begin);
+  for (int base = s_begin + SPW; base < s_end; base += SPW) k_pass(base);
   ITTS_STAMP(3);
 
   // ---- cross-wave reduction, fixed order.  Lane (g, r) of a tile holds Y[row = mt*16 + r][col = tile*16 + 4g .. 4g+3].
@@ -317,7 +296,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
   for (int t = 0; t < NTB; ++t)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) st16(red + (((wave * NTB + t) * MT + mt) * 64 + lane) * 4, acc[t][mt]);
-  // LDS-only wait + raw barrier: __syncthreads() would also drain vmcnt, i.e. wait for the run-ahead requests to land
+  // LDS-only wait + raw barrier (__syncthreads() would also drain vmcnt)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -425,7 +404,6 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
       ITTS_STAMP(9);
     }
   }
-  pf_keep(pfr);
 #if ITTS_STAMPS
   if (p.stamps != nullptr && threadIdx.x == 0) {
     ITTS_STAMP_DRAIN();
@@ -588,10 +566,6 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
     p.t_epoch = a->tail_epoch;
     p.t_err = a->tail_err;
     p.t_acquire = a->tail_acquire;
-    {
-      const int prc = itts_make_prefetch(a->pf, &p.pf);
-      if (prc != ITTS_OK) return prc;
-    }
 #if ITTS_STAMPS
     p.stamps = g_stamp_buf;
 #endif

@@ -24,19 +24,6 @@ class NativeError(RuntimeError):
     pass
 
 
-class Prefetch(C.Structure):
-    _fields_ = [("wp", C.c_void_p), ("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("ksplit", C.c_int),
-                ("part", C.c_int), ("parts", C.c_int)]
-
-
-def _set_prefetch(dst, pf):
-    """pf = dict(wp, dtype, M, N, K[, ksplit, part, parts]): the later skinny GEMM whose weight bytes this launch touches."""
-    if pf is None:
-        return
-    dst.wp, dst.dtype, dst.M, dst.N, dst.K = _p(pf["wp"]), dt(pf["dtype"]), pf["M"], pf["N"], pf["K"]
-    dst.ksplit, dst.part, dst.parts = pf.get("ksplit", 1), pf.get("part", 0), pf.get("parts", 1)
-
-
 class SkinnyArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("wp", C.c_void_p),
                 ("bias", C.c_void_p), ("x", C.c_void_p), ("epi", C.c_int), ("y", C.c_void_p), ("yf", C.c_void_p),
@@ -44,8 +31,7 @@ class SkinnyArgs(C.Structure):
                 ("smax", C.c_int), ("ksplit", C.c_int), ("tail_h", C.c_void_p), ("tail_bias", C.c_void_p),
                 ("tail_w", C.c_void_p), ("tail_b", C.c_void_p), ("tail_w2", C.c_void_p), ("tail_b2", C.c_void_p),
                 ("tail_y", C.c_void_p), ("tail_counter", C.c_void_p), ("tail_epoch", C.c_void_p), ("tail_err", C.c_void_p),
-                ("tail_acquire", C.c_int), ("x_packed", C.c_int), ("y_packed", C.c_int), ("tail_y_packed", C.c_int),
-                ("pf", Prefetch)]
+                ("tail_acquire", C.c_int), ("x_packed", C.c_int), ("y_packed", C.c_int), ("tail_y_packed", C.c_int)]
 
 
 class LnReduceArgs(C.Structure):
@@ -215,9 +201,8 @@ def aa_snake(x, alpha_log, beta_log, up_f, down_f, layout=0, out=None, valid_row
 
 
 def gemm_skinny(dtype, M, N, K, wp, bias=None, x=None, epi=EPI_STORE, y=None, yf=None, kcache=None, vcache=None, pos=None,
-                heads=0, smax=0, ksplit=1, tail=None, x_packed=False, y_packed=False, pf=None):
-    """pf = dict(wp, dtype, M, N, K[, ksplit, part, parts]): L2 run-ahead for a later launch (itts_prefetch).
-    tail = dict(h, w, b, y, counter, epoch, err[, bias, w2, b2, acquire]): reducer tail of a split-K launch --
+                heads=0, smax=0, ksplit=1, tail=None, x_packed=False, y_packed=False):
+    """tail = dict(h, w, b, y, counter, epoch, err[, bias, w2, b2, acquire]): reducer tail of a split-K launch --
     h += bias + slabs, y = LN(h) computed by the last M arriving workgroups of the same launch (see itts_skinny_args)."""
     a = SkinnyArgs()
     if tail is not None:
@@ -231,7 +216,6 @@ def gemm_skinny(dtype, M, N, K, wp, bias=None, x=None, epi=EPI_STORE, y=None, yf
     a.epi, a.y, a.yf = epi, _p(y), _p(yf)
     a.kcache, a.vcache, a.pos, a.heads, a.smax, a.ksplit = _p(kcache), _p(vcache), _p(pos), heads, smax, ksplit
     a.x_packed, a.y_packed = int(bool(x_packed)), int(bool(y_packed))
-    _set_prefetch(a.pf, pf)
     _check(lib().itts_gemm_skinny(C.byref(a), _stream()), "itts_gemm_skinny")
 
 

@@ -60,10 +60,6 @@ class GPTEngine:
         self._shared_prefix = None   # (B, num_beams) after prefill(beams=n): the prompt's K/V exists once per batch element
         self.max_rows_per_launch = 16 if dtype == torch.float32 else 96   # rows one skinny-GEMM launch covers
 
-        # L2 run-ahead (include/indextts_hip.h, itts_prefetch): which launches of a block touch a later GEMM's weights.
-        # Letters: q = the QKV GEMM touches the out-projection's, o = out-projection -> FC, f = FC -> FC2,
-        # p = FC2 -> the next block's QKV (the last block: the mel head).  Same bits with any setting.
-        self.prefetch = os.environ.get("ITTS_PREFETCH", "qofp")
         # Rows that have emitted their stop token are left out of the decode attention (the sampler pads them with the stop
         # token whatever their logits are).  Their logits -- decode(return_logits=True) -- are then UNDEFINED from the step
         # after their stop on; every other row is untouched (all later stages are per row).  False: compute them anyway.
@@ -417,11 +413,6 @@ class GPTEngine:
         nat.embed_step(self.tokens, self.mel_emb, self.mel_pos, step, 2 if bump else 1, h, epoch=self.state[6:7])
         nat.ln_reduce(h, self.layers[0]["ln1"][0], self.layers[0]["ln1"][1], xn, state_bump=self.state[0:2] if bump else None,
                       y_packed=pa)
-        pfs = self.prefetch if B <= self.max_rows_per_launch else ""   # (row-chunked launches: one weight pass each)
-
-        def pf(key, w, N, K, ksplit=1):
-            return dict(wp=w, dtype=T, M=B, N=N, K=K, ksplit=ksplit) if key in pfs else None
-
         for i, l in enumerate(self.layers):
             last = i + 1 == self.L
             n_o = l.get("lora_n_o", D)
@@ -429,14 +420,12 @@ class GPTEngine:
             w_o = l.get("w_o_lora", l["w_o"])
             w_pr = l.get("w_pr_lora", l["w_pr"])
             nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv"], l["b_qkv"], x=xn, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
-                            vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s, x_packed=pa,
-                            pf=pf("q", w_o if not tail else l["w_o"], n_o if not tail else D, D, KS))
+                            vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s, x_packed=pa)
             nat.attn_decode(self.q, self.kc[i], self.vc[i], self.a, self.pad, pos, B, H, self._cap_s, out_packed=pa,
                             kv_rows=self._kv_rows, kv_step=step if self._kv_rows is not None else None,
                             skip_rows=self.finished if self._kv_rows is None and self.skip_finished else None)
             nxt = self.ln_f if last else self.layers[i + 1]["ln1"]
             nxt2 = self.final_norm if last else None
-            pf_next = pf("p", self.w_head, self.V, D) if last else pf("p", self.layers[i + 1]["w_qkv"], 3 * D, D)
             if tail:
                 nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS, x_packed=pa,
                                 tail=self._tail(2 * i, h, xn, l["b_o"], l["ln2"]))
@@ -448,14 +437,13 @@ class GPTEngine:
                 # reduce launch adds (x A) B^T
                 sl_o = self.slab.view(-1)[: KS * B * n_o].view(KS, B, n_o)
                 nat.gemm_skinny(T, B, n_o, D, w_o, None, x=self.a, epi=nat.EPI_SLAB_F32, yf=sl_o, ksplit=KS,
-                                x_packed=pa, pf=pf("o", l["w_fc"], 4 * D, D))
+                                x_packed=pa)
                 nat.ln_reduce(h, l["ln2"][0], l["ln2"][1], xn, slab=sl_o, nslab=KS, bias=l["b_o"], y_packed=pa,
                               slab_stride=n_o, lora_b=l.get("lora_b_o"))
-                nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f, x_packed=pa, y_packed=pa,
-                                pf=pf("f", w_pr, n_p, 4 * D, KS))
+                nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f, x_packed=pa, y_packed=pa)
                 sl_p = self.slab.view(-1)[: KS * B * n_p].view(KS, B, n_p)
                 nat.gemm_skinny(T, B, n_p, 4 * D, w_pr, None, x=self.f, epi=nat.EPI_SLAB_F32, yf=sl_p, ksplit=KS,
-                                x_packed=pa, pf=pf_next)
+                                x_packed=pa)
                 if last:
                     nat.ln_reduce(h, nxt[0], nxt[1], xn, slab=sl_p, nslab=KS, bias=l["b_pr"], w2=nxt2[0], b2=nxt2[1], y_packed=pa,
                                   slab_stride=n_p, lora_b=l.get("lora_b_pr"))

@@ -154,24 +154,6 @@ def test_finished_rows_left_out_of_attention_change_nothing_else(gpt_small_fp32)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_l2_run_ahead_changes_no_bit(dtype):
-    """itts_prefetch (the decode GEMMs touch a later GEMM's weight bytes): any schedule gives the same logits and codes as
-    none, graph replay and eager launches alike -- the touched values are never used."""
-    m = make_gpt(2, dtype)
-    g = np.load(os.path.join(G, "gpt_small.npz"))
-    cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
-    text = torch.from_numpy(g["text"]).to(DEV)
-    kw = dict(do_sample=False, num_beams=1, repetition_penalty=10.0, max_generate_length=12, return_logits=True)
-    outs = []
-    for pf in ("", "qofp", "f", "op"):
-        m.engine.prefetch = pf
-        m.engine._graphs.clear()
-        outs.append(m.inference_speech(cond_mel, text, **kw))
-    for c, l in outs[1:]:
-        assert torch.equal(c, outs[0][0]) and torch.equal(l, outs[0][1])
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_latent_pass_reuses_the_cached_prompt(dtype):
     """GPTEngine.latent_mel_rows (only the mel rows recomputed, the prompt's keys / values taken from the KV cache the decode
     loop leaves behind) against the full teacher-forced pass over cond | text | mel: the SAME bits, for a left-padded batch of

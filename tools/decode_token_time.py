@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Microseconds per decode token of the GPT engine alone (BASELINE config 3 shape: 24 layers, bf16, 32 rows, ~72-position
-prompt, 140 tokens, graph replay) for a list of ITTS_PREFETCH settings / decode modes.  Appends to gpurun_out/token_time.txt.
-usage: decode_token_time.py [setting ...]   e.g.  "" ofp qofp     (a setting is the ITTS_PREFETCH letter string)"""
+prompt, 140 tokens, graph replay).  Appends to gpurun_out/token_time.txt.
+usage: decode_token_time.py [label ...]   (labels only tag the output lines; engine knobs come from the environment, e.g.
+ITTS_KSPLIT, ITTS_DECODE_MODE; ITTS_TOKENS shortens the run)"""
 import os
 import sys
 import time
@@ -15,8 +16,8 @@ import weights  # noqa: E402
 from indextts.gpt.engine import GPTEngine  # noqa: E402
 
 torch.set_grad_enabled(False)
-settings = sys.argv[1:] or ["", "ofp"]
-B, P, NEW = 32, 72, 140
+settings = sys.argv[1:] or ["default"]
+B, P, NEW = 32, 72, int(os.environ.get("ITTS_TOKENS", "140"))
 gsd = weights.gpt_state_dict(24)
 eng = GPTEngine(gsd, 24, 1280, 20, dtype=torch.bfloat16, device="cuda")
 g = torch.Generator().manual_seed(1)
@@ -28,7 +29,6 @@ out = open(os.path.join(ROOT, "gpurun_out", "token_time.txt"), "a")
 ref = None
 for rep in range(2):
     for st in settings:
-        eng.prefetch = st
         eng._graphs.clear()
         eng.prefill(prefix, pad, NEW + 2)
         codes = eng.decode(NEW, sp, force_stop=[NEW - 1] * B)   # warm-up + capture
@@ -41,7 +41,7 @@ for rep in range(2):
         if ref is None:
             ref = codes.clone()
         same = bool((codes == ref).all())
-        line = f"prefetch={st!r:8s} {us:8.1f} us/token  codes_equal_to_first={same}"
+        line = f"{st:10s} {us:8.1f} us/token  codes_equal_to_first={same}"
         print(line, flush=True)
         out.write(line + "\n")
         out.flush()

@@ -36,6 +36,6 @@ for k in range(n + 2):
     tts.infer_batch(cond_mel, texts, max_mel_tokens=max(stops) + 1, force_stop=stops, seed=100 + k, phase_events=pe, **gen)
     torch.cuda.synchronize()
     ph = {f"{a}->{b}": round(pe[a].elapsed_time(pe[b]), 2) for a, b in zip(names[:-1], names[1:])}
-    line = f"prefetch={os.environ.get('ITTS_PREFETCH', 'default')!r} step {k}: {ph}"
+    line = f"step {k}: {ph}"
     print(line, flush=True)
     out.write(line + "\n")
