@@ -497,9 +497,13 @@ class GPTEngine:
         nbytes += self.V * D * es + B * D * es + B * self.V * 4
         return n + 1, nbytes
 
-    def decode(self, max_new: int, sp: dict, force_stop=None, use_graph=True, check_every=16, return_logits=False):
+    def decode(self, max_new: int, sp: dict, force_stop=None, use_graph=True, check_every=16, return_logits=False,
+               logits_hook=None):
         """Run the sampling loop after prefill().  Returns codes int64 [B, n] padded with the stop token
-        (HF generate semantics: rows that emitted EOS keep emitting pad = EOS)."""
+        (HF generate semantics: rows that emitted EOS keep emitting pad = EOS).
+        logits_hook(logits fp32 [B, V] (modified in place), history int32 [B, k] of the tokens generated so far): an extra
+        logits processor run on the device in front of the sampling kernel at every step (typical sampling); the loop then
+        launches eagerly, one host call per step."""
         B = self._B
         if self._shared_prefix is not None:
             raise ValueError("decode(): prefill(beams=n) cached the prompt once per batch element; only decode_beam() can follow it")
@@ -511,11 +515,21 @@ class GPTEngine:
             self.force_stop[:B] = torch.as_tensor(force_stop, dtype=torch.int32).to(self.device)
         logits_trace = [self.logits[:B].clone()] if return_logits else None
         sp = self._seed_to_state(sp)
+        if logits_hook is not None:
+            use_graph = False
+            logits_hook(self.logits[:B], self.history[:B, :0])
         self._sample(B, sp)  # token 1 from the prefill logits
         n = 1
         G = 1 if return_logits else self.steps_per_graph
         while n < max_new:
-            if use_graph and not self.force_eager and n >= 2:
+            if logits_hook is not None:
+                k = 1
+                self._step_transformer(B)
+                if return_logits:
+                    logits_trace.append(self.logits[:B].clone())      # the trace holds what the model produced, not the hook's edit
+                logits_hook(self.logits[:B], self.history[:B, :n])
+                self._sample(B, sp)
+            elif use_graph and not self.force_eager and n >= 2:
                 k = G if n + G <= max_new else 1          # several tokens per replay while they fit
                 self._get_graph(B, sp, k).replay()
             else:
@@ -523,7 +537,7 @@ class GPTEngine:
                 self._step_kernels(B, sp)                 # eager: first step doubles as the warm-up before capture
             prev = n
             n += k
-            if return_logits:
+            if return_logits and logits_hook is None:
                 logits_trace.append(self.logits[:B].clone())
             if n // check_every != prev // check_every and self._poll() >= B:
                 break

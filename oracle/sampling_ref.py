@@ -59,6 +59,29 @@ def top_p(scores, p, min_keep=1):
     return out
 
 
+def typical(scores, mass=0.9, min_keep=1):
+    """TypicalLogitsWarper (transformers 4.44.2 logits_process.py; reached from indextts/gpt/model.py:704-708 when
+    typical_sampling=True): keep the tokens whose surprisal is closest to the entropy of the distribution until their
+    probability mass exceeds `mass`."""
+    out = scores.astype(np.float32).copy()
+    for b in range(scores.shape[0]):
+        x = out[b].astype(np.float64)
+        m = np.max(x)
+        lse = m + np.log(np.sum(np.exp(x - m)))
+        logp = (x - lse).astype(np.float32)
+        p_ = np.exp(logp)
+        ent = -np.nansum(logp * p_, dtype=np.float32)
+        shifted = np.abs(-logp - ent)
+        order = np.argsort(shifted, kind="stable")               # ascending
+        sl = out[b][order]
+        cum = np.cumsum(_softmax(sl[None])[0], dtype=np.float32)
+        last = min(int(np.sum(cum < np.float32(mass))), scores.shape[1] - 1)
+        remove_sorted = shifted[order] > shifted[order][last]
+        remove_sorted[:min_keep] = False
+        out[b, order[remove_sorted]] = NEG_INF
+    return out
+
+
 def process(scores, history, rep_pen=10.0, temp=1.0, k=30, p=0.8):
     s = repetition_penalty(scores, history, rep_pen) if rep_pen != 1.0 else scores.astype(np.float32)
     if temp != 1.0:

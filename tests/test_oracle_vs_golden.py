@@ -86,6 +86,20 @@ def test_sampling_processors():
     np.testing.assert_array_equal(s[np.isfinite(s)], g["after_topp"][np.isfinite(g["after_topp"])])
 
 
+def test_typical_warper_matches_transformers():
+    """oracle/sampling_ref.typical against the installed transformers' TypicalLogitsWarper (the class model.py:704-708 puts in
+    the processor list) on peaked and flat rows: the same tokens survive."""
+    transformers = pytest.importorskip("transformers")
+    from transformers.generation.logits_process import TypicalLogitsWarper
+    rng = np.random.default_rng(5)
+    for scale, mass, keep in ((1.0, 0.9, 1), (4.0, 0.9, 1), (0.3, 0.5, 2), (8.0, 0.95, 2)):
+        x = (rng.standard_normal((6, 257)) * scale).astype(np.float32)
+        want = TypicalLogitsWarper(mass=mass, min_tokens_to_keep=keep)(None, torch.from_numpy(x.copy())).numpy()
+        got = sampling_ref.typical(x, mass, keep)
+        np.testing.assert_array_equal(np.isfinite(got), np.isfinite(want))
+        np.testing.assert_array_equal(got[np.isfinite(got)], want[np.isfinite(want)])
+
+
 def test_philox_known_answer():
     # Random123 known-answer vectors for philox4x32-10
     assert [int(x) for x in sampling_ref.philox4x32((0, 0, 0, 0), (0, 0))] == \
