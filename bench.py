@@ -325,7 +325,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true", help="skip the `accuracy` object (benched precision vs this build's fp32 engines)")
     ap.add_argument("--no-beam", action="store_true", help="skip the extra beam-sample (32 x 3 rows) token-time measurement")
-    ap.add_argument("--inflight", type=int, default=2, help="batches in flight for --schedule concurrent")
+    ap.add_argument("--inflight", type=int, default=4, help="batches in flight for --schedule concurrent")
     ap.add_argument("--no-concurrency", action="store_true",
                     help="skip the extra (reported, never `value`) measurement with two batch-32 requests in flight")
     ap.add_argument("--schedule", choices=["pipelined", "serial", "concurrent"], default="serial",
@@ -588,6 +588,7 @@ def main():
         dtc = time.perf_counter() - tc
         result["concurrent_requests"] = {"inflight": len(pl.instances), "steps": nrun, "value": round(audio_s_step * nrun / dtc, 2),
                                          "unit": "audio-seconds/sec", "ms_per_step": round(1e3 * dtc / nrun, 3),
+                                         "streams": "ordinary (CU-masked streams measured slower: profiles/r03_pool_cu_masks.txt)",
                                          "note": "serving concurrency (indextts.infer.RequestPool): independent batch-32 requests "
                                                  "overlap; `value` above is one request at a time"}
         pl.close()

@@ -760,6 +760,29 @@ class BatchPipeline:
         self._thread.join()
 
 
+def stream_with_cu_mask(device, words):
+    """A HIP stream restricted to the compute units whose bits are set in `words` (uint32 list, bit i of word w = CU 32*w + i),
+    wrapped for torch.  Created through the HIP runtime this process has already loaded (the one torch and the kernel library
+    launch through)."""
+    import ctypes
+    path = None
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64.so" in line:
+                path = line.split()[-1]
+                break
+    if path is None:
+        raise RuntimeError("stream_with_cu_mask: the HIP runtime is not loaded in this process")
+    hip = ctypes.CDLL(path)
+    handle = ctypes.c_void_p()
+    arr = (ctypes.c_uint32 * len(words))(*[int(w) & 0xFFFFFFFF for w in words])
+    torch.cuda.set_device(device)
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(len(words)), arr)
+    if rc != 0 or not handle.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed (error {rc})")
+    return torch.cuda.ExternalStream(handle.value, device=device)
+
+
 class RequestPool:
     """Serving concurrency (not in the reference API): several independent utterance batches in flight on one GPU, each on
     its own IndexTTS instance, host thread and HIP stream.  A single request's token loop is a chain of ~170 dependent
@@ -779,12 +802,17 @@ class RequestPool:
             return self.out
 
     @classmethod
-    def of(cls, tts: "IndexTTS", inflight: int = 2) -> "RequestPool":
-        return cls([tts] + [tts.replica() for _ in range(max(1, inflight) - 1)])
+    def of(cls, tts: "IndexTTS", inflight: int = 2, cu_masks=None) -> "RequestPool":
+        return cls([tts] + [tts.replica() for _ in range(max(1, inflight) - 1)], cu_masks=cu_masks)
 
-    def __init__(self, instances: List["IndexTTS"]):
+    def __init__(self, instances: List["IndexTTS"], cu_masks=None):
+        """cu_masks: optional, one entry per instance: None (an ordinary stream) or a list of uint32 words, bit i = compute
+        unit i may run this instance's work (hipExtStreamCreateWithCUMask).  Measured on MI355X (tools/pool_cu_masks.py,
+        profiles/): partitioning the CUs between two requests is SLOWER than letting the dispatcher interleave them."""
         assert instances, "need at least one instance"
+        assert cu_masks is None or len(cu_masks) == len(instances), "one CU mask (or None) per instance"
         self.instances = list(instances)
+        self._cu_masks = list(cu_masks) if cu_masks is not None else [None] * len(instances)
         self._queues = [queue.Queue() for _ in self.instances]
         self._threads = [threading.Thread(target=self._run, args=(i,), name=f"itts-request-{i}", daemon=True)
                          for i in range(len(self.instances))]
@@ -795,7 +823,10 @@ class RequestPool:
     def _run(self, i):
         inst, q = self.instances[i], self._queues[i]
         torch.cuda.set_device(inst.device)
-        stream = torch.cuda.Stream(device=inst.device)
+        if self._cu_masks[i] is None:
+            stream = torch.cuda.Stream(device=inst.device)
+        else:
+            stream = stream_with_cu_mask(inst.device, self._cu_masks[i])
         while True:
             item = q.get()
             if item is None:
