@@ -48,7 +48,7 @@ extern "C" {
 #define ITTS_BF16 1
 #define ITTS_F16 2
 
-#define ITTS_ABI_VERSION 5 /* 5: same struct layouts as 4; itts_ln_reduce takes up to 6 slabs (4: <= 4) */
+#define ITTS_ABI_VERSION 6 /* 6: per-row clocks (row_step0) in itts_embed_step / itts_sample_args: slot refill; 5: itts_ln_reduce takes up to 6 slabs */
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -220,10 +220,12 @@ typedef struct itts_ln_reduce_args {
 } itts_ln_reduce_args;
 int itts_ln_reduce(const itts_ln_reduce_args* a, void* stream);
 
-/* h[b][:] = table[tokens[b]][:] + pos_table[*step + pos_add][:]   (fp32 tables, fp32 h).  If epoch != NULL, *epoch is
- * incremented once (the first launch of a decode step advances the epoch of that step's reducer tails). */
+/* h[b][:] = table[tokens[b]][:] + pos_table[*step - row_step0[b] + pos_add][:]   (fp32 tables, fp32 h).  If epoch != NULL,
+ * *epoch is incremented once (the first launch of a decode step advances the epoch of that step's reducer tails).
+ * row_step0 (int32 [B] on the device or NULL = zeros): the loop step at which row b started decoding -- a decode slot that
+ * was refilled with a new utterance in the middle of the loop counts its mel positions from its own first token. */
 int itts_embed_step(const int32_t* tokens, const float* table, const float* pos_table, const int32_t* step, int pos_add,
-                    float* h, int B, int D, int32_t* epoch, void* stream);
+                    float* h, int B, int D, int32_t* epoch, const int32_t* row_step0, void* stream);
 
 /* Single-query attention over the KV cache (decode).  q,out: T [B][H*64]; caches T [B][H][smax][64];
  * keys j in [pad[b], *pos] are visible (the key at *pos was just appended).  scale 1/8.  out_packed != 0: out is written in
@@ -278,6 +280,9 @@ typedef struct itts_sample_args {
   int no_advance;    /* != 0: leave state[0] / state[1] alone -- the caller advances them in the next step's first
                         itts_ln_reduce launch (state_bump), which removes a device-wide fence and a returning atomic
                         per row from this kernel; itts_embed_step is then given pos_add + 1 */
+  const int32_t* row_step0; /* [B] or NULL (= zeros): loop step at which row b started (slot refill).  Row b's own step
+                        k_b = state[0] - row_step0[b] indexes its history, bounds its repetition-penalty window and is what
+                        force_stop[b] is compared with; the Philox counter stays (b, state[0]). */
 } itts_sample_args;
 int itts_sample(const itts_sample_args* a, void* stream);
 

@@ -395,11 +395,14 @@ static int launch_ln_reduce(const itts_ln_reduce_args& a, hipStream_t s) {
 __global__ __launch_bounds__(256) void embed_step_kernel(const int32_t* __restrict__ tokens, const float* __restrict__ table,
                                                           const float* __restrict__ pos_table,
                                                           const int32_t* __restrict__ step, int pos_add,
-                                                          float* __restrict__ h, int D, int32_t* __restrict__ epoch) {
+                                                          float* __restrict__ h, int D, int32_t* __restrict__ epoch,
+                                                          const int32_t* __restrict__ row_step0) {
   int b = blockIdx.x;
   if (epoch != nullptr && b == 0 && threadIdx.x == 0) epoch[0] = epoch[0] + 1;  // read by LATER launches of this step only
   int tok = tokens[b];
-  int p = step[0] + pos_add;
+  const int32_t* s0p = row_step0 != nullptr ? row_step0 + b : step;   // a readable word either way (no branch around the load)
+  const int s0 = row_step0 != nullptr ? *s0p : 0;
+  int p = step[0] - s0 + pos_add;
   const float* e = table + (int64_t)tok * D;
   const float* pe = pos_table + (int64_t)p * D;
   for (int i = threadIdx.x; i < D; i += 256) h[(int64_t)b * D + i] = e[i] + pe[i];
@@ -539,10 +542,10 @@ extern "C" int itts_ln_reduce(const itts_ln_reduce_args* a, void* stream) {
 }
 
 extern "C" int itts_embed_step(const int32_t* tokens, const float* table, const float* pos_table, const int32_t* step,
-                               int pos_add, float* h, int B, int D, int32_t* epoch, void* stream) {
+                               int pos_add, float* h, int B, int D, int32_t* epoch, const int32_t* row_step0, void* stream) {
   ITTS_REQUIRE(tokens && table && pos_table && step && h && B > 0 && D > 0, "itts_embed_step: bad arguments");
   hipLaunchKernelGGL(embed_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, tokens, table, pos_table, step, pos_add, h, D,
-                     epoch);
+                     epoch, row_step0);
   return check_launch("itts_embed_step");
 }
 

@@ -26,6 +26,7 @@ struct SampleParams {
   int stop_token;
   float* dbg_scores;
   int advance;
+  const int32_t* row_step0;
 #if ITTS_STAMPS
   unsigned long long* stamps;
 #endif
@@ -67,7 +68,8 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
   __shared__ uint32_t sh_prefix;
 
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int k = p.state[0];
+  const int kg = p.state[0];                                                  // loop step: the Philox counter
+  const int k = kg - (p.row_step0 != nullptr ? p.row_step0[b] : 0);           // the ROW's step (a refilled slot starts at 0)
   const int V = p.V;
   const float* lg = p.logits + (int64_t)b * p.ldl;
 #if ITTS_STAMPS
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
     if (tid == 64) {
       // key = launch argument + the 64-bit seed held in state[4..5] (lets a captured launch serve every seed)
       const uint64_t key = (((uint64_t)p.seed_hi << 32) | p.seed_lo) + (((uint64_t)(uint32_t)p.state[5] << 32) | (uint32_t)p.state[4]);
-      uint32_t x = philox_first((uint32_t)b, (uint32_t)k, 0u, 0u, (uint32_t)key, (uint32_t)(key >> 32));
+      uint32_t x = philox_first((uint32_t)b, (uint32_t)kg, 0u, 0u, (uint32_t)key, (uint32_t)(key >> 32));
       rv[0] = (float)(x >> 8) * (1.0f / 16777216.0f);
     }
     __syncthreads();
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
       int done = atomicAdd(&p.state[3], 1);
       if (done == p.B - 1) {
         p.state[3] = 0;
-        p.state[0] = k + 1;
+        p.state[0] = kg + 1;
         p.state[1] = p.state[1] + 1;
       }
     }
@@ -402,6 +404,7 @@ extern "C" int itts_sample(const itts_sample_args* a, void* stream) {
   p.stop_token = a->stop_token;
   p.dbg_scores = a->dbg_scores;
   p.advance = a->no_advance ? 0 : 1;
+  p.row_step0 = a->row_step0;
 #if ITTS_STAMPS
   p.stamps = itts::g_stamp_buf_sample;
 #endif

@@ -56,7 +56,7 @@ class SampleArgs(C.Structure):
                 ("extra_ids", C.c_void_p), ("n_extra", C.c_int), ("force_stop", C.c_void_p),
                 ("rep_penalty", C.c_float), ("temperature", C.c_float), ("top_p", C.c_float), ("top_k", C.c_int),
                 ("do_sample", C.c_int), ("seed", C.c_uint64), ("stop_token", C.c_int), ("dbg_scores", C.c_void_p),
-                ("no_advance", C.c_int)]
+                ("no_advance", C.c_int), ("row_step0", C.c_void_p)]
 
 
 class BeamArgs(C.Structure):
@@ -87,7 +87,7 @@ _SIGNATURES = {
                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_ln_reduce": (C.c_int, [C.POINTER(LnReduceArgs), C.c_void_p]),
     "itts_embed_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
-                                  C.c_int, C.c_void_p, C.c_void_p]),
+                                  C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "itts_attn_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "itts_attn_prefill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -119,7 +119,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.itts_abi_version() != 5:
+        if L.itts_abi_version() != 6:
             raise NativeError("libindextts_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -299,11 +299,12 @@ def ln_reduce(h, w, b, out, slab=None, nslab=0, bias=None, w2=None, b2=None, sta
     return out
 
 
-def embed_step(tokens, table, pos_table, step, pos_add, h, epoch=None):
-    """epoch (int32 device word or None) is incremented once: the reducer tails of this decode step expect it."""
+def embed_step(tokens, table, pos_table, step, pos_add, h, epoch=None, row_step0=None):
+    """epoch (int32 device word or None) is incremented once: the reducer tails of this decode step expect it.
+    row_step0 (int32 [B] or None): the loop step at which each row started (slot refill)."""
     B, D = h.shape
-    _check(lib().itts_embed_step(_p(tokens), _p(table), _p(pos_table), _p(step), pos_add, _p(h), B, D, _p(epoch), _stream()),
-           "itts_embed_step")
+    _check(lib().itts_embed_step(_p(tokens), _p(table), _p(pos_table), _p(step), pos_add, _p(h), B, D, _p(epoch), _p(row_step0),
+                                 _stream()), "itts_embed_step")
 
 
 def attn_decode(q, kcache, vcache, out, pad, pos, B, H, smax, out_packed=False, kv_rows=None, kv_step=None, skip_rows=None):
@@ -325,7 +326,7 @@ def attn_prefill_packed(qkv, out, kcache, vcache, row_off, cache_shift, B, Smax,
 
 
 def sample(logits, tokens, history, finished, state, extra_ids, force_stop, rep_penalty, temperature, top_k, top_p,
-           do_sample, seed, stop_token, dbg_scores=None, no_advance=False):
+           do_sample, seed, stop_token, dbg_scores=None, no_advance=False, row_step0=None):
     a = SampleArgs()
     B, V = logits.shape
     a.logits, a.B, a.V, a.ldl = _p(logits), B, V, logits.stride(0)
@@ -337,6 +338,7 @@ def sample(logits, tokens, history, finished, state, extra_ids, force_stop, rep_
     a.top_k, a.do_sample, a.seed, a.stop_token = int(top_k), int(bool(do_sample)), int(seed), int(stop_token)
     a.dbg_scores = _p(dbg_scores)
     a.no_advance = int(bool(no_advance))
+    a.row_step0 = _p(row_step0)
     _check(lib().itts_sample(C.byref(a), _stream()), "itts_sample")
 
 

@@ -188,8 +188,8 @@ class GPTEngine:
         B = max(B, self._cap_b)
         smax = max(smax, self._cap_s)
         smax = (smax + 63) // 64 * 64
-        if smax > 2048:
-            raise ValueError(f"context {smax} exceeds the decode-attention limit of 2048")
+        if smax > 16384:
+            raise ValueError(f"context {smax} exceeds the decode-attention limit of 16384 cache positions")
         dev, T = self.device, self.dtype
         self.kc = torch.zeros(self.L, B, self.H, smax, 64, dtype=T, device=dev)
         self.vc = torch.zeros(self.L, B, self.H, smax, 64, dtype=T, device=dev)
@@ -205,6 +205,7 @@ class GPTEngine:
         self.finished = torch.zeros(B, dtype=torch.int32, device=dev)
         self.pad = torch.zeros(B, dtype=torch.int32, device=dev)
         self.force_stop = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        self.row_step0 = torch.zeros(B, dtype=torch.int32, device=dev)   # loop step at which each row started (decode_refill)
         self.state = torch.zeros(8, dtype=torch.int32, device=dev)
         self.history = torch.zeros(B, 2048, dtype=torch.int32, device=dev)
         self._cap_b, self._cap_s = B, smax
@@ -279,6 +280,7 @@ class GPTEngine:
         self.state[1] = S - 1
         self._pending_bump = False
         self.finished[:B] = 0
+        self.row_step0.zero_()
         self.history[:B].zero_()
         self._B, self._S = B, S
         self._shared_prefix = None
@@ -384,7 +386,7 @@ class GPTEngine:
         device-wide fence and a returning atomic per row out of the sampling kernel."""
         nat.sample(self.logits[:B], self.tokens, self.history, self.finished, self.state, self.extra_ids, self.force_stop,
                    sp["repetition_penalty"], sp["temperature"], sp["top_k"], sp["top_p"], sp["do_sample"], sp["seed"],
-                   self.stop_mel, dbg, no_advance=True)
+                   self.stop_mel, dbg, no_advance=True, row_step0=self.row_step0)
         self._pending_bump = True
 
     def _tail(self, site, h, xn, bias, ln, ln2=None):
@@ -410,7 +412,8 @@ class GPTEngine:
             bump = getattr(self, "_pending_bump", False)
         self._pending_bump = False
         # mel position of token k is k + 1 (model.py:163-167); with a pending bump state[0] still holds k - 1
-        nat.embed_step(self.tokens, self.mel_emb, self.mel_pos, step, 2 if bump else 1, h, epoch=self.state[6:7])
+        nat.embed_step(self.tokens, self.mel_emb, self.mel_pos, step, 2 if bump else 1, h, epoch=self.state[6:7],
+                       row_step0=self.row_step0 if self._kv_rows is None else None)
         nat.ln_reduce(h, self.layers[0]["ln1"][0], self.layers[0]["ln1"][1], xn, state_bump=self.state[0:2] if bump else None,
                       y_packed=pa)
         for i, l in enumerate(self.layers):
@@ -544,6 +547,152 @@ class GPTEngine:
         self._poll()
         codes = self.history[:B, :n].to(torch.int64)
         return (codes, torch.stack(logits_trace, 0)) if return_logits else codes
+
+    # ------------------------------------------------------------------------------------------------ slot refill
+    def _refill(self, rows, prefixes, stops, n):
+        """Put new utterances into the decode slots `rows` between two steps of a running loop in which every row has been
+        given n tokens' worth of steps (state[0] = n - 1 with the bump pending, the next step writes cache position S+n-1).
+        prefixes: fp32 [P_j, D] each (cond | text, no padding).  A new row is laid out exactly like an initial row of a batch
+        whose loop started n - 1 steps later: prompt + start token at cache positions [pad, S+n-2] of its slot, left padding
+        pad = S+n-1-(P_j+1), its clock row_step0 = n - 1 (mel positions, history index, stop step and repetition-penalty
+        window count from its own first token), its first token sampled here from its prefill logits."""
+        import numpy as np
+        T, D, H, dev = self.dtype, self.D, self.H, self.device
+        k = len(rows)
+        end = self._S + n - 1                              # one past the last prompt position
+        lens = [int(p.shape[0]) + 1 for p in prefixes]
+        if max(lens) > end:
+            raise ValueError("_refill(): a new prompt is longer than the positions the loop has passed")
+        pads = [end - L for L in lens]
+        start = (self.mel_emb[self.start_mel] + self.mel_pos[0])[None]
+        h = torch.cat([t for p in prefixes for t in (p.to(dev, torch.float32), start)], dim=0).contiguous()
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        M = int(off[-1])
+        slot = np.concatenate([np.full(L, r) for L, r in zip(lens, rows)])
+        posi = np.concatenate([pd + np.arange(L) for L, pd in zip(lens, pads)])
+        meta = torch.from_numpy(np.concatenate([slot, posi, off, off[1:] - 1, np.asarray(rows), np.asarray(pads),
+                                                np.asarray(stops)]).astype(np.int64)).to(dev)     # one upload
+        i_b, i_p = meta[:M], meta[M:2 * M]
+        row_off = meta[2 * M:2 * M + k + 1].to(torch.int32)
+        last = meta[2 * M + k + 1:2 * M + 2 * k + 1]
+        i_rows = meta[2 * M + 2 * k + 1:2 * M + 3 * k + 1]
+        pads_d = meta[2 * M + 3 * k + 1:2 * M + 4 * k + 1].to(torch.int32)
+        stops_d = meta[2 * M + 4 * k + 1:].to(torch.int32)
+        xn = torch.empty(M, D, dtype=T, device=dev)
+        qkv = torch.empty(M, 3, H, 64, dtype=T, device=dev)
+        att = torch.empty(M, D, dtype=T, device=dev)
+        ff = torch.empty(M, 4 * D, dtype=T, device=dev)
+        Smax = max(lens)
+        for i, l in enumerate(self.layers):
+            nat.layernorm(h, l["ln1"][0], l["ln1"][1], xn)
+            nat.gemm_conv(T, 1, M, M, D, 3 * D, l["w_qkv"], xn, qkv.view(M, 3 * D), bias=l["b_qkv"])
+            self.kc[i][i_b, :, i_p] = qkv[:, 1]            # the slots' cache rows, positions [pad, S+n-2]
+            self.vc[i][i_b, :, i_p] = qkv[:, 2]
+            nat.attn_prefill_packed(qkv.view(M, 3 * D), att, None, None, row_off, None, k, Smax, H, self._cap_s)
+            nat.gemm_conv(T, 1, M, M, D, D, l.get("w_o_merged", l["w_o"]), att, h, bias=l["b_o"], y_f32=True, resid=h)
+            nat.layernorm(h, l["ln2"][0], l["ln2"][1], xn)
+            nat.gemm_conv(T, 1, M, M, D, 4 * D, l["w_fc"], xn, ff, bias=l["b_fc"], act=1)
+            nat.gemm_conv(T, 1, M, M, 4 * D, D, l.get("w_pr_merged", l["w_pr"]), ff, h, bias=l["b_pr"], y_f32=True, resid=h)
+        # head + first token of the new rows on buffers of their own (the running rows' logits / packed activations stay)
+        kp = nat.packed_rows(k)
+        xn_t = torch.zeros(kp, D, dtype=T, device=dev)
+        lg_t = torch.empty(k, self.V, dtype=torch.float32, device=dev)
+        nat.ln_reduce(h[last].contiguous(), self.ln_f[0], self.ln_f[1], xn_t, w2=self.final_norm[0], b2=self.final_norm[1],
+                      y_packed=self.pa)
+        nat.gemm_skinny(T, k, self.V, D, self.w_head, self.b_head, x=xn_t, epi=nat.EPI_STORE_F32, yf=lg_t, x_packed=self.pa)
+        tok_t = torch.zeros(k, dtype=torch.int32, device=dev)
+        hist_t = torch.zeros(k, 8, dtype=torch.int32, device=dev)
+        fin_t = torch.zeros(k, dtype=torch.int32, device=dev)
+        step0_t = torch.full((k,), n - 1, dtype=torch.int32, device=dev)
+        sp = self._refill_sp
+        self.state[2:3] -= k                               # these slots were counted as finished
+        nat.sample(lg_t, tok_t, hist_t, fin_t, self.state, self.extra_ids, stops_d, sp["repetition_penalty"], sp["temperature"],
+                   sp["top_k"], sp["top_p"], sp["do_sample"], sp["seed"], self.stop_mel, None, no_advance=True, row_step0=step0_t)
+        self.tokens[i_rows] = tok_t
+        self.history[i_rows, 0] = tok_t
+        self.finished[i_rows] = fin_t
+        self.force_stop[i_rows] = stops_d
+        self.row_step0[i_rows] = step0_t
+        self.pad[i_rows] = pads_d
+
+    def decode_refill(self, max_new: int, sp: dict, feed, force_stop=None, use_graph=True, check_every=16, positions=None):
+        """Continuous batching: the sampling loop after prefill(), with every slot whose row has emitted its stop token
+        refilled from a queue (the mitigation for mixed output lengths).  num_beams = 1 only.
+        feed(k) -> up to k items (prefix_emb fp32 [P, D] = cond | text without padding, stop step or -1); fewer than k means
+        the queue is empty.  Rows are numbered in the order they entered: 0..B-1 = the prefilled batch, then the fed ones.
+        max_new bounds every row's own length (a row that reaches it is stopped there).  Returns (codes, leftover): codes[id]
+        int64 [n_id] ends with the stop token; leftover = items that were fed but could not be placed any more because the
+        cache positions reserved by prefill() -- or the smaller budget `positions` -- ran out (the caller starts a new loop
+        with them).
+        A row's tokens are those it would get decoded alone with the same logits (greedy: identical codes up to the usual
+        reduction-order noise of a different left padding); sampled rows draw from the loop's Philox stream (row slot, loop
+        step), so they differ from a stand-alone run as two seeds do."""
+        B, S = self._B, self._S
+        if self._shared_prefix is not None or self._kv_rows is not None:
+            raise ValueError("decode_refill(): num_beams = 1 only")
+        limit = self._cap_s if positions is None else min(self._cap_s, int(positions))
+        if S + max_new + 1 > limit:
+            raise ValueError("decode_refill(): the position budget does not hold one utterance of max_new tokens")
+        dev = self.device
+        fs = [-1] * B if force_stop is None else [int(v) for v in force_stop]
+        fs = [max_new - 1 if v < 0 else min(v, max_new - 1) for v in fs]
+        self.force_stop[:B] = torch.tensor(fs, dtype=torch.int32).to(dev)
+        sp = self._seed_to_state(sp)
+        self._refill_sp = sp
+        owner, start = list(range(B)), [0] * B
+        next_id, codes, leftover, fed_out = B, {}, [], False
+        stats = self.refill_stats = {"steps": 0, "polls": 0, "refill_calls": 0, "rows_refilled": 0}
+        self._sample(B, sp)
+        n = 1
+        stop_id = self.stop_mel
+        while True:
+            # ---- up to check_every steps
+            todo = check_every
+            while todo > 0:
+                if S + n + 1 > self._cap_s:
+                    raise ValueError("decode_refill(): the cache positions reserved by prefill() are used up")   # (cannot happen)
+                G = self.steps_per_graph
+                if use_graph and not self.force_eager and n >= 2:
+                    kk = G if G <= todo else 1
+                    self._get_graph(B, sp, kk).replay()
+                else:
+                    kk = 1
+                    self._step_kernels(B, sp)
+                n += kk
+                todo -= kk
+            # ---- one host synchronisation: which rows have stopped
+            stats["steps"], stats["polls"] = n, stats["polls"] + 1
+            self._poll()
+            fin = self.finished[:B].tolist()
+            newly = [r for r in range(B) if fin[r] and owner[r] is not None]
+            if newly:
+                width = max(n - start[r] for r in newly)
+                hist = self.history[torch.tensor(newly, device=dev), :width].cpu()
+                for j, r in enumerate(newly):
+                    row = hist[j, : n - start[r]].to(torch.int64)
+                    hit = (row == stop_id).nonzero()
+                    codes[owner[r]] = row[: int(hit[0]) + 1] if hit.numel() else row
+                    owner[r] = None
+            free = [r for r in range(B) if owner[r] is None]
+            if free and not fed_out:
+                items = list(feed(len(free)))
+                if len(items) < len(free):
+                    fed_out = True
+                room = limit - (S + n + 1)                 # steps the loop can still take
+                if items and room < max_new + check_every:
+                    leftover, items, fed_out = items, [], True
+                if items:
+                    rows = free[: len(items)]
+                    stops = [max_new - 1 if int(st) < 0 else min(int(st), max_new - 1) for _, st in items]
+                    self._refill(rows, [p for p, _ in items], stops, n)
+                    stats["refill_calls"] += 1
+                    stats["rows_refilled"] += len(rows)
+                    for r in rows:
+                        owner[r], start[r] = next_id, n - 1
+                        next_id += 1
+            if fed_out and all(o is None for o in owner):
+                break
+        return [codes[i] for i in range(next_id)], leftover
 
     # ------------------------------------------------------------------------------------------------ beam search
     def _ensure_beam(self, B: int, nb: int):

@@ -602,6 +602,88 @@ class IndexTTS:
         outs = self._batch_waveforms(st, phase_events, reuse_prefix=True)   # serial: the KV cache still holds this batch's prompt
         return (outs, st["rows"]) if return_codes else outs
 
+    def infer_queue(self, cond_mel: torch.Tensor, text_token_rows: List[torch.Tensor], slots=32, max_mel_tokens=600,
+                    force_stop=None, seed=1234, return_codes=False, cache_positions=4096, phase_events: dict | None = None,
+                    **generation_kwargs):
+        """Continuous batching (not in the reference API; SURVEY.md section 8e's mitigation for mixed output lengths): any
+        number of utterances of one prompt through `slots` decode slots.  The longest texts start; whenever a row emits its
+        stop token its codes are taken and its slot is refilled with the next utterance (GPTEngine.decode_refill: the new
+        prompt is prefilled into that slot's KV rows right in front of the loop's current cache position, the row gets its
+        own clock), so the token loop runs sum(lengths) / slots steps instead of, batch after batch, to each batch's longest
+        row.  Then the latent pass and the vocoder run over groups of `slots` finished utterances of similar length.
+        num_beams = 1 only.  cache_positions bounds the KV cache (one loop runs at most that many steps past its prompt; the
+        queue continues in a fresh loop after that).  Returns the waveforms in the order of text_token_rows, as infer_batch."""
+        gen, _ = self._gen_kwargs(generation_kwargs)
+        if int(gen.get("num_beams", 1)) != 1:
+            raise NotImplementedError("infer_queue: num_beams = 1 only (beam rows cannot be refilled one at a time)")
+        self._mark(phase_events, "start")
+        bf = self._batch_feat
+        if bf is not None and bf[0] is cond_mel and bf[1] == cond_mel._version:
+            conds, spk = bf[2], bf[3]
+        else:
+            conds, spk = self._prompt_features(cond_mel)
+            self._batch_feat = (cond_mel, cond_mel._version, conds, spk)
+        g, eng = self.gpt, self.gpt.engine
+        N = len(text_token_rows)
+        texts = [t.reshape(-1).to(torch.int32).cpu() for t in text_token_rows]
+        stops = [-1] * N if force_stop is None else [int(v) for v in force_stop]
+        sp = dict(do_sample=bool(gen["do_sample"]), top_p=float(gen["top_p"]), top_k=int(gen["top_k"]),
+                  temperature=float(gen["temperature"]), repetition_penalty=float(gen["repetition_penalty"]), seed=int(seed))
+        if not sp["do_sample"]:
+            sp["top_p"], sp["top_k"], sp["temperature"] = 1.0, 0, 1.0
+        stop_text = self.cfg.gpt.stop_text_token
+
+        def prefixes(ids):
+            """(left-padded prefix batch, pad) of the utterances `ids` -- one prepare_gpt_inputs call"""
+            L = max(int(texts[i].numel()) for i in ids)
+            bh = torch.full((len(ids), L), stop_text, dtype=torch.int32)
+            for j, i in enumerate(ids):
+                bh[j, : texts[i].numel()] = texts[i]
+            _, emb, mask = g.prepare_gpt_inputs(conds, bh.to(self.device))
+            return emb, (mask == 0).sum(dim=1).to(torch.int32)
+
+        queue = sorted(range(N), key=lambda i: -int(texts[i].numel()))     # longest first: every later prompt fits
+        rows: List[torch.Tensor | None] = [None] * N
+        self._mark(phase_events, "conditioned")
+        while queue:
+            first, queue = queue[:slots], queue[slots:]
+            emb, pad = prefixes(first)
+            eng.prefill(emb, pad, max(max_mel_tokens + 2, int(cache_positions) - emb.shape[1] - 2))
+            entered = list(first)
+
+            def feed(k):
+                nonlocal queue
+                take, queue = queue[:k], queue[k:]
+                if not take:
+                    return []
+                e, p = prefixes(take)
+                p = p.tolist()
+                entered.extend(take)
+                return [(e[j, p[j]:], stops[i]) for j, i in enumerate(take)]
+
+            codes, leftover = eng.decode_refill(max_mel_tokens, sp, feed, force_stop=[stops[i] for i in first],
+                                                positions=max(int(cache_positions), eng._S + max_mel_tokens + 2))
+            if leftover:                                               # fed but not placed: back to the head of the queue
+                back = entered[len(entered) - len(leftover):]
+                entered = entered[: len(entered) - len(leftover)]
+                queue = back + queue
+            for i, c in zip(entered, codes):
+                rows[i] = c
+        self._mark(phase_events, "decoded")
+        squeezed = []
+        for c in rows:
+            cc, ln = self.remove_long_silence(c[None])
+            squeezed.append(cc[0, : int(ln[0])].cpu())
+        outs: List[torch.Tensor | None] = [None] * N
+        order = sorted(range(N), key=lambda i: int(squeezed[i].numel()))
+        for k in range(0, N, slots):
+            ids = order[k: k + slots]
+            lat = self._latents(conds, [texts[i] for i in ids], [squeezed[i] for i in ids])
+            for i, w in zip(ids, self._vocode_ragged(lat, spk)):
+                outs[i] = w
+        self._mark(phase_events, "vocoded")
+        return (outs, squeezed) if return_codes else outs
+
     @staticmethod
     def _mark(phase_events, name):
         if phase_events is not None:

@@ -476,6 +476,110 @@ def test_request_pool_matches_serial_infer_batch():
         for a, b in zip(want, got):
             assert a.shape == b.shape and torch.equal(a, b)
     pool.close()
+    # the same on streams restricted to disjoint halves of the compute units (hipExtStreamCreateWithCUMask)
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    nw = (ncu + 31) // 32
+    even, odd = [0x55555555] * nw, [0xAAAAAAAA] * nw
+    pool = RequestPool(insts, cu_masks=[even, odd])
+    jobs = [pool.submit(cond_mel, b, seed=300 + i, **kw, **gen) for i, b in enumerate(batches)]
+    for want, job in zip(serial, jobs):
+        for a, b in zip(want, job.result()):
+            assert torch.equal(a, b)
+    pool.close()
+    with pytest.raises(AssertionError):
+        RequestPool(insts, cu_masks=[even])
+
+
+def test_decode_refill_gives_every_row_the_codes_it_gets_alone(gpt_small_fp32):
+    """Continuous batching (GPTEngine.decode_refill): 9 utterances of different text lengths and stop steps through 3 decode
+    slots, greedy.  Every utterance's codes equal those of decoding it ALONE (inference_speech on one row) -- compared up to
+    the first step whose top-2 margin in the stand-alone logits is below 1e-3 (a different left padding changes the
+    attention's reduction order) -- although it entered a running loop, at a shifted cache position, in a slot another
+    utterance had used, with its own clock for mel positions / history / stop step.  Graph replay and eager agree."""
+    m = gpt_small_fp32
+    eng = m.engine
+    rng = np.random.default_rng(21)
+    cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
+    conds = m.get_conditioning(cond_mel, None)
+    lens = [14, 12, 11, 9, 8, 7, 6, 5, 4]                       # longest first
+    texts = [torch.from_numpy(rng.integers(2, 12000, size=n)).to(torch.int32) for n in lens]
+    stops = [9, 21, 5, 13, 30, 3, 17, 8, 11]
+    max_new = 40
+    sp = dict(do_sample=False, top_p=1.0, top_k=0, temperature=1.0, repetition_penalty=10.0, seed=0)
+
+    def prefix(ids):
+        L = max(lens[i] for i in ids)
+        bh = torch.full((len(ids), L), m.stop_text_token, dtype=torch.int32)
+        for j, i in enumerate(ids):
+            bh[j, : lens[i]] = texts[i]
+        _, emb, mask = m.prepare_gpt_inputs(conds, bh.to(DEV))
+        return emb, (mask == 0).sum(1).to(torch.int32)
+
+    alone = []
+    for i in range(9):
+        c, lg = m.inference_speech(cond_mel, texts[i][None].to(DEV), do_sample=False, num_beams=1, repetition_penalty=10.0,
+                                   max_generate_length=max_new, force_stop=[stops[i]], return_logits=True)
+        alone.append((c[0].cpu(), lg[:, 0].cpu()))
+    got = {}
+    for use_graph in (False, True):
+        queue = list(range(3, 9))
+        emb, pad = prefix([0, 1, 2])
+        eng.prefill(emb, pad, 400)
+
+        def feed(k):
+            take = [queue.pop(0) for _ in range(min(k, len(queue)))]
+            if not take:
+                return []
+            e, p = prefix(take)
+            return [(e[j, int(p[j]):], stops[i]) for j, i in enumerate(take)]
+
+        codes, leftover = eng.decode_refill(max_new, sp, feed, force_stop=stops[:3], use_graph=use_graph, check_every=4)
+        assert not leftover and len(codes) == 9
+        got[use_graph] = [c.cpu() for c in codes]
+    for a, b in zip(got[False], got[True]):
+        assert torch.equal(a, b)
+    for i, c in enumerate(got[True]):
+        want, lg = alone[i]
+        assert int(c[-1]) == m.stop_mel_token and c.numel() == stops[i] + 1, (i, c)
+        for s_ in range(c.numel()):
+            if int(c[s_]) != int(want[s_]):
+                top2 = torch.topk(lg[s_], 2).values
+                assert (top2[0] - top2[1]).item() < 1e-3, (i, s_, c, want)
+                break
+    # the cache positions reserved by prefill() bound the loop: what no longer fits comes back as leftover
+    queue = list(range(3, 9))
+    emb, pad = prefix([0, 1, 2])
+    eng.prefill(emb, pad, 400)
+    codes, leftover = eng.decode_refill(max_new, sp, feed, force_stop=stops[:3], check_every=4, positions=128)
+    assert len(codes) + len(leftover) + len(queue) == 9 and len(leftover) > 0
+
+
+def test_infer_queue_equals_utterances_synthesised_one_by_one():
+    """IndexTTS.infer_queue (continuous batching through 3 slots) returns, in input order, the waveforms infer_batch gives
+    for each utterance alone; a tiny cache budget (several loops) changes nothing."""
+    from indextts.infer import IndexTTS
+    cfg = weights.reference_config()
+    cfg["gpt"]["layers"] = 2
+    tts = IndexTTS.from_weights(cfg, weights.gpt_state_dict(2), weights.bigvgan_state_dict(), device="cuda:0",
+                                precision_config={"gpt": "fp32", "vocoder": "fp32"})
+    cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
+    rng = np.random.default_rng(5)
+    lens = [6, 13, 4, 9, 11, 5, 8]
+    texts = [torch.from_numpy(rng.integers(2, 12000, size=n)).to(torch.int32) for n in lens]
+    stops = [7, 3, 12, 5, 9, 4, 6]
+    gen = dict(do_sample=False, num_beams=1, repetition_penalty=10.0)
+    want = [tts.infer_batch(cond_mel, [texts[i]], max_mel_tokens=20, force_stop=[stops[i]], return_codes=True, **gen)
+            for i in range(7)]
+    for cache in (4096, 160):
+        outs, codes = tts.infer_queue(cond_mel, texts, slots=3, max_mel_tokens=20, force_stop=stops, return_codes=True,
+                                      cache_positions=cache, **gen)
+        for i in range(7):
+            w, c = want[i][0][0], want[i][1][0]
+            assert torch.equal(codes[i].long().cpu(), c.long().cpu()), (cache, i, codes[i], c)
+            assert outs[i].shape == w.shape
+            assert (outs[i] - w).abs().max().item() <= 1e-3 * max(1.0, w.abs().max().item()), (cache, i)
+    with pytest.raises(NotImplementedError):
+        tts.infer_queue(cond_mel, texts, slots=3, num_beams=3)
 
 
 def test_beam_decode_full_size_bf16_graph_equals_eager():

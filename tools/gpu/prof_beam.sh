@@ -13,4 +13,6 @@ for r in rows[:60]:
     if "itts" in n:
         print(f'{float(r["TotalDurationNs"])/1e6:9.2f} ms n={r["Calls"]:>7} avg={float(r["AverageNs"])/1e3:8.2f} us  {n[:130]}')
 PY
+cp "$(find gpurun_out/prof_beam -name "*kernel_stats.csv" | head -1)" gpurun_out/${R}_beam_kernel_stats.csv
+rm -rf gpurun_out/prof_beam   # the per-dispatch trace is > 64 MiB: only the stats summary travels back
 echo ALLDONE

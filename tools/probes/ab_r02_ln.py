@@ -33,7 +33,7 @@ if os.environ.get("ITTS_HIP_LIB"):
         restype = argtypes = None
 
         def __call__(self):
-            return 5
+            return 6
 
     class Proxy:
         def __init__(self, path):
