@@ -549,20 +549,21 @@ class GPTEngine:
         return (codes, torch.stack(logits_trace, 0)) if return_logits else codes
 
     # ------------------------------------------------------------------------------------------------ slot refill
-    def _refill(self, rows, prefixes, stops, n):
-        """Put new utterances into the decode slots `rows` between two steps of a running loop in which every row has been
-        given n tokens' worth of steps (state[0] = n - 1 with the bump pending, the next step writes cache position S+n-1).
+    def _stage(self, rows, prefixes, stops, n):
+        """Prepare new utterances for the decode slots `rows`, to JOIN a running loop at the moment every row has been given
+        n tokens' worth of steps (state[0] = n - 1 with the bump pending, the next step writes cache position S+n-1).
         prefixes: fp32 [P_j, D] each (cond | text, no padding).  A new row is laid out exactly like an initial row of a batch
         whose loop started n - 1 steps later: prompt + start token at cache positions [pad, S+n-2] of its slot, left padding
-        pad = S+n-1-(P_j+1), its clock row_step0 = n - 1 (mel positions, history index, stop step and repetition-penalty
-        window count from its own first token), its first token sampled here from its prefill logits."""
+        pad = S+n-1-(P_j+1).  One packed prefill pass over all new rows; their keys / values are kept aside ([M, L, H, 64]) and
+        the logits of their last positions computed on buffers of their own -- nothing the running loop reads or writes is
+        touched, so this may run on another stream beside the loop's steps."""
         import numpy as np
         T, D, H, dev = self.dtype, self.D, self.H, self.device
         k = len(rows)
         end = self._S + n - 1                              # one past the last prompt position
         lens = [int(p.shape[0]) + 1 for p in prefixes]
         if max(lens) > end:
-            raise ValueError("_refill(): a new prompt is longer than the positions the loop has passed")
+            raise ValueError("decode_refill(): a new prompt is longer than the positions the loop has passed")
         pads = [end - L for L in lens]
         start = (self.mel_emb[self.start_mel] + self.mel_pos[0])[None]
         h = torch.cat([t for p in prefixes for t in (p.to(dev, torch.float32), start)], dim=0).contiguous()
@@ -572,50 +573,62 @@ class GPTEngine:
         posi = np.concatenate([pd + np.arange(L) for L, pd in zip(lens, pads)])
         meta = torch.from_numpy(np.concatenate([slot, posi, off, off[1:] - 1, np.asarray(rows), np.asarray(pads),
                                                 np.asarray(stops)]).astype(np.int64)).to(dev)     # one upload
-        i_b, i_p = meta[:M], meta[M:2 * M]
+        st = {"k": k, "n": n, "i_b": meta[:M], "i_p": meta[M:2 * M],
+              "i_rows": meta[2 * M + 2 * k + 1:2 * M + 3 * k + 1],
+              "pads": meta[2 * M + 3 * k + 1:2 * M + 4 * k + 1].to(torch.int32), "stops": meta[2 * M + 4 * k + 1:].to(torch.int32)}
         row_off = meta[2 * M:2 * M + k + 1].to(torch.int32)
         last = meta[2 * M + k + 1:2 * M + 2 * k + 1]
-        i_rows = meta[2 * M + 2 * k + 1:2 * M + 3 * k + 1]
-        pads_d = meta[2 * M + 3 * k + 1:2 * M + 4 * k + 1].to(torch.int32)
-        stops_d = meta[2 * M + 4 * k + 1:].to(torch.int32)
         xn = torch.empty(M, D, dtype=T, device=dev)
         qkv = torch.empty(M, 3, H, 64, dtype=T, device=dev)
         att = torch.empty(M, D, dtype=T, device=dev)
         ff = torch.empty(M, 4 * D, dtype=T, device=dev)
+        kst = torch.empty(M, self.L, H, 64, dtype=T, device=dev)
+        vst = torch.empty(M, self.L, H, 64, dtype=T, device=dev)
         Smax = max(lens)
         for i, l in enumerate(self.layers):
             nat.layernorm(h, l["ln1"][0], l["ln1"][1], xn)
             nat.gemm_conv(T, 1, M, M, D, 3 * D, l["w_qkv"], xn, qkv.view(M, 3 * D), bias=l["b_qkv"])
-            self.kc[i][i_b, :, i_p] = qkv[:, 1]            # the slots' cache rows, positions [pad, S+n-2]
-            self.vc[i][i_b, :, i_p] = qkv[:, 2]
+            kst[:, i] = qkv[:, 1]
+            vst[:, i] = qkv[:, 2]
             nat.attn_prefill_packed(qkv.view(M, 3 * D), att, None, None, row_off, None, k, Smax, H, self._cap_s)
             nat.gemm_conv(T, 1, M, M, D, D, l.get("w_o_merged", l["w_o"]), att, h, bias=l["b_o"], y_f32=True, resid=h)
             nat.layernorm(h, l["ln2"][0], l["ln2"][1], xn)
             nat.gemm_conv(T, 1, M, M, D, 4 * D, l["w_fc"], xn, ff, bias=l["b_fc"], act=1)
             nat.gemm_conv(T, 1, M, M, 4 * D, D, l.get("w_pr_merged", l["w_pr"]), ff, h, bias=l["b_pr"], y_f32=True, resid=h)
-        # head + first token of the new rows on buffers of their own (the running rows' logits / packed activations stay)
-        kp = nat.packed_rows(k)
-        xn_t = torch.zeros(kp, D, dtype=T, device=dev)
+        xn_t = torch.zeros(nat.packed_rows(k), D, dtype=T, device=dev)
         lg_t = torch.empty(k, self.V, dtype=torch.float32, device=dev)
         nat.ln_reduce(h[last].contiguous(), self.ln_f[0], self.ln_f[1], xn_t, w2=self.final_norm[0], b2=self.final_norm[1],
                       y_packed=self.pa)
         nat.gemm_skinny(T, k, self.V, D, self.w_head, self.b_head, x=xn_t, epi=nat.EPI_STORE_F32, yf=lg_t, x_packed=self.pa)
+        st.update(kst=kst, vst=vst, logits=lg_t)
+        return st
+
+    def _join(self, st, sp):
+        """The staged rows enter the loop (between two of its steps, at the n they were staged for): keys / values into the
+        slots' cache rows, the first token of every new row sampled from its prefill logits -- on buffers of its own, the
+        running rows' logits stay --, and the per-row state: left padding, stop step, own clock row_step0 = n - 1 (mel
+        positions, history index and the repetition-penalty window count from the row's own first token)."""
+        k, n, dev = st["k"], st["n"], self.device
+        self.kc[:, st["i_b"], :, st["i_p"]] = st["kst"]    # [M, L, H, 64] -> positions [pad, S+n-2] of the slots
+        self.vc[:, st["i_b"], :, st["i_p"]] = st["vst"]
         tok_t = torch.zeros(k, dtype=torch.int32, device=dev)
         hist_t = torch.zeros(k, 8, dtype=torch.int32, device=dev)
         fin_t = torch.zeros(k, dtype=torch.int32, device=dev)
         step0_t = torch.full((k,), n - 1, dtype=torch.int32, device=dev)
-        sp = self._refill_sp
         self.state[2:3] -= k                               # these slots were counted as finished
-        nat.sample(lg_t, tok_t, hist_t, fin_t, self.state, self.extra_ids, stops_d, sp["repetition_penalty"], sp["temperature"],
-                   sp["top_k"], sp["top_p"], sp["do_sample"], sp["seed"], self.stop_mel, None, no_advance=True, row_step0=step0_t)
+        nat.sample(st["logits"], tok_t, hist_t, fin_t, self.state, self.extra_ids, st["stops"], sp["repetition_penalty"],
+                   sp["temperature"], sp["top_k"], sp["top_p"], sp["do_sample"], sp["seed"], self.stop_mel, None, no_advance=True,
+                   row_step0=step0_t)
+        i_rows = st["i_rows"]
         self.tokens[i_rows] = tok_t
         self.history[i_rows, 0] = tok_t
         self.finished[i_rows] = fin_t
-        self.force_stop[i_rows] = stops_d
+        self.force_stop[i_rows] = st["stops"]
         self.row_step0[i_rows] = step0_t
-        self.pad[i_rows] = pads_d
+        self.pad[i_rows] = st["pads"]
 
-    def decode_refill(self, max_new: int, sp: dict, feed, force_stop=None, use_graph=True, check_every=16, positions=None):
+    def decode_refill(self, max_new: int, sp: dict, feed, force_stop=None, use_graph=True, check_every=16, positions=None,
+                      staged=True):
         """Continuous batching: the sampling loop after prefill(), with every slot whose row has emitted its stop token
         refilled from a queue (the mitigation for mixed output lengths).  num_beams = 1 only.
         feed(k) -> up to k items (prefix_emb fp32 [P, D] = cond | text without padding, stop step or -1); fewer than k means
@@ -624,6 +637,11 @@ class GPTEngine:
         int64 [n_id] ends with the stop token; leftover = items that were fed but could not be placed any more because the
         cache positions reserved by prefill() -- or the smaller budget `positions` -- ran out (the caller starts a new loop
         with them).
+        Every check_every steps the host reads the `finished` flags (the loop's one synchronisation).  staged = True: the
+        prompts of the utterances that take the freed slots are prefilled on a SECOND STREAM while the loop runs its next
+        check_every steps, and join at the following poll -- the ~300 launches of that pass are enqueued and executed under
+        the loop's own steps instead of stalling it (the slot idles check_every steps longer).  staged = False: prefill and
+        join at once, the loop waits.
         A row's tokens are those it would get decoded alone with the same logits (greedy: identical codes up to the usual
         reduction-order noise of a different left padding); sampled rows draw from the loop's Philox stream (row slot, loop
         step), so they differ from a stand-alone run as two seeds do."""
@@ -638,19 +656,56 @@ class GPTEngine:
         fs = [max_new - 1 if v < 0 else min(v, max_new - 1) for v in fs]
         self.force_stop[:B] = torch.tensor(fs, dtype=torch.int32).to(dev)
         sp = self._seed_to_state(sp)
-        self._refill_sp = sp
-        owner, start = list(range(B)), [0] * B
+        owner, start = list(range(B)), [0] * B              # owner: utterance id | None (free) | -1 (reserved for staged rows)
         next_id, codes, leftover, fed_out = B, {}, [], False
-        stats = self.refill_stats = {"steps": 0, "polls": 0, "refill_calls": 0, "rows_refilled": 0}
+        stats = self.refill_stats = {"steps": 0, "polls": 0, "refill_calls": 0, "rows_refilled": 0, "staged": bool(staged)}
+        main = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev) if staged else None
+        pending = None                                      # (staged rows, slots, event)
+        stop_id = self.stop_mel
         self._sample(B, sp)
         n = 1
-        stop_id = self.stop_mel
         while True:
-            # ---- up to check_every steps
+            # ---- A: rows staged during the last steps join here
+            if pending is not None:
+                st, rows, ev = pending
+                main.wait_event(ev)
+                self._join(st, sp)
+                for t in st.values():                       # allocated on the side stream, last used on this one
+                    if torch.is_tensor(t):
+                        t.record_stream(main)
+                for r in rows:
+                    owner[r], start[r] = next_id, n - 1
+                    next_id += 1
+                pending = None
+            # ---- B: utterances for the slots that are free now
+            free = [r for r in range(B) if owner[r] is None]
+            items, n_join = [], n + check_every if staged else n
+            if free and not fed_out and n > 1:
+                items = list(feed(len(free)))
+                if len(items) < len(free):
+                    fed_out = True
+                if items and limit - (S + n_join + 1) < max_new + check_every:    # steps the loop could still take
+                    leftover, items, fed_out = items, [], True
+            if items:
+                rows = free[: len(items)]
+                stops = [max_new - 1 if int(v) < 0 else min(int(v), max_new - 1) for _, v in items]
+                stats["refill_calls"] += 1
+                stats["rows_refilled"] += len(rows)
+                if not staged:
+                    self._join(self._stage(rows, [p for p, _ in items], stops, n), sp)
+                    for r in rows:
+                        owner[r], start[r] = next_id, n - 1
+                        next_id += 1
+                    items = []
+                else:
+                    fed = torch.cuda.Event()
+                    fed.record(main)                        # the prefix embeddings are complete on the loop's stream
+            if fed_out and pending is None and not items and all(o is None for o in owner):
+                break
+            # ---- C: check_every steps of the loop
             todo = check_every
             while todo > 0:
-                if S + n + 1 > self._cap_s:
-                    raise ValueError("decode_refill(): the cache positions reserved by prefill() are used up")   # (cannot happen)
                 G = self.steps_per_graph
                 if use_graph and not self.force_eager and n >= 2:
                     kk = G if G <= todo else 1
@@ -660,11 +715,23 @@ class GPTEngine:
                     self._step_kernels(B, sp)
                 n += kk
                 todo -= kk
-            # ---- one host synchronisation: which rows have stopped
+            # ---- D: the new rows' prompts, enqueued behind the steps on the host and run beside them on the GPU
+            if items:
+                with torch.cuda.stream(side):
+                    side.wait_event(fed)
+                    for p, _ in items:
+                        p.record_stream(side)               # allocated on the loop's stream, read on this one
+                    st = self._stage(rows, [p for p, _ in items], stops, n_join)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                for r in rows:
+                    owner[r] = -1
+                pending = (st, rows, ev)
+            # ---- E: one host synchronisation: which rows have stopped
             stats["steps"], stats["polls"] = n, stats["polls"] + 1
             self._poll()
             fin = self.finished[:B].tolist()
-            newly = [r for r in range(B) if fin[r] and owner[r] is not None]
+            newly = [r for r in range(B) if fin[r] and owner[r] is not None and owner[r] >= 0]
             if newly:
                 width = max(n - start[r] for r in newly)
                 hist = self.history[torch.tensor(newly, device=dev), :width].cpu()
@@ -673,25 +740,6 @@ class GPTEngine:
                     hit = (row == stop_id).nonzero()
                     codes[owner[r]] = row[: int(hit[0]) + 1] if hit.numel() else row
                     owner[r] = None
-            free = [r for r in range(B) if owner[r] is None]
-            if free and not fed_out:
-                items = list(feed(len(free)))
-                if len(items) < len(free):
-                    fed_out = True
-                room = limit - (S + n + 1)                 # steps the loop can still take
-                if items and room < max_new + check_every:
-                    leftover, items, fed_out = items, [], True
-                if items:
-                    rows = free[: len(items)]
-                    stops = [max_new - 1 if int(st) < 0 else min(int(st), max_new - 1) for _, st in items]
-                    self._refill(rows, [p for p, _ in items], stops, n)
-                    stats["refill_calls"] += 1
-                    stats["rows_refilled"] += len(rows)
-                    for r in rows:
-                        owner[r], start[r] = next_id, n - 1
-                        next_id += 1
-            if fed_out and all(o is None for o in owner):
-                break
         return [codes[i] for i in range(next_id)], leftover
 
     # ------------------------------------------------------------------------------------------------ beam search

@@ -603,8 +603,8 @@ class IndexTTS:
         return (outs, st["rows"]) if return_codes else outs
 
     def infer_queue(self, cond_mel: torch.Tensor, text_token_rows: List[torch.Tensor], slots=32, max_mel_tokens=600,
-                    force_stop=None, seed=1234, return_codes=False, cache_positions=4096, phase_events: dict | None = None,
-                    **generation_kwargs):
+                    force_stop=None, seed=1234, return_codes=False, cache_positions=4096, check_every=16, staged=True,
+                    phase_events: dict | None = None, **generation_kwargs):
         """Continuous batching (not in the reference API; SURVEY.md section 8e's mitigation for mixed output lengths): any
         number of utterances of one prompt through `slots` decode slots.  The longest texts start; whenever a row emits its
         stop token its codes are taken and its slot is refilled with the next utterance (GPTEngine.decode_refill: the new
@@ -612,7 +612,9 @@ class IndexTTS:
         own clock), so the token loop runs sum(lengths) / slots steps instead of, batch after batch, to each batch's longest
         row.  Then the latent pass and the vocoder run over groups of `slots` finished utterances of similar length.
         num_beams = 1 only.  cache_positions bounds the KV cache (one loop runs at most that many steps past its prompt; the
-        queue continues in a fresh loop after that).  Returns the waveforms in the order of text_token_rows, as infer_batch."""
+        queue continues in a fresh loop after that); check_every / staged: how often the loop looks for finished rows and whether
+        a refill's prefill runs on a second stream under the loop's next steps (GPTEngine.decode_refill).  Returns the waveforms
+        in the order of text_token_rows, as infer_batch."""
         gen, _ = self._gen_kwargs(generation_kwargs)
         if int(gen.get("num_beams", 1)) != 1:
             raise NotImplementedError("infer_queue: num_beams = 1 only (beam rows cannot be refilled one at a time)")
@@ -662,7 +664,8 @@ class IndexTTS:
                 return [(e[j, p[j]:], stops[i]) for j, i in enumerate(take)]
 
             codes, leftover = eng.decode_refill(max_mel_tokens, sp, feed, force_stop=[stops[i] for i in first],
-                                                positions=max(int(cache_positions), eng._S + max_mel_tokens + 2))
+                                                positions=max(int(cache_positions), eng._S + max_mel_tokens + 2),
+                                                check_every=int(check_every), staged=bool(staged))
             if leftover:                                               # fed but not placed: back to the head of the queue
                 back = entered[len(entered) - len(leftover):]
                 entered = entered[: len(entered) - len(leftover)]

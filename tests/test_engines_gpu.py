@@ -491,7 +491,7 @@ def test_request_pool_matches_serial_infer_batch():
 
 
 def test_decode_refill_gives_every_row_the_codes_it_gets_alone(gpt_small_fp32):
-    """Continuous batching (GPTEngine.decode_refill): 9 utterances of different text lengths and stop steps through 3 decode
+    """Continuous batching (GPTEngine.decode_refill; refills joined at once or staged on a second stream): 9 utterances of different text lengths and stop steps through 3 decode
     slots, greedy.  Every utterance's codes equal those of decoding it ALONE (inference_speech on one row) -- compared up to
     the first step whose top-2 margin in the stand-alone logits is below 1e-3 (a different left padding changes the
     attention's reduction order) -- although it entered a running loop, at a shifted cache position, in a slot another
@@ -521,7 +521,7 @@ def test_decode_refill_gives_every_row_the_codes_it_gets_alone(gpt_small_fp32):
                                    max_generate_length=max_new, force_stop=[stops[i]], return_logits=True)
         alone.append((c[0].cpu(), lg[:, 0].cpu()))
     got = {}
-    for use_graph in (False, True):
+    for use_graph, staged in ((False, False), (True, False), (True, True)):
         queue = list(range(3, 9))
         emb, pad = prefix([0, 1, 2])
         eng.prefill(emb, pad, 400)
@@ -533,19 +533,23 @@ def test_decode_refill_gives_every_row_the_codes_it_gets_alone(gpt_small_fp32):
             e, p = prefix(take)
             return [(e[j, int(p[j]):], stops[i]) for j, i in enumerate(take)]
 
-        codes, leftover = eng.decode_refill(max_new, sp, feed, force_stop=stops[:3], use_graph=use_graph, check_every=4)
+        codes, leftover = eng.decode_refill(max_new, sp, feed, force_stop=stops[:3], use_graph=use_graph, check_every=4,
+                                            staged=staged)
         assert not leftover and len(codes) == 9
-        got[use_graph] = [c.cpu() for c in codes]
-    for a, b in zip(got[False], got[True]):
+        assert eng.refill_stats["rows_refilled"] == 6 and eng.refill_stats["staged"] == staged
+        got[(use_graph, staged)] = [c.cpu() for c in codes]
+    for a, b in zip(got[(False, False)], got[(True, False)]):
         assert torch.equal(a, b)
-    for i, c in enumerate(got[True]):
-        want, lg = alone[i]
-        assert int(c[-1]) == m.stop_mel_token and c.numel() == stops[i] + 1, (i, c)
-        for s_ in range(c.numel()):
-            if int(c[s_]) != int(want[s_]):
-                top2 = torch.topk(lg[s_], 2).values
-                assert (top2[0] - top2[1]).item() < 1e-3, (i, s_, c, want)
-                break
+    # (a staged refill joins one poll later, at another cache position: same utterance ids, same codes)
+    for mode in ((True, False), (True, True)):
+        for i, c in enumerate(got[mode]):
+            want, lg = alone[i]
+            assert int(c[-1]) == m.stop_mel_token and c.numel() == stops[i] + 1, (mode, i, c)
+            for s_ in range(c.numel()):
+                if int(c[s_]) != int(want[s_]):
+                    top2 = torch.topk(lg[s_], 2).values
+                    assert (top2[0] - top2[1]).item() < 1e-3, (mode, i, s_, c, want)
+                    break
     # the cache positions reserved by prefill() bound the loop: what no longer fits comes back as leftover
     queue = list(range(3, 9))
     emb, pad = prefix([0, 1, 2])

@@ -50,9 +50,9 @@ def static(seed):
     return outs
 
 
-def refill(seed):
+def refill(seed, check_every=16, staged=True):
     return tts.infer_queue(cond_mel, texts, slots=32, max_mel_tokens=max_new, force_stop=stops, seed=seed,
-                           cache_positions=4096, **gen)
+                           cache_positions=4096, check_every=check_every, staged=staged, **gen)
 
 
 res = {"workload": f"{N} utterances, text U{{8..100}}, stop steps U{{40..400}} (BASELINE config 4's distribution), 32 decode slots, 1 GPU",
@@ -60,7 +60,12 @@ res = {"workload": f"{N} utterances, text U{{8..100}}, stop steps U{{40..400}} (
 order = sorted(range(N), key=lambda i: -int(texts[i].numel()))
 res["decode_steps_static"] = sum(max(stops[i] for i in order[k:k + 32]) + 1 for k in range(0, N, 32))
 res["decode_steps_ideal_refill"] = round(sum(s + 1 for s in stops) / 32, 1)
-for name, fn in (("static", static), ("refill", refill)):
+import functools  # noqa: E402
+variants = [("static", static), ("refill", refill)]
+if os.environ.get("ITTS_REFILL_SWEEP") == "1":
+    variants += [(f"refill_every{ce}_{'staged' if stg else 'immediate'}", functools.partial(refill, check_every=ce, staged=stg))
+                 for ce, stg in ((16, False), (8, True), (8, False), (32, True))]
+for name, fn in variants:
     fn(1)                                             # warm-up, graph capture
     torch.cuda.synchronize()
     pe = {}
@@ -70,7 +75,7 @@ for name, fn in (("static", static), ("refill", refill)):
     dt = time.perf_counter() - t0
     assert all(int(o.numel()) == stops[i] * 1024 for i, o in enumerate(outs)), name
     res[name] = {"seconds": round(dt, 3), "audio_s_per_s": round(audio_s / dt, 1)}
-    if name == "refill":
+    if name.startswith("refill"):
         res[name]["loop"] = dict(tts.gpt.engine.refill_stats)
     print(f"{name}: {dt:.3f} s -> {audio_s / dt:.1f} audio-s/s", file=sys.stderr, flush=True)
 res["speedup"] = round(res["static"]["seconds"] / res["refill"]["seconds"], 3)
