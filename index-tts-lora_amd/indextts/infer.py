@@ -791,11 +791,14 @@ class BatchPipeline:
     to infer_batch(): the two stages share only read-only weights (the latent pass and the vocoder allocate their
     activations per call from the stream-aware allocator, the decode loop owns the KV cache and its state)."""
 
-    def __init__(self, tts: "IndexTTS"):
+    def __init__(self, tts: "IndexTTS", cu_mask_b=None):
+        """cu_mask_b: optional uint32 words (bit i = CU i) restricting stage B's stream to a subset of the compute units
+        (hipExtStreamCreateWithCUMask), so that its thousand-workgroup launches leave CUs to the token loop."""
         self.tts = tts
         lo, hi = 0, -1
         self.stream_a = torch.cuda.Stream(device=tts.device, priority=hi)   # latency-critical token loop
-        self.stream_b = torch.cuda.Stream(device=tts.device, priority=lo)   # throughput work
+        self.stream_b = (torch.cuda.Stream(device=tts.device, priority=lo) if cu_mask_b is None   # throughput work
+                         else stream_with_cu_mask(tts.device, cu_mask_b))
         self._jobs: "queue.Queue" = queue.Queue()
         self._inflight: List[BatchTicket] = []
         self._thread = threading.Thread(target=self._worker, name="itts-stage-b", daemon=True)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Two (or three) batch-32 requests in flight on one MI355X (BASELINE config 3 through indextts.infer.RequestPool): ordinary
 streams against streams restricted to disjoint CU subsets (hipExtStreamCreateWithCUMask).
-usage: pool_cu_masks.py [schedule ...]   schedules: serial plainN (N requests in flight) halves interleaved xcd44 split192_64
+usage: pool_cu_masks.py [schedule ...]   schedules: serial plainN (N requests in flight) halves interleaved xcd44 split192_64 pipe pipe_bN (stage B on N CUs)
 Appends to gpurun_out/pool_cu_masks.txt"""
 import contextlib
 import os
@@ -15,7 +15,7 @@ import torch  # noqa: E402
 
 import synth  # noqa: E402
 import weights  # noqa: E402
-from indextts.infer import IndexTTS, RequestPool  # noqa: E402
+from indextts.infer import BatchPipeline, IndexTTS, RequestPool  # noqa: E402
 from indextts.utils import dist as idist  # noqa: E402
 
 sys.path.insert(0, ROOT)
@@ -60,7 +60,21 @@ def masks(name):
 out = open(os.path.join(ROOT, "gpurun_out", "pool_cu_masks.txt"), "a")
 replicas = [tts.replica() for _ in range(max([int(n[5:]) for n in scheds if n.startswith("plain")] + [2]) - 1)]
 for name in scheds:
-    if name == "serial":
+    if name.startswith("pipe"):
+        # BatchPipeline: stage B (latent pass + vocoder) of batch k on a second stream beside the token loop of batch k + 1;
+        # pipe_bN: that stream restricted to the first N compute units
+        nb = int(name[6:]) if name.startswith("pipe_b") else 0
+        pipe = BatchPipeline(tts, cu_mask_b=words(range(nb)) if nb else None)
+        for seed0, n in ((7000, 2), (8000, 8)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tickets = [pipe.submit(cond_mel, texts, seed=seed0 + k, **kw) for k in range(n)]
+            for t in tickets:
+                t.result()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        pipe.close()
+    elif name == "serial":
         for k in range(2):
             tts.infer_batch(cond_mel, texts, seed=10 + k, **kw)
         torch.cuda.synchronize()
