@@ -573,7 +573,7 @@ def main():
         # Reported beside `value`, never as `value`: two independent batch-32 requests in flight (one engine instance,
         # thread and HIP stream each).  A single request's token loop is latency-bound and leaves the CUs mostly idle.
         pl = make_pool()
-        nrun = max(4, 2 * len(pl.instances))
+        nrun = 4 * len(pl.instances)   # long enough that ramp-up and drain (fewer requests in flight) do not dominate
 
         def run_conc(seed0):
             jobs = [pl.submit(cond_mel, texts, max_mel_tokens=max_new, force_stop=force, seed=seed0 + k, **gen)

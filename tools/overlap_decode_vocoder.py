@@ -2,7 +2,7 @@
 """What one request's token loop pays while ANOTHER stream runs the vocoder (MI355X): decode microseconds per token (engine
 alone, config 3 shape, graph replay) with a background thread that vocodes [32, 140, 1280] latents in a loop on a second
 stream -- an ordinary stream, or one restricted to the first N compute units (hipExtStreamCreateWithCUMask).
-usage: overlap_decode_vocoder.py [none plain b192 b128 b64 ...]   Appends to gpurun_out/overlap_decode_vocoder.txt"""
+usage: overlap_decode_vocoder.py [none plain prio b192 b128 b64 ...]   Appends to gpurun_out/overlap_decode_vocoder.txt"""
 import os
 import sys
 import threading
@@ -44,6 +44,8 @@ for mode in modes:
     if mode != "none":
         if mode == "plain":
             sb = torch.cuda.Stream()
+        elif mode == "prio":                       # vocoder on a low-priority stream, the token loop on a high-priority one
+            sb = torch.cuda.Stream(priority=0)
         else:
             n = int(mode[1:])
             w = [0] * ((NCU + 31) // 32)
@@ -64,11 +66,13 @@ for mode in modes:
         th.start()
         time.sleep(0.3)
         count[0], count[1] = 0, 0.0
-    eng.prefill(prefix, pad, NEW + 2)
-    torch.cuda.current_stream().synchronize()
-    t0 = time.perf_counter()
-    eng.decode(NEW, sp, force_stop=[NEW - 1] * B)
-    torch.cuda.current_stream().synchronize()
+    sa = torch.cuda.Stream(priority=-1) if mode == "prio" else torch.cuda.current_stream()
+    with torch.cuda.stream(sa):
+        eng.prefill(prefix, pad, NEW + 2)
+        sa.synchronize()
+        t0 = time.perf_counter()
+        eng.decode(NEW, sp, force_stop=[NEW - 1] * B)
+        sa.synchronize()
     us = 1e6 * (time.perf_counter() - t0) / NEW
     nv, tv = count[0], count[1]
     stop.set()
