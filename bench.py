@@ -21,6 +21,12 @@ import subprocess
 import sys
 import time
 
+# The HIP runtime multiplexes a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4).  The serving-concurrency
+# leg keeps four requests in flight, each on its own stream; with four queues two of those streams end up sharing one and
+# the leg measures two-deep concurrency (1 400 instead of 1 740 audio-s/s, profiles/r03_pool_cu_masks.txt).  `value` (one
+# request at a time) is the same either way.  Read by the runtime at its initialisation, i.e. after this line.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "index-tts-lora_amd"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
@@ -589,6 +595,7 @@ def main():
         result["concurrent_requests"] = {"inflight": len(pl.instances), "steps": nrun, "value": round(audio_s_step * nrun / dtc, 2),
                                          "unit": "audio-seconds/sec", "ms_per_step": round(1e3 * dtc / nrun, 3),
                                          "streams": "ordinary (CU-masked streams measured slower: profiles/r03_pool_cu_masks.txt)",
+                                         "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                                          "note": "serving concurrency (indextts.infer.RequestPool): independent batch-32 requests "
                                                  "overlap; `value` above is one request at a time"}
         pl.close()
