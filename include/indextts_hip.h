@@ -48,7 +48,7 @@ extern "C" {
 #define ITTS_BF16 1
 #define ITTS_F16 2
 
-#define ITTS_ABI_VERSION 6 /* 6: per-row clocks (row_step0) in itts_embed_step / itts_sample_args: slot refill; 5: itts_ln_reduce takes up to 6 slabs */
+#define ITTS_ABI_VERSION 6 /* 6: per-row clocks (row_step0) in itts_embed_step / itts_sample_args (slot refill), itts_attn_prefill_prefix; 5: itts_ln_reduce takes up to 6 slabs */
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -252,6 +252,16 @@ int itts_attn_prefill(const void* qkv, void* out, void* kcache, void* vcache, co
  * element's left padding this reproduces the cache layout of the padded form. */
 int itts_attn_prefill_packed(const void* qkv, void* out, void* kcache, void* vcache, const int32_t* row_off,
                              const int32_t* cache_shift, int B, int Smax, int H, int smax, int dtype, void* stream);
+
+/* Packed rows behind a CACHED PREFIX (the teacher-forced latent pass, model.py:459-474 / 548-597, for a batch whose prompt the
+ * decode loop has cached): element b's sequence is  pre_len[b] keys / values read from cache row pre_row[b], positions
+ * pre_pos0[b] .. pre_pos0[b] + pre_len[b] - 1 (caches T [rows][H][smax][64], read only)  |  its rows [row_off[b], row_off[b+1])
+ * of qkv.  Only the qkv rows are queries (query i sits at sequence position pre_len[b] + i and sees every key up to it); out has
+ * the rows of qkv.  Key tiles are cut from sequence position 0, so every output row equals, bit for bit, the row
+ * itts_attn_prefill_packed produces when the prefix's k / v rows are part of qkv. */
+int itts_attn_prefill_prefix(const void* qkv, void* out, const void* kcache, const void* vcache, const int32_t* row_off,
+                             const int32_t* pre_len, const int32_t* pre_row, const int32_t* pre_pos0, int B, int Smax, int H,
+                             int smax, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Token selection for one decode step, on device (no host sync in the loop).

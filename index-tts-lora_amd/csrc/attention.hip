@@ -193,7 +193,11 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const T* __restrict__
                                                             T* __restrict__ kc, T* __restrict__ vc,
                                                             const int32_t* __restrict__ pad, int S, int H, int smax,
                                                             const int32_t* __restrict__ row_off,
-                                                            const int32_t* __restrict__ cache_shift) {
+                                                            const int32_t* __restrict__ cache_shift,
+                                                            const T* __restrict__ pkc, const T* __restrict__ pvc,
+                                                            const int32_t* __restrict__ pre_len,
+                                                            const int32_t* __restrict__ pre_row,
+                                                            const int32_t* __restrict__ pre_pos0) {
   typedef Elem<T> EL;
   typedef typename EL::frag frag;
   constexpr int E = EL::E, KS = EL::KS, NKS = HD / KS;
@@ -215,6 +219,12 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const T* __restrict__
   const int cshift = (row_off && cache_shift) ? cache_shift[b] : 0;
   const int j0 = (pad && !row_off) ? pad[b] : 0;
   const T* base = qkv + (int64_t)rbeg * 3 * D;
+  // prefix form (pkc != NULL, packed rows only): the element's sequence is  pl cached keys | its S rows of qkv; only the S
+  // rows are queries (query q sits at sequence position pl + q), and key j < pl is read from the cache row pre_row[b] at
+  // position pre_pos0[b] + j.  Key tiles are cut from sequence position 0, exactly as if the prefix rows were part of qkv.
+  const int pl = pkc != nullptr ? pre_len[b] : 0;
+  const int64_t pbase = pkc != nullptr ? (((int64_t)pre_row[b] * H + h) * smax + pre_pos0[b]) * HD : 0;
+  const int Stot = pl + S;
 
   frag qf[NKS];
   {
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const T* __restrict__
 #pragma unroll
   for (int j = 0; j < 4; ++j) { m[j] = -INFINITY; l[j] = 0.f; }
 
-  const int jend = min(S, q0 + 64);
+  const int jend = min(Stot, pl + q0 + 64);
   for (int jt = (j0 / 64) * 64; jt < jend; jt += 64) {
     __syncthreads();
     // ---- stage K rows and V^T (and append to the cache when this workgroup owns the tile)
@@ -238,8 +248,11 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const T* __restrict__
       const int kk = ch / CPR, dc = ch - kk * CPR;
       const int key = jt + kk;
       frag kv = zero_frag<frag>(), vv = zero_frag<frag>();
-      if (key < S) {
-        const T* src = base + (int64_t)key * 3 * D + D + h * HD + dc * E;
+      if (key < pl) {
+        kv = ld16<frag>(pkc + pbase + (int64_t)key * HD + dc * E);
+        vv = ld16<frag>(pvc + pbase + (int64_t)key * HD + dc * E);
+      } else if (key < Stot) {
+        const T* src = base + (int64_t)(key - pl) * 3 * D + D + h * HD + dc * E;
         kv = ld16<frag>(src);
         vv = ld16<frag>(src + D);
         if (kc != nullptr && jt == q0) {
@@ -269,12 +282,12 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const T* __restrict__
     float rmax[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int q = q0 + wave * 16 + 4 * g + j;
+      const int q = pl + q0 + wave * 16 + 4 * g + j;   // sequence position of the query
       float mx = -INFINITY;
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         const int key = jt + 16 * n + c;
-        const bool vis = (key <= q) && (key >= j0) && (key < S);
+        const bool vis = (key <= q) && (key >= j0) && (key < Stot);
         const float v = vis ? sacc[n][j] * 0.125f : -INFINITY;
         sacc[n][j] = v;
         mx = fmaxf(mx, v);
@@ -378,7 +391,9 @@ extern "C" int itts_attn_decode(const void* q, const void* kcache, const void* v
 }
 
 static int attn_prefill_impl(const void* qkv, void* out, void* kcache, void* vcache, const int32_t* pad, int B, int S, int H,
-                             int smax, int dtype, const int32_t* row_off, const int32_t* cache_shift, void* stream) {
+                             int smax, int dtype, const int32_t* row_off, const int32_t* cache_shift, void* stream,
+                             const void* pkc = nullptr, const void* pvc = nullptr, const int32_t* pre_len = nullptr,
+                             const int32_t* pre_row = nullptr, const int32_t* pre_pos0 = nullptr) {
   ITTS_REQUIRE(qkv && out, "itts_attn_prefill: null pointer");
   ITTS_REQUIRE((kcache == nullptr) == (vcache == nullptr), "itts_attn_prefill: pass both caches or neither");
   ITTS_REQUIRE(B > 0 && S > 0 && H > 0 && (!kcache || S <= smax), "itts_attn_prefill: bad shape B=%d S=%d H=%d smax=%d", B, S, H, smax);
@@ -387,13 +402,16 @@ static int attn_prefill_impl(const void* qkv, void* out, void* kcache, void* vca
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
     case ITTS_F32:
-      hipLaunchKernelGGL(attn_prefill_kernel<float>, grid, block, 0, s, (const float*)qkv, (float*)out, (float*)kcache, (float*)vcache, pad, S, H, smax, row_off, cache_shift);
+      hipLaunchKernelGGL(attn_prefill_kernel<float>, grid, block, 0, s, (const float*)qkv, (float*)out, (float*)kcache, (float*)vcache, pad, S, H, smax, row_off, cache_shift,
+                         (const float*)pkc, (const float*)pvc, pre_len, pre_row, pre_pos0);
       break;
     case ITTS_BF16:
-      hipLaunchKernelGGL(attn_prefill_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, (bf16_t*)kcache, (bf16_t*)vcache, pad, S, H, smax, row_off, cache_shift);
+      hipLaunchKernelGGL(attn_prefill_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, (bf16_t*)kcache, (bf16_t*)vcache, pad, S, H, smax, row_off, cache_shift,
+                         (const bf16_t*)pkc, (const bf16_t*)pvc, pre_len, pre_row, pre_pos0);
       break;
     case ITTS_F16:
-      hipLaunchKernelGGL(attn_prefill_kernel<f16_t>, grid, block, 0, s, (const f16_t*)qkv, (f16_t*)out, (f16_t*)kcache, (f16_t*)vcache, pad, S, H, smax, row_off, cache_shift);
+      hipLaunchKernelGGL(attn_prefill_kernel<f16_t>, grid, block, 0, s, (const f16_t*)qkv, (f16_t*)out, (f16_t*)kcache, (f16_t*)vcache, pad, S, H, smax, row_off, cache_shift,
+                         (const f16_t*)pkc, (const f16_t*)pvc, pre_len, pre_row, pre_pos0);
       break;
     default:
       ITTS_REQUIRE(false, "itts_attn_prefill: unknown dtype %d", dtype);
@@ -404,6 +422,14 @@ static int attn_prefill_impl(const void* qkv, void* out, void* kcache, void* vca
 extern "C" int itts_attn_prefill(const void* qkv, void* out, void* kcache, void* vcache, const int32_t* pad, int B, int S,
                                  int H, int smax, int dtype, void* stream) {
   return attn_prefill_impl(qkv, out, kcache, vcache, pad, B, S, H, smax, dtype, nullptr, nullptr, stream);
+}
+
+extern "C" int itts_attn_prefill_prefix(const void* qkv, void* out, const void* kcache, const void* vcache, const int32_t* row_off,
+                                        const int32_t* pre_len, const int32_t* pre_row, const int32_t* pre_pos0, int B, int Smax,
+                                        int H, int smax, int dtype, void* stream) {
+  ITTS_REQUIRE(row_off && kcache && vcache && pre_len && pre_row && pre_pos0, "itts_attn_prefill_prefix: null pointer");
+  return attn_prefill_impl(qkv, out, nullptr, nullptr, nullptr, B, Smax, H, smax, dtype, row_off, nullptr, stream, kcache, vcache,
+                           pre_len, pre_row, pre_pos0);
 }
 
 extern "C" int itts_attn_prefill_packed(const void* qkv, void* out, void* kcache, void* vcache, const int32_t* row_off,

@@ -94,6 +94,8 @@ _SIGNATURES = {
                                     C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_attn_prefill_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "itts_attn_prefill_prefix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_sample": (C.c_int, [C.POINTER(SampleArgs), C.c_void_p]),
     "itts_beam_step": (C.c_int, [C.POINTER(BeamArgs), C.c_void_p]),
     "itts_beam_kv_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -323,6 +325,15 @@ def attn_prefill_packed(qkv, out, kcache, vcache, row_off, cache_shift, B, Smax,
     """Packed rows (no padding): row_off int32 [B+1]; cache row of local row i = cache_shift[b] + i."""
     _check(lib().itts_attn_prefill_packed(_p(qkv), _p(out), _p(kcache), _p(vcache), _p(row_off), _p(cache_shift), B, Smax, H,
                                           smax, dt(qkv.dtype), _stream()), "itts_attn_prefill_packed")
+
+
+def attn_prefill_prefix(qkv, out, kcache, vcache, row_off, pre_len, pre_row, pre_pos0, B, Smax, H, smax):
+    """Packed query rows behind a cached prefix: element b = pre_len[b] keys of cache row pre_row[b] from position pre_pos0[b],
+    then its rows of qkv (see include/indextts_hip.h)."""
+    if not (kcache.is_contiguous() and vcache.is_contiguous()):
+        raise NativeError("itts_attn_prefill_prefix: the caches must be contiguous [rows][H][smax][64] views")
+    _check(lib().itts_attn_prefill_prefix(_p(qkv), _p(out), _p(kcache), _p(vcache), _p(row_off), _p(pre_len), _p(pre_row),
+                                          _p(pre_pos0), B, Smax, H, smax, dt(qkv.dtype), _stream()), "itts_attn_prefill_prefix")
 
 
 def sample(logits, tokens, history, finished, state, extra_ids, force_stop, rep_penalty, temperature, top_k, top_p,

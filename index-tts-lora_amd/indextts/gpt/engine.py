@@ -325,10 +325,9 @@ class GPTEngine:
         prefill() cached.  In cond | text | mel the causal mask lets no prompt position see a mel position, so the prompt's
         keys and values in every layer are exactly what prefill() computed for the decode loop -- same kernels, same inputs,
         bit for bit -- and they are still in the KV cache at positions [pad_b, P) (the decode loop only appends behind them).
-        Only the mel rows (start, codes, stop: ~60 % of the sequence) go through the GEMMs and LayerNorms; per layer their
-        q | k | v rows are scattered into the full packed layout, the prompt's K / V rows are gathered from the cache beside
-        them (its q rows stay zero: those outputs are never read), the flash-attention kernel runs over the full layout as in
-        latent(), and the mel rows of its output are gathered back.  Same bits as latent() on the whole sequence
+        Only the mel rows (start, codes, stop: ~60 % of the sequence) go through the GEMMs, LayerNorms and attention queries;
+        the flash-attention kernel reads the prompt's K / V tiles from the cache rows and the mel rows' from this pass's qkv,
+        with its key tiles cut from sequence position 0 as in latent().  Same bits as latent() on the whole sequence
         (tests/test_engines_gpu.py::test_latent_pass_reuses_the_cached_prompt).
         mel_emb fp32 [sum(m_lens), D]: the mel segments' embeddings, elements in prefill order; cache_rows: the cache row that
         holds element b's prompt (default b; b * num_beams after a beam prefill that copied rows).
@@ -342,36 +341,23 @@ class GPTEngine:
         pads = [self._pad_host[r] for r in cache_rows]   # (a prefill of expanded beam rows lists the padding per cache row)
         pl = [P - p for p in pads]                        # real prompt rows per element
         m = [int(v) for v in m_lens]
-        off = np.concatenate([[0], np.cumsum([a + b for a, b in zip(pl, m)])]).astype(np.int64)
-        idx_mel = np.concatenate([off[b] + pl[b] + np.arange(m[b]) for b in range(B)])
-        idx_pre = np.concatenate([off[b] + np.arange(pl[b]) for b in range(B)])
-        bidx = np.concatenate([np.full(pl[b], cache_rows[b]) for b in range(B)])
-        pidx = np.concatenate([pads[b] + np.arange(pl[b]) for b in range(B)])
-        Mm, Mp, Mf = int(idx_mel.size), int(idx_pre.size), int(off[-1])
-        packed = torch.from_numpy(np.concatenate([idx_mel, idx_pre, bidx, pidx, off]).astype(np.int64)).to(dev)   # one upload
-        i_mel, i_pre, i_b, i_p = packed[:Mm], packed[Mm:Mm + Mp], packed[Mm + Mp:Mm + 2 * Mp], packed[Mm + 2 * Mp:Mm + 3 * Mp]
-        row_off = packed[Mm + 3 * Mp:].to(torch.int32)
-        Smax = max(a + b for a, b in zip(pl, m))
+        off = np.concatenate([[0], np.cumsum(m)])
+        Mm = int(off[-1])
         if mel_emb.shape[0] != Mm:
             raise ValueError("latent_mel_rows(): mel_emb does not hold sum(m_lens) rows")
-        # the prompt's K / V of all layers in two gathers: [L, Mp, H, 64] views of the cache
-        kp = self.kc[:, i_b, :, i_p].permute(1, 0, 2, 3)
-        vp = self.vc[:, i_b, :, i_p].permute(1, 0, 2, 3)
+        meta = torch.from_numpy(np.concatenate([off, pl, cache_rows, pads]).astype(np.int32)).to(dev)   # one upload
+        row_off, pre_len, pre_row, pre_pos0 = meta[: B + 1], meta[B + 1:2 * B + 1], meta[2 * B + 1:3 * B + 1], meta[3 * B + 1:]
         h = mel_emb.to(dev, torch.float32).contiguous()
         xn = torch.empty(Mm, D, dtype=T, device=dev)
-        qkv_m = torch.empty(Mm, 3 * D, dtype=T, device=dev)
+        qkv = torch.empty(Mm, 3 * D, dtype=T, device=dev)
+        att = torch.empty(Mm, D, dtype=T, device=dev)
         ff = torch.empty(Mm, 4 * D, dtype=T, device=dev)
-        qkv_f = torch.zeros(Mf, 3, D, dtype=T, device=dev)
-        att_f = torch.empty(Mf, D, dtype=T, device=dev)
         for i, l in enumerate(self.layers):
             nat.layernorm(h, l["ln1"][0], l["ln1"][1], xn)
-            nat.gemm_conv(T, 1, Mm, Mm, D, 3 * D, l["w_qkv"], xn, qkv_m, bias=l["b_qkv"])
-            qkv_f.view(Mf, 3 * D).index_copy_(0, i_mel, qkv_m)
-            qkv_f[i_pre, 1] = kp[i].reshape(Mp, D)
-            qkv_f[i_pre, 2] = vp[i].reshape(Mp, D)
-            nat.attn_prefill_packed(qkv_f.view(Mf, 3 * D), att_f, None, None, row_off, None, B, Smax, H, self._cap_s)
-            att_m = att_f.index_select(0, i_mel)
-            nat.gemm_conv(T, 1, Mm, Mm, D, D, l.get("w_o_merged", l["w_o"]), att_m, h, bias=l["b_o"], y_f32=True, resid=h)
+            nat.gemm_conv(T, 1, Mm, Mm, D, 3 * D, l["w_qkv"], xn, qkv, bias=l["b_qkv"])
+            # the prompt's keys / values straight from the decode cache (itts_attn_prefill_prefix), the mel rows' from qkv
+            nat.attn_prefill_prefix(qkv, att, self.kc[i], self.vc[i], row_off, pre_len, pre_row, pre_pos0, B, max(m), H, self._cap_s)
+            nat.gemm_conv(T, 1, Mm, Mm, D, D, l.get("w_o_merged", l["w_o"]), att, h, bias=l["b_o"], y_f32=True, resid=h)
             nat.layernorm(h, l["ln2"][0], l["ln2"][1], xn)
             nat.gemm_conv(T, 1, Mm, Mm, D, 4 * D, l["w_fc"], xn, ff, bias=l["b_fc"], act=1)
             nat.gemm_conv(T, 1, Mm, Mm, 4 * D, D, l.get("w_pr_merged", l["w_pr"]), ff, h, bias=l["b_pr"], y_f32=True, resid=h)

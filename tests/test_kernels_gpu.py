@@ -792,6 +792,41 @@ def test_attn_decode_row_table_shared_prefix(nat, nb):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attn_prefill_prefix_equals_packed_rows_with_the_prefix_inside(nat, dtype):
+    """itts_attn_prefill_prefix (query rows behind keys / values that live in a KV cache, at any row and offset of it) gives,
+    bit for bit, the rows itts_attn_prefill_packed gives when the prefix's k / v rows are part of qkv -- prefix lengths 0,
+    short, a multiple of the 64-key tile and long; query counts below and above one 64-row tile; cache rows permuted."""
+    B, H, smax = 4, 3, 256
+    D = H * 64
+    pre = [0, 37, 128, 201]          # cached keys per element
+    mq = [70, 5, 64, 131]            # query rows per element
+    pos0 = [0, 11, 3, 40]            # cache position of the first prefix key
+    crow = [2, 0, 3, 1]              # cache row that holds it
+    tot = [a + b for a, b in zip(pre, mq)]
+    full = rnd(sum(tot), 3 * D, seed=97).to(dtype)
+    off_f = np.concatenate([[0], np.cumsum(tot)])
+    out_f = torch.empty(sum(tot), D, dtype=dtype, device=DEV)
+    nat.attn_prefill_packed(full, out_f, None, None, torch.tensor(off_f, dtype=torch.int32, device=DEV), None, B, max(tot), H, smax)
+    kc = rnd(B, H, smax, 64, seed=98).to(dtype)     # noise everywhere else: nothing outside the prefix may be read
+    vc = rnd(B, H, smax, 64, seed=99).to(dtype)
+    q_rows = []
+    for b in range(B):
+        blk = full[off_f[b]: off_f[b + 1]].view(tot[b], 3, H, 64)
+        kc[crow[b], :, pos0[b]: pos0[b] + pre[b]] = blk[: pre[b], 1].transpose(0, 1)
+        vc[crow[b], :, pos0[b]: pos0[b] + pre[b]] = blk[: pre[b], 2].transpose(0, 1)
+        q_rows.append(torch.arange(off_f[b] + pre[b], off_f[b + 1]))
+    q_rows = torch.cat(q_rows).to(DEV)
+    qkv = full[q_rows].contiguous()
+    qkv.view(-1, 3, D)[:, 0]                          # (queries of the prefix rows are not needed at all)
+    out = torch.empty(qkv.shape[0], D, dtype=dtype, device=DEV)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)   # noqa: E731
+    nat.attn_prefill_prefix(qkv, out, kc, vc, i32(np.concatenate([[0], np.cumsum(mq)])), i32(pre), i32(crow), i32(pos0), B, max(mq),
+                            H, smax)
+    assert torch.isfinite(out.float()).all()
+    assert torch.equal(out, out_f[q_rows])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_attn_prefill_packed_equals_left_padded(nat, dtype):
     """Packed rows (no padding rows at all) give the attention outputs and the KV cache contents of the left-padded form
     for every real position."""
