@@ -530,7 +530,7 @@ def main():
     for _ in range(32):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        conds = tts.gpt.get_conditioning(cond_mel, None)
+        conds = tts._prompt_conds(cond_mel)              # the product path: Conformer + Perceiver as one graph replay
         _, emb, mask = tts.gpt.prepare_gpt_inputs(conds, batch_tokens)
         tts.gpt.engine.prefill(emb, (mask == 0).sum(1).to(torch.int32), 4)
         tts.gpt.engine._sample(BATCH, sp)

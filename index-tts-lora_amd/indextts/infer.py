@@ -198,6 +198,7 @@ class IndexTTS:
         r = copy.copy(self)
         r.gpt = self.gpt.replica()
         r.cache_audio_prompt = r.cache_cond_mel = r._cache_conds = r._cache_spk = r._batch_feat = None
+        r._feat_graphs = {}       # captured graphs replay into their own static buffers: one set per instance
         return r
 
     # ------------------------------------------------------------------------------------------------ helpers
@@ -307,36 +308,45 @@ class IndexTTS:
             self._cache_conds = self._cache_spk = None
         return self.cache_cond_mel
 
-    def _prompt_features(self, cond_mel):
-        """(conditioning latents [1,32,D], speaker embedding [1,1,512]) of a prompt mel.  The two host-side PyTorch
-        networks are a few hundred small launches; for a given prompt length they are captured once into a CUDA graph
-        and replayed (first call runs eagerly as warm-up; any capture failure falls back to eager execution)."""
-        key = tuple(cond_mel.shape)
+    def _graphed(self, name, fn, cond_mel):
+        """fn(prompt mel) through a CUDA graph per (network, prompt shape): the host-side PyTorch networks are a few hundred
+        small launches each; the first call runs eagerly as warm-up, the second captures, later ones replay (any capture
+        failure falls back to eager execution)."""
+        key = (name,) + tuple(cond_mel.shape)
         ent = self._feat_graphs.get(key)
         if ent is None:
             self._feat_graphs[key] = "warm"
-            lens = torch.full((cond_mel.shape[0],), cond_mel.shape[-1], device=self.device)
-            return self.gpt.get_conditioning(cond_mel, lens), self.bigvgan.speaker_embedding(cond_mel.transpose(1, 2))
+            return fn(cond_mel)
         if ent == "warm":
             try:
                 static_mel = cond_mel.clone()
-                lens = torch.full((cond_mel.shape[0],), cond_mel.shape[-1], device=self.device)
                 g = torch.cuda.CUDAGraph()
                 with nat.CAPTURE_LOCK, torch.cuda.graph(g):
-                    conds = self.gpt.get_conditioning(static_mel, lens)
-                    spk = self.bigvgan.speaker_embedding(static_mel.transpose(1, 2))
-                ent = (g, static_mel, conds, spk, lens)  # lens is read by the captured kernels: keep it alive
+                    out = fn(static_mel)
+                ent = (g, static_mel, out)
             except Exception as e:  # noqa: BLE001
                 warnings.warn(f"prompt-feature graph capture failed ({e}); running eagerly", RuntimeWarning)
                 ent = "eager"
             self._feat_graphs[key] = ent
         if ent == "eager":
-            lens = torch.full((cond_mel.shape[0],), cond_mel.shape[-1], device=self.device)
-            return self.gpt.get_conditioning(cond_mel, lens), self.bigvgan.speaker_embedding(cond_mel.transpose(1, 2))
-        g, static_mel, conds, spk, _ = ent
+            return fn(cond_mel)
+        g, static_mel, out = ent
         static_mel.copy_(cond_mel)
         g.replay()
-        return conds.clone(), spk.clone()
+        return out.clone()
+
+    def _prompt_conds(self, cond_mel):
+        """Conditioning latents [1, 32, D] of a prompt mel (Conformer + Perceiver): all the first token needs."""
+        return self._graphed("conds", lambda m: self.gpt.get_conditioning(
+            m, torch.full((m.shape[0],), m.shape[-1], device=self.device)), cond_mel)
+
+    def _prompt_spk(self, cond_mel):
+        """Speaker embedding [1, 1, 512] of a prompt mel (ECAPA-TDNN): only the vocoder needs it."""
+        return self._graphed("spk", lambda m: self.bigvgan.speaker_embedding(m.transpose(1, 2)), cond_mel)
+
+    def _prompt_features(self, cond_mel):
+        """(conditioning latents, speaker embedding) of a prompt mel."""
+        return self._prompt_conds(cond_mel), self._prompt_spk(cond_mel)
 
     def _conds(self, cond_mel, speaker_id=None):
         """Conditioning latents of the call.  The reference passes BOTH the prompt mel and speaker_ids=[speaker_id] to
@@ -598,7 +608,8 @@ class IndexTTS:
         group of equal-length utterances (batching unequal lengths would change the tail of the shorter waveforms).
         Returns a list of fp32 waveforms already scaled to the int16 range, like infer.py:892.
         phase_events, if given, receives torch.cuda.Event marks at the phase boundaries."""
-        st = self._batch_tokens(cond_mel, text_token_rows, max_mel_tokens, force_stop, seed, phase_events, **generation_kwargs)
+        st = self._batch_tokens(cond_mel, text_token_rows, max_mel_tokens, force_stop, seed, phase_events, lazy_spk=True,
+                                **generation_kwargs)
         outs = self._batch_waveforms(st, phase_events, reuse_prefix=True)   # serial: the KV cache still holds this batch's prompt
         return (outs, st["rows"]) if return_codes else outs
 
@@ -624,7 +635,9 @@ class IndexTTS:
             conds, spk = bf[2], bf[3]
         else:
             conds, spk = self._prompt_features(cond_mel)
-            self._batch_feat = (cond_mel, cond_mel._version, conds, spk)
+            self._batch_feat = [cond_mel, cond_mel._version, conds, spk]
+        if spk is None:
+            spk = self._batch_feat[3] = self._prompt_spk(cond_mel)
         g, eng = self.gpt, self.gpt.engine
         N = len(text_token_rows)
         texts = [t.reshape(-1).to(torch.int32).cpu() for t in text_token_rows]
@@ -695,7 +708,7 @@ class IndexTTS:
             phase_events[name] = e
 
     def _batch_tokens(self, cond_mel, text_token_rows, max_mel_tokens=600, force_stop=None, seed=1234, phase_events=None,
-                      **generation_kwargs):
+                      lazy_spk=False, **generation_kwargs):
         """Stage A of infer_batch: prompt conditioning -> prefill -> sampling loop -> silence squeeze (host).  Everything
         here is latency-bound small launches; it ends with the codes on the host, as infer.py:848-861 does."""
         gen, _ = self._gen_kwargs(generation_kwargs)
@@ -707,8 +720,10 @@ class IndexTTS:
         if bf is not None and bf[0] is cond_mel and bf[1] == cond_mel._version:
             conds, spk = bf[2], bf[3]
         else:
-            conds, spk = self._prompt_features(cond_mel)
-            self._batch_feat = (cond_mel, cond_mel._version, conds, spk)
+            # the token loop needs the conditioning latents only; the speaker embedding (ECAPA, vocoder input) is computed
+            # when stage B asks for it (lazy_spk) -- it is not on the first token's critical path
+            conds, spk = self._prompt_conds(cond_mel), (None if lazy_spk else self._prompt_spk(cond_mel))
+            self._batch_feat = [cond_mel, cond_mel._version, conds, spk]
         L = max(int(t.numel()) for t in text_token_rows)
         stop = self.cfg.gpt.stop_text_token
         batch_h = torch.full((len(text_token_rows), L), stop, dtype=torch.int32)
@@ -747,13 +762,19 @@ class IndexTTS:
         # where the latent pass finds each element's prompt in the KV cache: row b, or row b * num_beams when the beam prefill
         # expanded the rows (beam_kv = "copy")
         crows = [b * nb for b in range(len(rows))] if nb > 1 and g.engine.beam_kv != "table" else None
-        return dict(conds=conds, spk=spk, rows=rows, texts=[t.reshape(-1) for t in text_token_rows], cache_rows=crows)
+        return dict(conds=conds, spk=spk, rows=rows, texts=[t.reshape(-1) for t in text_token_rows], cache_rows=crows,
+                    cond_mel=cond_mel)
 
     def _batch_waveforms(self, st, phase_events=None, reuse_prefix=False):
         """Stage B of infer_batch: batched teacher-forced latent pass + vocoder (large MFMA-bound launches, no host sync).
         With reuse_prefix = False it touches no decode-loop state, so it may run on another stream beside the next batch's
         stage A (BatchPipeline, whose prefill overwrites the KV cache: it must not reuse the prompt's keys / values)."""
         conds, spk = st["conds"], st["spk"]
+        if spk is None:                                   # lazy_spk: first batch of this prompt
+            spk = self._prompt_spk(st["cond_mel"])
+            bf = self._batch_feat
+            if bf is not None and bf[0] is st["cond_mel"] and bf[2] is conds:
+                bf[3] = spk
         lat = self._latents(conds, st["texts"], st["rows"], reuse_prefix=reuse_prefix, cache_rows=st.get("cache_rows"))
         self._mark(phase_events, "latents")
         outs = self._vocode_ragged(lat, spk)
