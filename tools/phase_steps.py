@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase split (HIP events) of several consecutive bench steps -- BASELINE config 3 through IndexTTS.infer_batch.
-usage: phase_steps.py [steps]   (ITTS_PREFETCH etc. from the environment).  Appends to gpurun_out/phase_steps.txt"""
+usage: phase_steps.py [steps]   (engine knobs such as ITTS_KSPLIT come from the environment).  Appends to gpurun_out/phase_steps.txt"""
 import contextlib
 import os
 import sys
