@@ -29,11 +29,14 @@ def _lin(x, W, p):
     return F.linear(x, W[p + ".weight"], W.get(p + ".bias"))
 
 
-def conformer_encode(W: dict, mel_btf: torch.Tensor, lengths: torch.Tensor, heads: int = 8, prefix="conditioning_encoder."):
-    """mel_btf [B,T,100], lengths [B] -> (x [B,T',512], mask [B,1,T'] bool)."""
+def conformer_encode(W: dict, mel_btf: torch.Tensor, lengths, heads: int = 8, prefix="conditioning_encoder."):
+    """mel_btf [B,T,100], lengths [B] -> (x [B,T',512], mask [B,1,T'] bool).
+    lengths = None: every row is T frames long (one prompt, or prompts of one length) -- there is no padding, the mask
+    operations of the general form are identities and are left out (same values, ~50 launches fewer); mask is returned as None."""
     B, T, _ = mel_btf.shape
     dev = mel_btf.device
-    mask = (torch.arange(T, device=dev)[None, :] < lengths.to(dev)[:, None])[:, None, :]
+    full = lengths is None
+    mask = None if full else (torch.arange(T, device=dev)[None, :] < lengths.to(dev)[:, None])[:, None, :]
     # Conv2dSubsampling2
     # Conv2d(1, C, 3, stride 2) as unfold + matmul (a [T'*F', 9] x [9, C] product)
     w0 = W[prefix + "embed.conv.0.weight"]
@@ -43,14 +46,24 @@ def conformer_encode(W: dict, mel_btf: torch.Tensor, lengths: torch.Tensor, head
     b, c = x.shape[0], x.shape[1]
     x = x.view(b, c, t, f)
     x = _lin(x.transpose(1, 2).reshape(b, t, c * f), W, prefix + "embed.out.0")
-    mask = mask[:, :, 2::2]
+    if not full:
+        mask = mask[:, :, 2::2]
     d = x.shape[-1]
     x = x * math.sqrt(d)
-    pos = sinusoid_table(t, d, dev, x.dtype)[None]
     dk = d // heads
     n = 0
     while f"{prefix}encoders.{n}.norm_mha.weight" in W:
         n += 1
+    # the sinusoid table and its per-layer projection depend on t and the weights only: computed once, outside any captured graph
+    # (kept inside the weight dict itself, so they live and die with these weights)
+    const = W.setdefault(("const", prefix), {})
+    ck = (t, x.dtype, str(dev))
+    if ck not in const and not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+        pos = sinusoid_table(t, d, dev, x.dtype)[None]
+        const[ck] = [F.linear(pos, W[f"{prefix}encoders.{i}.self_attn.linear_pos.weight"]).view(1, t, heads, dk).transpose(1, 2)
+                     for i in range(n)]
+    pps = const.get(ck)
+    pos = None if pps is not None else sinusoid_table(t, d, dev, x.dtype)[None]
     for i in range(n):
         p = f"{prefix}encoders.{i}."
         # --- rel-pos self attention
@@ -58,18 +71,22 @@ def conformer_encode(W: dict, mel_btf: torch.Tensor, lengths: torch.Tensor, head
         q = _lin(y, W, p + "self_attn.linear_q").view(B, t, heads, dk)
         k = _lin(y, W, p + "self_attn.linear_k").view(B, t, heads, dk).transpose(1, 2)
         v = _lin(y, W, p + "self_attn.linear_v").view(B, t, heads, dk).transpose(1, 2)
-        pp = F.linear(pos, W[p + "self_attn.linear_pos.weight"]).view(1, t, heads, dk).transpose(1, 2)
+        pp = pps[i] if pps is not None else F.linear(pos, W[p + "self_attn.linear_pos.weight"]).view(1, t, heads, dk).transpose(1, 2)
         qu = (q + W[p + "self_attn.pos_bias_u"]).transpose(1, 2)
         qv = (q + W[p + "self_attn.pos_bias_v"]).transpose(1, 2)
         sc = (qu @ k.transpose(-1, -2) + qv @ pp.transpose(-1, -2)) / math.sqrt(dk)
-        km = ~mask[:, None]  # [B,1,1,T'] True = padded
-        sc = sc.masked_fill(km, float("-inf"))
-        att = torch.softmax(sc, dim=-1).masked_fill(km, 0.0)
+        if full:
+            att = torch.softmax(sc, dim=-1)
+        else:
+            km = ~mask[:, None]  # [B,1,1,T'] True = padded
+            sc = sc.masked_fill(km, float("-inf"))
+            att = torch.softmax(sc, dim=-1).masked_fill(km, 0.0)
         y = (att @ v).transpose(1, 2).reshape(B, t, d)
         x = x + _lin(y, W, p + "self_attn.linear_out")
         # --- convolution module
         y = _ln(x, W, p + "norm_conv").transpose(1, 2)
-        y = y.masked_fill(~mask, 0.0)
+        if not full:
+            y = y.masked_fill(~mask, 0.0)
         y = F.glu(torch.matmul(W[p + "conv_module.pointwise_conv1.weight"][:, :, 0], y)
                   + W[p + "conv_module.pointwise_conv1.bias"][None, :, None], dim=1)
         wd = W[p + "conv_module.depthwise_conv.weight"]                                # [C, 1, k] depthwise
@@ -79,7 +96,8 @@ def conformer_encode(W: dict, mel_btf: torch.Tensor, lengths: torch.Tensor, head
         y = F.silu(_ln(y.transpose(1, 2), W, p + "conv_module.norm")).transpose(1, 2)
         y = torch.matmul(W[p + "conv_module.pointwise_conv2.weight"][:, :, 0], y) \
             + W[p + "conv_module.pointwise_conv2.bias"][None, :, None]
-        y = y.masked_fill(~mask, 0.0)
+        if not full:
+            y = y.masked_fill(~mask, 0.0)
         x = x + y.transpose(1, 2)
         # --- feed forward
         y = _ln(x, W, p + "norm_ff")

@@ -116,12 +116,12 @@ class UnifiedVoice:
         mel = speech_conditioning_input.to(self.device, torch.float32)
         if mel.ndim == 2:
             mel = mel[None]
-        if cond_mel_lengths is None:
-            cond_mel_lengths = torch.full((mel.shape[0],), mel.shape[-1], device=self.device)
         W = self._cond_weights()
-        x, mask = conformer_encode(W, mel.transpose(1, 2), cond_mel_lengths.to(self.device),
+        # cond_mel_lengths = None: every row is as long as the tensor (model.py:491 builds exactly that) -- no padding, the
+        # mask operations of the two networks are identities and are skipped
+        x, mask = conformer_encode(W, mel.transpose(1, 2), None if cond_mel_lengths is None else cond_mel_lengths.to(self.device),
                                    heads=int(self.condition_module.get("attention_heads", 8)))
-        cmask = F.pad(mask.squeeze(1), (self.cond_num, 0), value=True)
+        cmask = None if mask is None else F.pad(mask.squeeze(1), (self.cond_num, 0), value=True)
         return perceiver_resample(W, x, cmask, heads=int(self.condition_module.get("attention_heads", 8)))
 
     def prepare_gpt_inputs(self, conditional_latents, text_inputs):

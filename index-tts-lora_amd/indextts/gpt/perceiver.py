@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 
 def perceiver_resample(W: dict, ctx: torch.Tensor, ctx_mask: torch.Tensor, heads: int = 8, prefix="perceiver_encoder."):
-    """ctx [B,T',512], ctx_mask [B,32+T'] bool (True = attend) -> conds [B,32,1280]."""
+    """ctx [B,T',512], ctx_mask [B,32+T'] bool (True = attend; None = attend everywhere) -> conds [B,32,1280]."""
     B = ctx.shape[0]
     if prefix + "proj_context.weight" in W:
         ctx = F.linear(ctx, W[prefix + "proj_context.weight"], W[prefix + "proj_context.bias"])
@@ -25,7 +25,8 @@ def perceiver_resample(W: dict, ctx: torch.Tensor, ctx_mask: torch.Tensor, heads
         dh = q.shape[-1] // heads
         q, k, v = (t.view(B, -1, heads, dh).transpose(1, 2) for t in (q, k, v))
         sim = (q @ k.transpose(-1, -2)) * dh ** -0.5
-        sim = sim.masked_fill(~ctx_mask[:, None, None, :], -torch.finfo(sim.dtype).max)
+        if ctx_mask is not None:                          # None: nothing is padded
+            sim = sim.masked_fill(~ctx_mask[:, None, None, :], -torch.finfo(sim.dtype).max)
         o = (torch.softmax(sim, dim=-1) @ v).transpose(1, 2).reshape(B, -1, heads * dh)
         lat = lat + F.linear(o, W[p + "0.to_out.weight"])
         h = F.linear(lat, W[p + "1.0.weight"], W[p + "1.0.bias"])

@@ -337,8 +337,7 @@ class IndexTTS:
 
     def _prompt_conds(self, cond_mel):
         """Conditioning latents [1, 32, D] of a prompt mel (Conformer + Perceiver): all the first token needs."""
-        return self._graphed("conds", lambda m: self.gpt.get_conditioning(
-            m, torch.full((m.shape[0],), m.shape[-1], device=self.device)), cond_mel)
+        return self._graphed("conds", lambda m: self.gpt.get_conditioning(m, None), cond_mel)   # None: rows are T frames long
 
     def _prompt_spk(self, cond_mel):
         """Speaker embedding [1, 1, 512] of a prompt mel (ECAPA-TDNN): only the vocoder needs it."""
