@@ -669,6 +669,8 @@ class GPTEngine:
             items, n_join = [], n + check_every if staged else n
             if free and not fed_out and n > 1:
                 items = list(feed(len(free)))
+                if len(items) > len(free):
+                    raise ValueError(f"decode_refill(): feed({len(free)}) returned {len(items)} items")
                 if len(items) < len(free):
                     fed_out = True
                 if items and limit - (S + n_join + 1) < max_new + check_every:    # steps the loop could still take

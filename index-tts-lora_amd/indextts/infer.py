@@ -628,6 +628,10 @@ class IndexTTS:
         gen, _ = self._gen_kwargs(generation_kwargs)
         if int(gen.get("num_beams", 1)) != 1:
             raise NotImplementedError("infer_queue: num_beams = 1 only (beam rows cannot be refilled one at a time)")
+        if not text_token_rows:
+            return ([], []) if return_codes else []
+        if int(slots) < 1:
+            raise ValueError("infer_queue: slots must be >= 1")
         self._mark(phase_events, "start")
         bf = self._batch_feat
         if bf is not None and bf[0] is cond_mel and bf[1] == cond_mel._version:
