@@ -582,6 +582,15 @@ def test_infer_queue_equals_utterances_synthesised_one_by_one():
             assert torch.equal(codes[i].long().cpu(), c.long().cpu()), (cache, i, codes[i], c)
             assert outs[i].shape == w.shape
             assert (outs[i] - w).abs().max().item() <= 1e-3 * max(1.0, w.abs().max().item()), (cache, i)
+    # sampling: the loop's Philox stream is keyed by (slot, loop step) -- reproducible for a seed, different between seeds
+    sgen = dict(do_sample=True, top_k=30, top_p=0.8, temperature=1.0, repetition_penalty=10.0, num_beams=1)
+    runs = [tts.infer_queue(cond_mel, texts, slots=3, max_mel_tokens=20, force_stop=stops, return_codes=True, seed=sd, **sgen)
+            for sd in (5, 5, 6)]
+    for i in range(7):
+        assert torch.equal(runs[0][1][i], runs[1][1][i]) and torch.equal(runs[0][0][i], runs[1][0][i])
+        assert runs[0][1][i].numel() == stops[i] and runs[0][0][i].numel() == stops[i] * 1024
+    assert any(not torch.equal(runs[0][1][i], runs[2][1][i]) for i in range(7))
+    assert tts.infer_queue(cond_mel, [], slots=3, num_beams=1) == []
     with pytest.raises(NotImplementedError):
         tts.infer_queue(cond_mel, texts, slots=3, num_beams=3)
 
