@@ -48,7 +48,7 @@ extern "C" {
 #define ITTS_BF16 1
 #define ITTS_F16 2
 
-#define ITTS_ABI_VERSION 6 /* 6: per-row clocks (row_step0) in itts_embed_step / itts_sample_args (slot refill), itts_attn_prefill_prefix; 5: itts_ln_reduce takes up to 6 slabs */
+#define ITTS_ABI_VERSION 6 /* 6: per-row clocks (row_step0) in itts_embed_step / itts_sample_args (slot refill), itts_attn_prefill_prefix / _shared; 5: itts_ln_reduce takes up to 6 slabs */
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -262,6 +262,18 @@ int itts_attn_prefill_packed(const void* qkv, void* out, void* kcache, void* vca
 int itts_attn_prefill_prefix(const void* qkv, void* out, const void* kcache, const void* vcache, const int32_t* row_off,
                              const int32_t* pre_len, const int32_t* pre_row, const int32_t* pre_pos0, int B, int Smax, int H,
                              int smax, int dtype, void* stream);
+
+/* Packed rows behind a prefix that is SHARED and computed in the same pass (the prefill of a batch whose elements all start
+ * with the same conditioning latents, model.py:606-667 with one prompt: those rows see only themselves, so their hidden states
+ * are the same in every element and are computed once).  Element e of the E packed elements owns rows [row_off[e],
+ * row_off[e+1]) of qkv / out; its sequence is  pre_len[e] keys taken from qkv rows pre_row0[e] .. pre_row0[e] + pre_len[e] - 1
+ * (k / v thirds of those rows)  |  its own rows.  pre_len[e] = 0 for the shared block itself.  Same key tiling from sequence
+ * position 0 as itts_attn_prefill_packed over the un-shared layout: same bits per row.  With caches (T [rows][H][smax][64]),
+ * element e's OWN rows are appended to cache row w_row[e] at positions w_pos0[e] + local row (the caller copies the shared
+ * block's cache rows to the other elements' cache rows). */
+int itts_attn_prefill_shared(const void* qkv, void* out, void* kcache, void* vcache, const int32_t* row_off,
+                             const int32_t* pre_len, const int32_t* pre_row0, const int32_t* w_row, const int32_t* w_pos0,
+                             int E, int Smax, int H, int smax, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Token selection for one decode step, on device (no host sync in the loop).

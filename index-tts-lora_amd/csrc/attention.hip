@@ -197,7 +197,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const T* __restrict__
                                                             const T* __restrict__ pkc, const T* __restrict__ pvc,
                                                             const int32_t* __restrict__ pre_len,
                                                             const int32_t* __restrict__ pre_row,
-                                                            const int32_t* __restrict__ pre_pos0) {
+                                                            const int32_t* __restrict__ pre_pos0, int pre_qkv,
+                                                            T* wkc, T* wvc, const int32_t* __restrict__ w_row,
+                                                            const int32_t* __restrict__ w_pos0) {
   typedef Elem<T> EL;
   typedef typename EL::frag frag;
   constexpr int E = EL::E, KS = EL::KS, NKS = HD / KS;
@@ -222,9 +224,27 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const T* __restrict__
   // prefix form (pkc != NULL, packed rows only): the element's sequence is  pl cached keys | its S rows of qkv; only the S
   // rows are queries (query q sits at sequence position pl + q), and key j < pl is read from the cache row pre_row[b] at
   // position pre_pos0[b] + j.  Key tiles are cut from sequence position 0, exactly as if the prefix rows were part of qkv.
+  // pre_qkv != 0: the prefix keys are ROWS OF qkv instead (rows pre_pos0[b] .. of the packed buffer: a block that several
+  // elements share, computed once in this very pass); pkc / pvc then point at the k / v thirds of qkv.
   const int pl = pkc != nullptr ? pre_len[b] : 0;
-  const int64_t pbase = pkc != nullptr ? (((int64_t)pre_row[b] * H + h) * smax + pre_pos0[b]) * HD : 0;
+  const int64_t pstr = pre_qkv ? (int64_t)3 * D : HD;
+  const int64_t pbase = pkc == nullptr ? 0
+                        : pre_qkv      ? (int64_t)pre_pos0[b] * 3 * D + h * HD
+                                       : (((int64_t)pre_row[b] * H + h) * smax + pre_pos0[b]) * HD;
   const int Stot = pl + S;
+  // cache append of the prefix form: this workgroup's own 64 rows go to cache row w_row[b], positions w_pos0[b] + local row
+  if (wkc != nullptr) {
+    const int64_t wbase = (((int64_t)w_row[b] * H + h) * smax + w_pos0[b]) * HD;
+    for (int ch = tid; ch < 64 * CPR; ch += 256) {
+      const int kk = ch / CPR, dc = ch - kk * CPR;
+      const int q = q0 + kk;
+      if (q < S) {
+        const T* src = base + (int64_t)q * 3 * D + D + h * HD + dc * E;
+        st16(wkc + wbase + (int64_t)q * HD + dc * E, ld16<frag>(src));
+        st16(wvc + wbase + (int64_t)q * HD + dc * E, ld16<frag>(src + D));
+      }
+    }
+  }
 
   frag qf[NKS];
   {
@@ -249,8 +269,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const T* __restrict__
       const int key = jt + kk;
       frag kv = zero_frag<frag>(), vv = zero_frag<frag>();
       if (key < pl) {
-        kv = ld16<frag>(pkc + pbase + (int64_t)key * HD + dc * E);
-        vv = ld16<frag>(pvc + pbase + (int64_t)key * HD + dc * E);
+        kv = ld16<frag>(pkc + pbase + (int64_t)key * pstr + dc * E);
+        vv = ld16<frag>(pvc + pbase + (int64_t)key * pstr + dc * E);
       } else if (key < Stot) {
         const T* src = base + (int64_t)(key - pl) * 3 * D + D + h * HD + dc * E;
         kv = ld16<frag>(src);
@@ -393,7 +413,9 @@ extern "C" int itts_attn_decode(const void* q, const void* kcache, const void* v
 static int attn_prefill_impl(const void* qkv, void* out, void* kcache, void* vcache, const int32_t* pad, int B, int S, int H,
                              int smax, int dtype, const int32_t* row_off, const int32_t* cache_shift, void* stream,
                              const void* pkc = nullptr, const void* pvc = nullptr, const int32_t* pre_len = nullptr,
-                             const int32_t* pre_row = nullptr, const int32_t* pre_pos0 = nullptr) {
+                             const int32_t* pre_row = nullptr, const int32_t* pre_pos0 = nullptr, int pre_qkv = 0,
+                             void* wkc = nullptr, void* wvc = nullptr, const int32_t* w_row = nullptr,
+                             const int32_t* w_pos0 = nullptr) {
   ITTS_REQUIRE(qkv && out, "itts_attn_prefill: null pointer");
   ITTS_REQUIRE((kcache == nullptr) == (vcache == nullptr), "itts_attn_prefill: pass both caches or neither");
   ITTS_REQUIRE(B > 0 && S > 0 && H > 0 && (!kcache || S <= smax), "itts_attn_prefill: bad shape B=%d S=%d H=%d smax=%d", B, S, H, smax);
@@ -403,15 +425,15 @@ static int attn_prefill_impl(const void* qkv, void* out, void* kcache, void* vca
   switch (dtype) {
     case ITTS_F32:
       hipLaunchKernelGGL(attn_prefill_kernel<float>, grid, block, 0, s, (const float*)qkv, (float*)out, (float*)kcache, (float*)vcache, pad, S, H, smax, row_off, cache_shift,
-                         (const float*)pkc, (const float*)pvc, pre_len, pre_row, pre_pos0);
+                         (const float*)pkc, (const float*)pvc, pre_len, pre_row, pre_pos0, pre_qkv, (float*)wkc, (float*)wvc, w_row, w_pos0);
       break;
     case ITTS_BF16:
       hipLaunchKernelGGL(attn_prefill_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, (bf16_t*)kcache, (bf16_t*)vcache, pad, S, H, smax, row_off, cache_shift,
-                         (const bf16_t*)pkc, (const bf16_t*)pvc, pre_len, pre_row, pre_pos0);
+                         (const bf16_t*)pkc, (const bf16_t*)pvc, pre_len, pre_row, pre_pos0, pre_qkv, (bf16_t*)wkc, (bf16_t*)wvc, w_row, w_pos0);
       break;
     case ITTS_F16:
       hipLaunchKernelGGL(attn_prefill_kernel<f16_t>, grid, block, 0, s, (const f16_t*)qkv, (f16_t*)out, (f16_t*)kcache, (f16_t*)vcache, pad, S, H, smax, row_off, cache_shift,
-                         (const f16_t*)pkc, (const f16_t*)pvc, pre_len, pre_row, pre_pos0);
+                         (const f16_t*)pkc, (const f16_t*)pvc, pre_len, pre_row, pre_pos0, pre_qkv, (f16_t*)wkc, (f16_t*)wvc, w_row, w_pos0);
       break;
     default:
       ITTS_REQUIRE(false, "itts_attn_prefill: unknown dtype %d", dtype);
@@ -430,6 +452,19 @@ extern "C" int itts_attn_prefill_prefix(const void* qkv, void* out, const void* 
   ITTS_REQUIRE(row_off && kcache && vcache && pre_len && pre_row && pre_pos0, "itts_attn_prefill_prefix: null pointer");
   return attn_prefill_impl(qkv, out, nullptr, nullptr, nullptr, B, Smax, H, smax, dtype, row_off, nullptr, stream, kcache, vcache,
                            pre_len, pre_row, pre_pos0);
+}
+
+extern "C" int itts_attn_prefill_shared(const void* qkv, void* out, void* kcache, void* vcache, const int32_t* row_off,
+                                        const int32_t* pre_len, const int32_t* pre_row0, const int32_t* w_row,
+                                        const int32_t* w_pos0, int E, int Smax, int H, int smax, int dtype, void* stream) {
+  ITTS_REQUIRE(qkv && row_off && pre_len && pre_row0 && (kcache == nullptr) == (vcache == nullptr) &&
+                   (kcache == nullptr || (w_row && w_pos0)), "itts_attn_prefill_shared: null pointer");
+  const int D = H * 64;
+  const int es = dtype == ITTS_F32 ? 4 : 2;
+  const char* q = (const char*)qkv;
+  return attn_prefill_impl(qkv, out, nullptr, nullptr, nullptr, E, Smax, H, smax, dtype, row_off, nullptr, stream,
+                           q + (int64_t)D * es, q + (int64_t)2 * D * es, pre_len, pre_len /* unused */, pre_row0, 1, kcache, vcache,
+                           w_row, w_pos0);
 }
 
 extern "C" int itts_attn_prefill_packed(const void* qkv, void* out, void* kcache, void* vcache, const int32_t* row_off,

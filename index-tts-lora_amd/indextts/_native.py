@@ -96,6 +96,8 @@ _SIGNATURES = {
                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_attn_prefill_prefix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "itts_attn_prefill_shared": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_sample": (C.c_int, [C.POINTER(SampleArgs), C.c_void_p]),
     "itts_beam_step": (C.c_int, [C.POINTER(BeamArgs), C.c_void_p]),
     "itts_beam_kv_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -334,6 +336,16 @@ def attn_prefill_prefix(qkv, out, kcache, vcache, row_off, pre_len, pre_row, pre
         raise NativeError("itts_attn_prefill_prefix: the caches must be contiguous [rows][H][smax][64] views")
     _check(lib().itts_attn_prefill_prefix(_p(qkv), _p(out), _p(kcache), _p(vcache), _p(row_off), _p(pre_len), _p(pre_row),
                                           _p(pre_pos0), B, Smax, H, smax, dt(qkv.dtype), _stream()), "itts_attn_prefill_prefix")
+
+
+def attn_prefill_shared(qkv, out, kcache, vcache, row_off, pre_len, pre_row0, w_row, w_pos0, E, Smax, H, smax):
+    """Packed elements behind a prefix block that lives in qkv itself (computed once, shared); own rows appended to the caches
+    (see include/indextts_hip.h)."""
+    if kcache is not None and not (kcache.is_contiguous() and vcache.is_contiguous()):
+        raise NativeError("itts_attn_prefill_shared: the caches must be contiguous [rows][H][smax][64] views")
+    _check(lib().itts_attn_prefill_shared(_p(qkv), _p(out), _p(kcache), _p(vcache), _p(row_off), _p(pre_len), _p(pre_row0),
+                                          _p(w_row), _p(w_pos0), E, Smax, H, smax, dt(qkv.dtype), _stream()),
+           "itts_attn_prefill_shared")
 
 
 def sample(logits, tokens, history, finished, state, extra_ids, force_stop, rep_penalty, temperature, top_k, top_p,

@@ -94,6 +94,7 @@ class GPTEngine:
         # workgroups of TWO tiles, whose waves fetch each activation fragment once for both (a third less load traffic per CU)
         self.KSPLIT = int(os.environ.get("ITTS_KSPLIT", "3"))
         self.force_eager = False  # measurement aid: launch every kernel eagerly
+        self.share_prefix = os.environ.get("ITTS_SHARE_PREFIX", "1") != "0"   # prefill(shared_rows=C): compute the shared rows once
         self.steps_per_graph = int(os.environ.get("ITTS_STEPS_PER_GRAPH", "1"))  # decode tokens per CUDA-graph replay; measured 1 > 2 > 4 > 8 (1297 / 1319 / 1342 / 1368 us per token)
         self._sink = torch.zeros(4, dtype=torch.int32, device=dev)
         # arrival counters of the reducer tails: one per split-K launch site (2 per block), monotonic, never reset by the
@@ -243,12 +244,69 @@ class GPTEngine:
         nat.gemm_skinny(self.dtype, B, self.V, self.D, self.w_head, self.b_head, x=self.xn, epi=nat.EPI_STORE_F32,
                         yf=self.logits, x_packed=self.pa)
 
-    def prefill(self, prefix_emb: torch.Tensor, pad: torch.Tensor, max_new: int, beams: int = 1):
+    def _prefill_shared(self, emb, pad_h, S, C):
+        """The packed prefill pass for a batch whose elements all begin with the SAME C rows (one prompt's conditioning
+        latents: no position embedding is added to them and they see only themselves, so their hidden states, keys and values
+        are the same in every element).  Those C rows go through the blocks ONCE; every element contributes only its own rows
+        (text + start token), whose attention reads the shared block's keys / values out of the same qkv buffer
+        (itts_attn_prefill_shared: key tiles cut from sequence position 0 as in the un-shared pass, same bits per row).  The
+        kernel appends every element's own rows to its cache row; the shared block's cache rows are copied to the other
+        elements afterwards (one gather / scatter over all layers).  Returns the hidden states of the elements' last rows."""
+        import numpy as np
+        T, D, H, dev = self.dtype, self.D, self.H, self.device
+        B = emb.shape[0]
+        own = [S - p - C for p in pad_h]                     # rows of each element behind the shared block
+        if min(own) < 1:
+            raise ValueError("prefill(shared_rows): an element has no row of its own behind the shared block")
+        off = np.concatenate([[0, C], C + np.cumsum(own)]).astype(np.int64)
+        M = int(off[-1])
+        idx = np.concatenate([pad_h[0] + np.arange(C)] + [b * S + pad_h[b] + C + np.arange(own[b]) for b in range(B)])
+        dst_b = np.repeat(np.arange(1, B), C)
+        dst_p = np.concatenate([pad_h[b] + np.arange(C) for b in range(1, B)]) if B > 1 else np.zeros(0, np.int64)
+        meta = torch.from_numpy(np.concatenate([
+            idx, off, [0] + [C] * B, np.zeros(B + 1, np.int64), [0] + list(range(B)), [pad_h[0]] + [p + C for p in pad_h],
+            off[2:] - 1, dst_b, dst_p]).astype(np.int64)).to(dev)                                           # one upload
+        E = B + 1
+        o = 0
+
+        def take(n, as32=True):
+            nonlocal o
+            t = meta[o:o + n]
+            o += n
+            return t.to(torch.int32) if as32 else t
+        i_rows, row_off = take(M, False), take(E + 1)
+        pre_len, pre_row0, w_row, w_pos0 = take(E), take(E), take(E), take(E)
+        last_rows, i_db, i_dp = take(B, False), take((B - 1) * C, False), take((B - 1) * C, False)
+        h = emb.view(B * S, D)[i_rows]
+        xn = torch.empty(M, D, dtype=T, device=dev)
+        qkv = torch.empty(M, 3 * D, dtype=T, device=dev)
+        att = torch.empty(M, D, dtype=T, device=dev)
+        ff = torch.empty(M, 4 * D, dtype=T, device=dev)
+        Smax = max(C, max(own))
+        for i, l in enumerate(self.layers):
+            nat.layernorm(h, l["ln1"][0], l["ln1"][1], xn)
+            nat.gemm_conv(T, 1, M, M, D, 3 * D, l["w_qkv"], xn, qkv, bias=l["b_qkv"])
+            nat.attn_prefill_shared(qkv, att, self.kc[i], self.vc[i], row_off, pre_len, pre_row0, w_row, w_pos0, E, Smax, H,
+                                    self._cap_s)
+            nat.gemm_conv(T, 1, M, M, D, D, l.get("w_o_merged", l["w_o"]), att, h, bias=l["b_o"], y_f32=True, resid=h)
+            nat.layernorm(h, l["ln2"][0], l["ln2"][1], xn)
+            nat.gemm_conv(T, 1, M, M, D, 4 * D, l["w_fc"], xn, ff, bias=l["b_fc"], act=1)
+            nat.gemm_conv(T, 1, M, M, 4 * D, D, l.get("w_pr_merged", l["w_pr"]), ff, h, bias=l["b_pr"], y_f32=True, resid=h)
+        if B > 1:   # the shared block's keys / values: cache row 0 -> the same sequence positions of every other cache row
+            p0 = pad_h[0]
+            self.kc[:, i_db, :, i_dp] = self.kc[:, 0, :, p0:p0 + C].permute(2, 0, 1, 3).repeat(B - 1, 1, 1, 1)
+            self.vc[:, i_db, :, i_dp] = self.vc[:, 0, :, p0:p0 + C].permute(2, 0, 1, 3).repeat(B - 1, 1, 1, 1)
+        return h[last_rows].contiguous()
+
+    def prefill(self, prefix_emb: torch.Tensor, pad: torch.Tensor, max_new: int, beams: int = 1, shared_rows: int = 0):
         """prefix_emb fp32 [B,P,D] (left-padded with zeros), pad int [B].  Runs prefix + start token (mel position 0,
         model.py:152-162), fills the KV cache rows [pad_b, P] of every element, leaves logits of the last position in
         self.logits.  The left-padding rows are never computed: the real rows are packed (one gather), the GEMMs run over
         sum(P + 1 - pad_b) rows instead of B*(P+1), and the attention kernel writes each element's keys at its padded
         cache position, so the decode loop sees the reference's left-padded cache layout.
+        shared_rows = C > 0: the caller promises that the first C real rows of every element are THE SAME rows (one prompt's
+        conditioning latents, model.py:606-667 with a [1, C, D] conditioning tensor); they are then computed once for the
+        batch (_prefill_shared: same logits and cache contents, a third fewer GEMM rows at config 3's shape).
         beams > 1 (beam search with the row table): HF expands every row to `beams` identical rows BEFORE the first forward;
         here the prompt is computed and cached ONCE per batch element (cache rows 0..B-1) and decode_beam() points the table
         entries of all its beams at that copy -- a third of the prefill work and prompt cache at 3 beams, identical values
@@ -265,16 +323,20 @@ class GPTEngine:
         pad_h = [int(v) for v in torch.as_tensor(pad).tolist()]
         self._pad_host = pad_h             # latent_mel_rows() finds the prompt's K/V in the cache through it
         self.pad[:B] = torch.tensor(pad_h, dtype=torch.int32).to(dev)
-        lens = [S - p for p in pad_h]
-        off = [0]
-        for n in lens:
-            off.append(off[-1] + n)
-        idx = torch.cat([torch.arange(b * S + pad_h[b], (b + 1) * S) for b in range(B)])
-        meta = torch.tensor(off + [b_off - 1 for b_off in off[1:]], dtype=torch.int32).to(dev)   # row_off | last rows
-        row_off, last_rows = meta[: B + 1], meta[B + 1:].long()
-        h = emb.view(B * S, D)[idx.to(dev)]
-        h = self._blocks_full(h, B, S, None, True, row_off=row_off, cache_shift=self.pad[:B])
-        self._head(h[last_rows].contiguous(), B)
+        if shared_rows and B > 1 and self.share_prefix:
+            # every element starts with the same `shared_rows` rows (the caller's promise: one prompt's conditioning latents)
+            self._head(self._prefill_shared(emb, pad_h, S, int(shared_rows)), B)
+        else:
+            lens = [S - p for p in pad_h]
+            off = [0]
+            for n in lens:
+                off.append(off[-1] + n)
+            idx = torch.cat([torch.arange(b * S + pad_h[b], (b + 1) * S) for b in range(B)])
+            meta = torch.tensor(off + [b_off - 1 for b_off in off[1:]], dtype=torch.int32).to(dev)   # row_off | last rows
+            row_off, last_rows = meta[: B + 1], meta[B + 1:].long()
+            h = emb.view(B * S, D)[idx.to(dev)]
+            h = self._blocks_full(h, B, S, None, True, row_off=row_off, cache_shift=self.pad[:B])
+            self._head(h[last_rows].contiguous(), B)
         self.state.zero_()                 # step, cache position, finished rows, ..., tail epoch [6], tail error [7]
         self.tail_cnt.zero_()              # the reducer tails count from (epoch - 1) * workgroups: both restart together
         self.state[1] = S - 1

@@ -193,6 +193,7 @@ class UnifiedVoice:
         conds = self.get_conditioning(speech_conditioning_mel, cond_mel_lengths, speaker_ids=speaker_ids)
         _, emb, mask = self.prepare_gpt_inputs(conds, text_inputs)
         pad = (mask == 0).sum(dim=1).to(torch.int32)
+        shared = int(conds.shape[1]) if conds.shape[0] == 1 else 0   # one prompt: every row starts with the same latents
         max_new = (self.max_mel_tokens - 1) if max_generate_length is None else int(max_generate_length)
         if num_beams > 1:
             # generate() expands every row to num_beams identical rows before the first forward (beam search / beam-sample)
@@ -200,9 +201,9 @@ class UnifiedVoice:
                 raise NotImplementedError("force_stop / return_logits are measurement aids of the num_beams=1 loop")
             sp["length_penalty"] = length_penalty
             if self.engine.beam_kv == "table":   # prompt computed and cached once per batch element (row table)
-                self.engine.prefill(emb, pad, max_new, beams=num_beams)
+                self.engine.prefill(emb, pad, max_new, beams=num_beams, shared_rows=shared)
             else:
-                self.engine.prefill(emb.repeat_interleave(num_beams, dim=0), pad.repeat_interleave(num_beams), max_new)
+                self.engine.prefill(emb.repeat_interleave(num_beams, dim=0), pad.repeat_interleave(num_beams), max_new, shared_rows=shared)
             return self.engine.decode_beam(max_new, sp, num_beams, num_return_sequences=nrs)
         if nrs > 1:
             # sampling: generate() expands every row to num_return_sequences copies before the first forward
@@ -233,7 +234,7 @@ class UnifiedVoice:
                 remove_sorted = srt > srt.gather(1, last[:, None])
                 remove_sorted[:, :1] = False                                   # min_tokens_to_keep = 1 (no beams)
                 logits.masked_fill_(torch.zeros_like(remove_sorted).scatter(1, idx, remove_sorted), -1e30)
-        self.engine.prefill(emb, pad, max_new)
+        self.engine.prefill(emb, pad, max_new, shared_rows=shared)
         out = self.engine.decode(max_new, sp, force_stop=force_stop, return_logits=return_logits, logits_hook=hook)
         return out
 

@@ -375,6 +375,7 @@ class IndexTTS:
         g = self.gpt
         _, emb, mask = g.prepare_gpt_inputs(conds, text_tokens)
         pad = (mask == 0).sum(dim=1).to(torch.int32)
+        shared = int(conds.shape[1]) if conds.shape[0] == 1 else 0   # one prompt: every row starts with the same latents
         sp = dict(do_sample=bool(gen["do_sample"]), top_p=float(gen["top_p"]), top_k=int(gen["top_k"]),
                   temperature=float(gen["temperature"]), repetition_penalty=float(gen["repetition_penalty"]),
                   seed=int(extra.pop("seed", torch.initial_seed() & 0x7FFFFFFFFFFFFFFF)))
@@ -383,9 +384,9 @@ class IndexTTS:
         nb = int(gen.get("num_beams", 1))
         if nb > 1:  # beam search / beam-sample: every row becomes num_beams rows (HF generate semantics)
             sp["length_penalty"] = float(gen.get("length_penalty", 0.0))
-            g.engine.prefill(emb.repeat_interleave(nb, dim=0), pad.repeat_interleave(nb), max_mel_tokens)
+            g.engine.prefill(emb.repeat_interleave(nb, dim=0), pad.repeat_interleave(nb), max_mel_tokens, shared_rows=shared)
             return g.engine.decode_beam(max_mel_tokens, sp, nb)
-        g.engine.prefill(emb, pad, max_mel_tokens)
+        g.engine.prefill(emb, pad, max_mel_tokens, shared_rows=shared)
         return g.engine.decode(max_mel_tokens, sp, force_stop=extra.pop("force_stop", None))
 
     def _latents(self, conds, text_rows: List[torch.Tensor], code_rows: List[torch.Tensor], reuse_prefix=False, cache_rows=None):
@@ -666,7 +667,8 @@ class IndexTTS:
         while queue:
             first, queue = queue[:slots], queue[slots:]
             emb, pad = prefixes(first)
-            eng.prefill(emb, pad, max(max_mel_tokens + 2, int(cache_positions) - emb.shape[1] - 2))
+            eng.prefill(emb, pad, max(max_mel_tokens + 2, int(cache_positions) - emb.shape[1] - 2),
+                        shared_rows=int(conds.shape[1]) if conds.shape[0] == 1 else 0)
             entered = list(first)
 
             def feed(k):
@@ -744,18 +746,19 @@ class IndexTTS:
             sp["top_p"], sp["top_k"], sp["temperature"] = 1.0, 0, 1.0
         self._mark(phase_events, "conditioned")
         nb = int(gen.get("num_beams", 1))
+        shared = int(conds.shape[1]) if conds.shape[0] == 1 else 0   # one prompt: every row starts with the same latents
         if nb > 1:
             if force_stop is not None:
                 raise NotImplementedError("force_stop is a measurement aid of the num_beams=1 loop")
             sp["length_penalty"] = float(gen.get("length_penalty", 0.0))
             if g.engine.beam_kv == "table":    # the prompt is computed and cached once per batch element (row table)
-                g.engine.prefill(emb, pad, max_mel_tokens, beams=nb)
+                g.engine.prefill(emb, pad, max_mel_tokens, beams=nb, shared_rows=shared)
             else:                              # generate() expands every row to num_beams copies before the first forward
-                g.engine.prefill(emb.repeat_interleave(nb, dim=0), pad.repeat_interleave(nb), max_mel_tokens)
+                g.engine.prefill(emb.repeat_interleave(nb, dim=0), pad.repeat_interleave(nb), max_mel_tokens, shared_rows=shared)
             self._mark(phase_events, "prefilled")
             codes = g.engine.decode_beam(max_mel_tokens, sp, nb)
         else:
-            g.engine.prefill(emb, pad, max_mel_tokens)
+            g.engine.prefill(emb, pad, max_mel_tokens, shared_rows=shared)
             self._mark(phase_events, "prefilled")
             codes = g.engine.decode(max_mel_tokens, sp, force_stop=force_stop)
         self._mark(phase_events, "decoded")

@@ -490,6 +490,50 @@ def test_request_pool_matches_serial_infer_batch():
         RequestPool(insts, cu_masks=[even])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_prefill_computes_the_shared_conditioning_rows_once(dtype):
+    """prefill(shared_rows=32): the 32 conditioning latents every element of a one-prompt batch starts with go through the
+    blocks once, each element contributes only its text rows, their attention reads the shared block out of the same qkv
+    buffer.  Logits, the whole KV cache region the decode loop reads, and the decoded tokens are those of the plain packed
+    prefill, bit for bit -- mixed text lengths (different left paddings), also through the beam prefill (row table)."""
+    m = gpt_small_fp32_or(dtype)
+    eng = m.engine
+    rng = np.random.default_rng(31)
+    cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
+    conds = m.get_conditioning(cond_mel, None)
+    lens = [17, 3, 9, 12, 1]
+    L = max(lens)
+    text = torch.full((len(lens), L), m.stop_text_token, dtype=torch.int32)
+    for i, n in enumerate(lens):
+        text[i, :n] = torch.from_numpy(rng.integers(2, 12000, size=n)).to(torch.int32)
+    _, emb, mask = m.prepare_gpt_inputs(conds, text.to(DEV))
+    pad = (mask == 0).sum(1).to(torch.int32)
+    sp = dict(do_sample=False, top_p=1.0, top_k=0, temperature=1.0, repetition_penalty=10.0, seed=0)
+    B, S = emb.shape[0], emb.shape[1] + 1
+    got = {}
+    for shared in (0, 32):
+        eng._cap_b = eng._cap_s = 0                       # fresh (zeroed) caches for both runs
+        logits = eng.prefill(emb, pad, 12, shared_rows=shared).clone()
+        kc, vc = eng.kc[:, :B, :, :S].clone(), eng.vc[:, :B, :, :S].clone()
+        codes = eng.decode(12, sp)
+        got[shared] = (logits, kc, vc, codes.clone())
+    assert eng.share_prefix
+    for a, b in zip(got[0], got[32]):
+        assert torch.equal(a, b)
+    for b_, p_ in enumerate(pad.tolist()):                # (the comparison above is not vacuous: the prompt region is filled)
+        assert got[32][1][:, b_, :, p_:S].abs().sum().item() > 0 and got[32][1][:, b_, :, :p_].abs().sum().item() == 0
+    # beam prefill (prompt cached once per element, rows expanded afterwards) on top of it
+    outs = []
+    for shared in (0, 32):
+        eng.prefill(emb[:2], pad[:2], 10, beams=3, shared_rows=shared)
+        outs.append(eng.decode_beam(10, dict(sp, do_sample=True, top_k=30, top_p=0.8, length_penalty=0.0, seed=4), 3).clone())
+    assert torch.equal(outs[0], outs[1])
+
+
+def gpt_small_fp32_or(dtype):
+    return make_gpt(2, dtype)
+
+
 def test_decode_refill_gives_every_row_the_codes_it_gets_alone(gpt_small_fp32):
     """Continuous batching (GPTEngine.decode_refill; refills joined at once or staged on a second stream): 9 utterances of different text lengths and stop steps through 3 decode
     slots, greedy.  Every utterance's codes equal those of decoding it ALONE (inference_speech on one row) -- compared up to
