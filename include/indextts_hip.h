@@ -48,7 +48,7 @@ extern "C" {
 #define ITTS_BF16 1
 #define ITTS_F16 2
 
-#define ITTS_ABI_VERSION 6 /* 6: per-row clocks (row_step0) in itts_embed_step / itts_sample_args (slot refill), itts_attn_prefill_prefix / _shared; 5: itts_ln_reduce takes up to 6 slabs */
+#define ITTS_ABI_VERSION 6 /* 6: per-row clocks (row_step0) in itts_embed_step / itts_sample_args (slot refill), itts_attn_prefill_prefix / _shared, kv_share in itts_attn_decode; 5: itts_ln_reduce takes up to 6 slabs */
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -235,10 +235,14 @@ int itts_embed_step(const int32_t* tokens, const float* table, const float* pos_
  * Entries of different rows may name the SAME physical row (the beams of a batch element share their prompt and common
  * history; the engine caches the prompt once per batch element).
  * skip_rows (int32 [B] on the device or NULL): rows with a nonzero entry are left out (out[b] keeps its old contents) --
- * the decode loop passes its `finished` flags, a finished row's logits no longer matter. */
+ * the decode loop passes its `finished` flags, a finished row's logits no longer matter.
+ * kv_share (one int32 word on the device, or NULL): (p0 << 8) | C with C <= 255 -- a promise that the first C keys / values of
+ * every row, positions [pad[b], pad[b] + C), hold the same bytes as cache row 0's positions [p0, p0 + C) (a one-prompt
+ * batch's conditioning latents after itts_attn_prefill_shared); they are then read from row 0 (one L2-resident copy instead
+ * of B copies from HBM).  0 = no sharing.  Ignored with kv_rows. */
 int itts_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, const int32_t* pad,
                      const int32_t* pos, int B, int H, int smax, int dtype, int out_packed, const int32_t* kv_rows,
-                     const int32_t* kv_step, const int32_t* skip_rows, void* stream);
+                     const int32_t* kv_step, const int32_t* skip_rows, const int32_t* kv_share, void* stream);
 
 /* Causal self-attention over a whole (left-padded) sequence.  qkv: T [B][S][3*H*64] (q|k|v); out: T [B][S][H*64];
  * query i sees key j iff pad[b] <= j <= i; rows with no visible key produce zeros.  If kcache/vcache are non-NULL the

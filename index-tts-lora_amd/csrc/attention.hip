@@ -36,7 +36,8 @@ __global__ __launch_bounds__(NWV * 64) void attn_decode_kernel(const T* __restri
                                                            const int32_t* __restrict__ pad, const int32_t* __restrict__ pos,
                                                            int H, int smax, int out_mtp, const int32_t* __restrict__ kv_rows,
                                                            const int32_t* __restrict__ kv_step, int rows_total,
-                                                           const int32_t* __restrict__ skip_rows) {
+                                                           const int32_t* __restrict__ skip_rows,
+                                                           const int32_t* __restrict__ kv_share) {
   typedef Elem<T> EL;
   typedef typename EL::frag frag;
   constexpr int E = EL::E;
@@ -62,11 +63,19 @@ __global__ __launch_bounds__(NWV * 64) void attn_decode_kernel(const T* __restri
   // requests, no store.  A select, not an early return: a branch here makes the compiler sink the other scalar loads (and the
   // query load) below it, one more round trip each.
   const bool skipped = skip_rows != nullptr && skip_raw != 0;
+  // kv_share (one word, (p0 << 8) | C, or NULL / 0): the first C keys of EVERY row ([pad_b, pad_b + C): a one-prompt batch's
+  // conditioning latents) hold the same bytes as cache row 0's positions [p0, p0 + C) -- read them there: 32 rows x 20 heads
+  // then hit one L2-resident copy instead of streaming 32 copies from HBM (13 % of the K / V bytes at config 3's contexts).
+  const int32_t* share_ptr = kv_share != nullptr ? kv_share : pos;     // (a readable word either way, as for skip_rows)
+  const int share_raw = *share_ptr;
+  const int share_w = (kv_share != nullptr && !IND) ? share_raw : 0;
+  const int shC = share_w & 255;
   int pos0 = pos[0];
   asm volatile("" : "+s"(pos0));              // (keeps the load here: the compiler would otherwise load it only for rows that need it)
   const int ctx = skipped ? j0 : pos0 + 1;    // keys [j0, ctx)
   const T* kb = kc + ((int64_t)b * H + h) * smax * HD + part * E;
   const T* vb = vc + ((int64_t)b * H + h) * smax * HD + part * E;
+  const int64_t sh_off = ((int64_t)h * smax + (share_w >> 8)) * HD + part * E;   // row 0, head h, position p0
   const int32_t* tab = nullptr;
   if constexpr (IND) tab = kv_rows + ((int64_t)(kv_step[0] & 1) * rows_total + b) * smax;
 
@@ -96,8 +105,16 @@ __global__ __launch_bounds__(NWV * 64) void attn_decode_kernel(const T* __restri
       int j = min(base + (i * NWV + wave) * RPW + rg, ctx - 1);
       int64_t ro = (int64_t)j * HD;
       if constexpr (IND) ro += (int64_t)(prow[i] - b) * H * smax * HD;   // same head, same position, another row
-      kf[i] = ld16<frag>(kb + ro);
-      vf[i] = ld16<frag>(vb + ro);
+      const T* kp = kb + ro;
+      const T* vp = vb + ro;
+      if constexpr (!IND) {
+        const bool sh = (unsigned)(j - j0) < (unsigned)shC;   // a select, not a branch (also false for j < j0: skipped rows)
+        const int64_t so = sh_off + (int64_t)(j - j0) * HD;
+        kp = sh ? kc + so : kp;
+        vp = sh ? vc + so : vp;
+      }
+      kf[i] = ld16<frag>(kp);
+      vf[i] = ld16<frag>(vp);
     }
     __builtin_amdgcn_sched_barrier(0);   // every K AND V request of the pass is out before anything waits
     if constexpr (FIRST) {
@@ -375,7 +392,7 @@ namespace itts { constexpr int g_attn_waves = 4; }  // measured equal to 8; the 
 
 extern "C" int itts_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, const int32_t* pad,
                                 const int32_t* pos, int B, int H, int smax, int dtype, int out_packed, const int32_t* kv_rows,
-                                const int32_t* kv_step, const int32_t* skip_rows, void* stream) {
+                                const int32_t* kv_step, const int32_t* skip_rows, const int32_t* kv_share, void* stream) {
   const int out_mtp = out_packed ? (B + 15) / 16 : 0;
   ITTS_REQUIRE(q && kcache && vcache && out && pad && pos, "itts_attn_decode: null pointer");
   ITTS_REQUIRE(B > 0 && H > 0 && smax > 0 && smax <= AD_MAXCTX, "itts_attn_decode: bad shape B=%d H=%d smax=%d (max %d)", B, H,
@@ -386,7 +403,7 @@ extern "C" int itts_attn_decode(const void* q, const void* kcache, const void* v
   const bool ind = kv_rows != nullptr;
 #define ITTS_AD(TT_, NW_, IND_)                                                                                             \
   hipLaunchKernelGGL((attn_decode_kernel<TT_, NW_, IND_>), grid, block, 0, s, (const TT_*)q, (const TT_*)kcache,           \
-                     (const TT_*)vcache, (TT_*)out, pad, pos, H, smax, out_mtp, kv_rows, kv_step, B, skip_rows)
+                     (const TT_*)vcache, (TT_*)out, pad, pos, H, smax, out_mtp, kv_rows, kv_step, B, skip_rows, kv_share)
 #define ITTS_AD_T(TT_)                                                            \
   do {                                                                            \
     if (g_attn_waves == 8) { if (ind) ITTS_AD(TT_, 8, true); else ITTS_AD(TT_, 8, false); } \

@@ -311,11 +311,14 @@ def embed_step(tokens, table, pos_table, step, pos_add, h, epoch=None, row_step0
                                  _stream()), "itts_embed_step")
 
 
-def attn_decode(q, kcache, vcache, out, pad, pos, B, H, smax, out_packed=False, kv_rows=None, kv_step=None, skip_rows=None):
+def attn_decode(q, kcache, vcache, out, pad, pos, B, H, smax, out_packed=False, kv_rows=None, kv_step=None, skip_rows=None,
+                kv_share=None):
     """kv_rows int32 [2][B][smax] + kv_step (device word): beam-search row table instead of permuted cache rows.
-    skip_rows int32 [B]: rows with a nonzero entry are left out (their slice of `out` is not written)."""
+    skip_rows int32 [B]: rows with a nonzero entry are left out (their slice of `out` is not written).
+    kv_share (device word (p0 << 8) | C): the first C keys of every row equal cache row 0's positions [p0, p0 + C)."""
     _check(lib().itts_attn_decode(_p(q), _p(kcache), _p(vcache), _p(out), _p(pad), _p(pos), B, H, smax, dt(q.dtype),
-                                  int(bool(out_packed)), _p(kv_rows), _p(kv_step), _p(skip_rows), _stream()), "itts_attn_decode")
+                                  int(bool(out_packed)), _p(kv_rows), _p(kv_step), _p(skip_rows), _p(kv_share), _stream()),
+           "itts_attn_decode")
 
 
 def attn_prefill(qkv, out, kcache, vcache, pad, B, S, H, smax):

@@ -95,6 +95,7 @@ class GPTEngine:
         self.KSPLIT = int(os.environ.get("ITTS_KSPLIT", "3"))
         self.force_eager = False  # measurement aid: launch every kernel eagerly
         self.share_prefix = os.environ.get("ITTS_SHARE_PREFIX", "1") != "0"   # prefill(shared_rows=C): compute the shared rows once
+        self.share_kv_reads = os.environ.get("ITTS_SHARE_KV_READS", "1") != "0"   # ... and let the decode attention read them from row 0
         self.steps_per_graph = int(os.environ.get("ITTS_STEPS_PER_GRAPH", "1"))  # decode tokens per CUDA-graph replay; measured 1 > 2 > 4 > 8 (1297 / 1319 / 1342 / 1368 us per token)
         self._sink = torch.zeros(4, dtype=torch.int32, device=dev)
         # arrival counters of the reducer tails: one per split-K launch site (2 per block), monotonic, never reset by the
@@ -207,6 +208,7 @@ class GPTEngine:
         self.pad = torch.zeros(B, dtype=torch.int32, device=dev)
         self.force_stop = torch.full((B,), -1, dtype=torch.int32, device=dev)
         self.row_step0 = torch.zeros(B, dtype=torch.int32, device=dev)   # loop step at which each row started (decode_refill)
+        self.kv_share = torch.zeros(1, dtype=torch.int32, device=dev)    # (p0 << 8) | C: rows' first C keys == row 0's at p0 (itts_attn_decode)
         self.state = torch.zeros(8, dtype=torch.int32, device=dev)
         self.history = torch.zeros(B, 2048, dtype=torch.int32, device=dev)
         self._cap_b, self._cap_s = B, smax
@@ -323,9 +325,13 @@ class GPTEngine:
         pad_h = [int(v) for v in torch.as_tensor(pad).tolist()]
         self._pad_host = pad_h             # latent_mel_rows() finds the prompt's K/V in the cache through it
         self.pad[:B] = torch.tensor(pad_h, dtype=torch.int32).to(dev)
+        self.kv_share.zero_()
         if shared_rows and B > 1 and self.share_prefix:
             # every element starts with the same `shared_rows` rows (the caller's promise: one prompt's conditioning latents)
             self._head(self._prefill_shared(emb, pad_h, S, int(shared_rows)), B)
+            if beams == 1 and int(shared_rows) <= 255 and self.share_kv_reads:
+                # the decode attention reads those rows' keys / values from cache row 0 for every row (same bytes, one copy in L2)
+                self.kv_share.fill_((pad_h[0] << 8) | int(shared_rows))
         else:
             lens = [S - p for p in pad_h]
             off = [0]
@@ -474,7 +480,8 @@ class GPTEngine:
                             vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s, x_packed=pa)
             nat.attn_decode(self.q, self.kc[i], self.vc[i], self.a, self.pad, pos, B, H, self._cap_s, out_packed=pa,
                             kv_rows=self._kv_rows, kv_step=step if self._kv_rows is not None else None,
-                            skip_rows=self.finished if self._kv_rows is None and self.skip_finished else None)
+                            skip_rows=self.finished if self._kv_rows is None and self.skip_finished else None,
+                            kv_share=self.kv_share if self._kv_rows is None else None)
             nxt = self.ln_f if last else self.layers[i + 1]["ln1"]
             nxt2 = self.final_norm if last else None
             if tail:
@@ -704,6 +711,7 @@ class GPTEngine:
         fs = [max_new - 1 if v < 0 else min(v, max_new - 1) for v in fs]
         self.force_stop[:B] = torch.tensor(fs, dtype=torch.int32).to(dev)
         sp = self._seed_to_state(sp)
+        self.kv_share.zero_()                                # a refilled row 0 no longer holds the shared block where the others expect it
         owner, start = list(range(B)), [0] * B              # owner: utterance id | None (free) | -1 (reserved for staged rows)
         next_id, codes, leftover, fed_out = B, {}, [], False
         stats = self.refill_stats = {"steps": 0, "polls": 0, "refill_calls": 0, "rows_refilled": 0, "staged": bool(staged)}

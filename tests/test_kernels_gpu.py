@@ -330,6 +330,45 @@ def test_gemm_conv_plain_gemm_residual(nat, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attn_decode_reads_the_shared_first_keys_from_row_zero(nat, dtype):
+    """kv_share = (p0 << 8) | C: the first C keys / values of every row are taken from cache row 0, positions [p0, p0 + C).
+    With the rows' own copies holding the same bytes the output does not change by a bit (rows with different left paddings,
+    a row whose context is shorter than C, a skipped row); with row 0's copy altered every other row's output changes
+    (the copy really is what is read) while a zero word reads the rows' own copies again."""
+    B, H, smax, pos, C = 6, 4, 320, 300, 32
+    q = rnd(B, H * 64, seed=170).to(dtype)
+    kc = rnd(B, H, smax, 64, seed=171).to(dtype)
+    vc = rnd(B, H, smax, 64, seed=172).to(dtype)
+    pads = [7, 0, 100, 255, 290, 40]                       # row 4: context 11 < C
+    p0 = pads[0]
+    for b in range(1, B):
+        n = min(C, pos + 1 - pads[b])
+        kc[b, :, pads[b]:pads[b] + n] = kc[0, :, p0:p0 + n]
+        vc[b, :, pads[b]:pads[b] + n] = vc[0, :, p0:p0 + n]
+    pad = torch.tensor(pads, dtype=torch.int32, device=DEV)
+    posd = torch.tensor([pos], dtype=torch.int32, device=DEV)
+    skip = torch.tensor([0, 0, 0, 0, 0, 1], dtype=torch.int32, device=DEV)
+    word = torch.tensor([(p0 << 8) | C], dtype=torch.int32, device=DEV)
+    zero = torch.zeros(1, dtype=torch.int32, device=DEV)
+    outs = []
+    for share in (None, zero, word):
+        o = torch.full((B, H * 64), 7.0, dtype=dtype, device=DEV)
+        nat.attn_decode(q, kc, vc, o, pad, posd, B, H, smax, skip_rows=skip, kv_share=share)
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert (outs[2][5] == 7.0).all() and torch.isfinite(outs[2].float()).all()
+    kc2, vc2 = kc.clone(), vc.clone()
+    kc2[0, :, p0:p0 + C] += 1.0                            # only row 0's copy changes
+    o2 = torch.empty_like(outs[0])
+    nat.attn_decode(q, kc2, vc2, o2, pad, posd, B, H, smax, kv_share=word)
+    for b in range(1, 5):
+        assert not torch.equal(o2[b], outs[0][b])
+    o3 = torch.empty_like(outs[0])
+    nat.attn_decode(q, kc2, vc2, o3, pad, posd, B, H, smax, kv_share=zero)
+    assert torch.equal(o3[1:5], outs[0][1:5])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("smax,pos", [(200, 150), (900, 777), (64, 0)])
 def test_attn_decode(nat, dtype, smax, pos):
     B, H = 5, 20
