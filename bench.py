@@ -25,7 +25,21 @@ import time
 # leg keeps four requests in flight, each on its own stream; with four queues two of those streams end up sharing one and
 # the leg measures two-deep concurrency (1 400 instead of 1 740 audio-s/s, profiles/r03_pool_cu_masks.txt).  `value` (one
 # request at a time) is the same either way.  Read by the runtime at its initialisation, i.e. after this line.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Only for the one-process run that has that leg: several processes sharing ONE GPU with 8 queues each oversubscribe the
+# hardware's queue slots and time-slice (the 2-ranks-on-1-GPU rehearsal fell from 1 443 to 407 audio-s/s with it).
+def _single_process_run():
+    if os.environ.get("WORLD_SIZE", "1") != "1":
+        return False
+    for i, a in enumerate(sys.argv):
+        if a == "--gpus" and i + 1 < len(sys.argv):
+            return sys.argv[i + 1] == "1"
+        if a.startswith("--gpus="):
+            return a.split("=", 1)[1] == "1"
+    return True
+
+
+if _single_process_run():
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "index-tts-lora_amd"), os.path.join(ROOT, "tests")):
