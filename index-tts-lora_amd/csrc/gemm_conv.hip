@@ -722,6 +722,170 @@ static int launch_plain(const ConvParams& p, hipStream_t s) {
 }
 
 // -------------------------------------------------------------------------------------------------------------------
+// Plain GEMM, large tile (round 3): 256 rows x 128 columns per workgroup, FOUR waves of 128 x 64 (8 x 4 accumulator tiles,
+// one wave per SIMD), BOTH operands through LDS in chunks of two k-steps.  Why: the 128 x 128 kernel above re-reads every
+// operand byte once per 128 rows / columns and fetches each weight fragment in two waves -- 43 FLOP per byte that crosses
+// L2 -> CU, 17 TB/s of L2 traffic at 745 TFLOP/s: it is L2-bandwidth bound.  This tile moves 85 FLOP per byte.  Per chunk a
+// wave issues 64 MFMAs (1 024 cycles) against 24 LDS fragment reads; the next chunk's rows / weight blocks are requested
+// from global memory one chunk ahead and written to the other LDS buffer under the current chunk's MFMAs.
+// MEASURED (diagnostic build only, itts_debug_set(3, 9 / 11); tools/probes/check_big_gemm.py, profiles/r03_big_gemm.txt):
+// bit-identical to the 128 x 128 kernel and SLOWER on every prefill / latent shape -- 300-475 against 580-670 TFLOP/s -- with
+// one or two chunks requested ahead and with or without the fragment reads of the second k-step issued under the first
+// one's MFMAs: a chunk takes ~5 000 cycles where its MFMAs need 1 024, whatever is prefetched.  Four waves per CU do not
+// keep this pipeline busy; the 16 waves of two 128 x 128 workgroups do.  Not used by the product.
+// -------------------------------------------------------------------------------------------------------------------
+// D = chunks requested ahead (register staging sets): the loads in flight per CU are D x 48 KB, and with one wave per SIMD
+// that product over the 2-3 us a loaded memory system takes IS the throughput (D = 1: 457 TFLOP/s measured = 48 KB / ~6 000 cycles)
+template <typename T, int D>
+__global__ __launch_bounds__(256, 1) void gemm_big_kernel(ConvParams p) {
+  typedef Elem<T> EL;
+  typedef typename EL::frag frag;
+  constexpr int TM = 8, TN = 4, BM = 256, BN = 128, KC = 2;
+  constexpr int ROWB = KC * 64 + 16;                  // LDS row stride of the activation tile (bytes)
+  constexpr int ABYTES = BM * ROWB, BBYTES = (BN / 16) * KC * 1024, BUFB = ABYTES + BBYTES;
+  constexpr int NA = BM * KC * 4 / 256, NB_ = BBYTES / 16 / 256;   // 16-byte staging slots per thread: 8 + 4
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  const int wm = wave >> 1, wn = wave & 1;
+  int mblk, nblk, b;
+  tile_of_workgroup(p, blockIdx.x, gridDim.x, mblk, nblk, b);
+  const int t0 = mblk * BM;
+  const int vrows = conv_valid_rows(p, b);
+  if (t0 + p.off0 >= vrows) return;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>((const T*)p.x + (int64_t)b * p.x_bstride), 0, (int)((int64_t)vrows * p.Cin * (int)sizeof(T)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.wp), 0, (int)((int64_t)p.NT * p.KT * 1024), 0x00020000);
+  const int NC = (p.KT + KC - 1) / KC;
+  const int kbytes = p.Cin * (int)sizeof(T);          // bytes of one activation row
+
+  // staging slots: chunk-independent parts of the addresses
+  unsigned a_g[NA], b_g[NB_];
+  int a_l[NA], b_l[NB_], a_cb[NA], b_ks[NB_];
+#pragma unroll
+  for (int q = 0; q < NA; ++q) {
+    const int idx = tid + q * 256, row = idx / (KC * 4), seg = idx - row * (KC * 4);
+    const int tin = t0 + p.off0 + row;
+    a_cb[q] = seg * 16;
+    a_g[q] = (tin >= 0 && tin < vrows) ? (unsigned)(tin * kbytes + seg * 16) : OOB;
+    a_l[q] = row * ROWB + seg * 16;
+  }
+#pragma unroll
+  for (int q = 0; q < NB_; ++q) {
+    const int idx = tid + q * 256, blk = idx >> 6, within = idx & 63;
+    const int nt = blk / KC, ks = blk - nt * KC;
+    const int gnt = nblk * (BN / 16) + nt;
+    b_ks[q] = ks;
+    b_g[q] = gnt < p.NT ? (unsigned)((gnt * p.KT + ks) * 1024 + within * 16) : OOB;
+    b_l[q] = ABYTES + blk * 1024 + within * 16;
+  }
+  frag sa[D][NA], sb[D][NB_];
+  auto request = [&](int c, frag (&xa)[NA], frag (&xb)[NB_]) {
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const bool ok = a_g[q] != OOB && c * (KC * 64) + a_cb[q] < kbytes;
+      xa[q] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? a_g[q] + (unsigned)(c * KC * 64) : OOB, 0, 0));
+    }
+#pragma unroll
+    for (int q = 0; q < NB_; ++q) {
+      const bool ok = b_g[q] != OOB && c * KC + b_ks[q] < p.KT;
+      xb[q] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? b_g[q] + (unsigned)(c * KC * 1024) : OOB, 0, 0));
+    }
+  };
+  auto commit = [&](unsigned char* buf, frag (&xa)[NA], frag (&xb)[NB_]) {
+#pragma unroll
+    for (int q = 0; q < NA; ++q) st16(buf + a_l[q], xa[q]);
+#pragma unroll
+    for (int q = 0; q < NB_; ++q) st16(buf + b_l[q], xb[q]);
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int a_off = (wm * TM * 16 + r) * ROWB + g * 16;
+  const int b_off = ABYTES + (wn * TN * KC) * 1024 + lane * 16;
+
+  // prologue: chunk 0 into LDS buffer 0; chunks 1 .. D in flight (chunk j lives in register set j % D)
+  request(0, sa[0], sb[0]);
+  commit(lds, sa[0], sb[0]);
+#pragma unroll
+  for (int j = 1; j <= D; ++j) request(j, sa[j % D], sb[j % D]);
+  __syncthreads();
+  constexpr int U = (D % 2 == 0) ? D : 2 * D;       // unroll so that both the LDS buffer (c & 1) and the set (c % D) are static
+  // NO guard inside the unrolled body: the trip count is rounded up to U chunks (chunks past the end are zeros: their loads
+  // are out of range and cost nothing, their MFMAs add zero).  With a guard per body the compiler's wait-count pass merges the
+  // "body skipped" path into every wait and drains the whole queue (vmcnt(11..0) where vmcnt(12 (D - 1) + 11) is meant).
+  const int NCp = (NC + U - 1) / U * U;
+  for (int c0 = 0; c0 < NCp; c0 += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u;
+      {
+        const unsigned char* cur = lds + (u & 1) * BUFB;
+        unsigned char* nxt = lds + ((u + 1) & 1) * BUFB;
+        // one wave per SIMD issues in order: the fragments of k-step 1 are requested BEFORE the MFMAs of k-step 0, so that
+        // their LDS latency runs under 32 MFMAs instead of stalling the wave (nothing else is there to fill the hole)
+        frag af0[TM], bf0[TN], af1[TM], bf1[TN];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) bf0[tn] = ld16<frag>(cur + b_off + (tn * KC + 0) * 1024);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) af0[tm] = ld16<frag>(cur + a_off + tm * 16 * ROWB + 0 * 64);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) bf1[tn] = ld16<frag>(cur + b_off + (tn * KC + 1) * 1024);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) af1[tm] = ld16<frag>(cur + a_off + tm * 16 * ROWB + 1 * 64);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = EL::mma(bf0[tn], af0[tm], acc[tm][tn]);   // weights as A: transposed tile
+        __builtin_amdgcn_sched_barrier(0);
+        commit(nxt, sa[(u + 1) % D], sb[(u + 1) % D]);                 // chunk c+1: requested D chunks ago
+        request(c + 1 + D, sa[(u + 1) % D], sb[(u + 1) % D]);          // past the last chunk: out-of-range offsets, no traffic
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = EL::mma(bf1[tn], af1[tm], acc[tm][tn]);
+        __syncthreads();
+      }
+    }
+  }
+  conv_epilogue<T, TM, TN>(p, acc, b, t0 + wm * TM * 16, nblk * (BN / 16) + wn * TN, g, r);
+}
+
+template <typename T, int D>
+static int launch_big(const ConvParams& p, hipStream_t s) {
+  constexpr int BM = 256, BN = 128;
+  constexpr size_t ldsb = (size_t)2 * (BM * (2 * 64 + 16) + (BN / 16) * 2 * 1024);
+  ConvParams q = p;
+  q.MB = (p.Tout + BM - 1) / BM;
+  q.NB = (p.N + BN - 1) / BN;
+  const int64_t wbytes = (int64_t)BN * p.KT * 64;
+  int gn = (int)((2 << 20) / (wbytes > 0 ? wbytes : 1));
+  gn = gn < 1 ? 1 : (gn > 8 ? 8 : gn);
+  int gm = 32 / gn;
+  gm = gm >= 32 ? 32 : (gm >= 16 ? 16 : (gm >= 8 ? 8 : 4));
+  q.GM = gm;
+  const int64_t total = (int64_t)q.MB * q.NB * p.B;
+  if (total > 0x7fffffff) {
+    set_error("itts_gemm_conv: too many tiles (%lld)", (long long)total);
+    return ITTS_ERR_INVALID;
+  }
+  static std::once_flag attr;
+  std::call_once(attr, [] {
+    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<T, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  hipLaunchKernelGGL((gemm_big_kernel<T, D>), dim3((unsigned)total), dim3(256), ldsb, s, q);
+  return check_launch("itts_gemm_conv");
+}
+
+// -------------------------------------------------------------------------------------------------------------------
 // Narrow convolution (Cin <= 64, N <= 64: the last two BigVGAN stages, conv_post and the last upsampler).  These layers
 // are HBM-bound (a k = 7 conv over 48 channels does 84 FLOP per byte moved), so the kernel is built around the row
 // stream, not the MFMA pipe:
@@ -1013,6 +1177,9 @@ static int dispatch_conv(const ConvParams& p, hipStream_t s) {
     // Measured on MI355X (bf16, M = 3008 / 7488, N = 1280..5120, K = 1280 / 5120): 128 x 128 pipelined 435-720 TFLOP/s,
     // 256 x 128 pipelined 300-625, the unpipelined 256 x 128 tile of the convolution kernel 260-540.
     if (g_conv_cfg == 5) return launch_plain<T, 2, 4, 8, 2>(p, s);   // 256 x 128
+    if (g_conv_cfg == 9) return launch_big<T, 1>(p, s);              // 256 x 128, both operands through LDS, 4 waves of 128 x 64
+    if (g_conv_cfg == 11) return launch_big<T, 2>(p, s);             // ... two / three chunks requested ahead
+
     return launch_plain<T, 2, 4, 4, 2>(p, s);                        // 128 x 128, two workgroups per CU
   }
   if (plain && p.N % 64 == 0) {
