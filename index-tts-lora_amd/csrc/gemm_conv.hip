@@ -831,27 +831,41 @@ __global__ __launch_bounds__(256, 1) void gemm_big_kernel(ConvParams p) {
         // one wave per SIMD issues in order: the fragments of k-step 1 are requested BEFORE the MFMAs of k-step 0, so that
         // their LDS latency runs under 32 MFMAs instead of stalling the wave (nothing else is there to fill the hole)
         frag af0[TM], bf0[TN], af1[TM], bf1[TN];
+        const int ex = ITTS_CONV_EXP(p);   // diagnostic ablations: 256 no MFMAs, 512 no global requests, 1024 no LDS commit, 2048 no fragment reads
+        if (!(ex & 2048)) {
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) bf0[tn] = ld16<frag>(cur + b_off + (tn * KC + 0) * 1024);
+          for (int tn = 0; tn < TN; ++tn) bf0[tn] = ld16<frag>(cur + b_off + (tn * KC + 0) * 1024);
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) af0[tm] = ld16<frag>(cur + a_off + tm * 16 * ROWB + 0 * 64);
+          for (int tm = 0; tm < TM; ++tm) af0[tm] = ld16<frag>(cur + a_off + tm * 16 * ROWB + 0 * 64);
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) bf1[tn] = ld16<frag>(cur + b_off + (tn * KC + 1) * 1024);
+          for (int tn = 0; tn < TN; ++tn) bf1[tn] = ld16<frag>(cur + b_off + (tn * KC + 1) * 1024);
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) af1[tm] = ld16<frag>(cur + a_off + tm * 16 * ROWB + 1 * 64);
+          for (int tm = 0; tm < TM; ++tm) af1[tm] = ld16<frag>(cur + a_off + tm * 16 * ROWB + 1 * 64);
+        } else {
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) bf0[tn] = bf1[tn] = sb[0][0];
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) af0[tm] = af1[tm] = sa[0][0];
+        }
         __builtin_amdgcn_sched_barrier(0);
+        if (!(ex & 256)) {
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+          for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = EL::mma(bf0[tn], af0[tm], acc[tm][tn]);   // weights as A: transposed tile
+            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = EL::mma(bf0[tn], af0[tm], acc[tm][tn]);   // weights as A: transposed tile
+        }
         __builtin_amdgcn_sched_barrier(0);
-        commit(nxt, sa[(u + 1) % D], sb[(u + 1) % D]);                 // chunk c+1: requested D chunks ago
-        request(c + 1 + D, sa[(u + 1) % D], sb[(u + 1) % D]);          // past the last chunk: out-of-range offsets, no traffic
+        if (!(ex & 1024)) commit(nxt, sa[(u + 1) % D], sb[(u + 1) % D]);                 // chunk c+1: requested D chunks ago
+        if (!(ex & 512)) request(c + 1 + D, sa[(u + 1) % D], sb[(u + 1) % D]);           // past the last chunk: out-of-range offsets, no traffic
         __builtin_amdgcn_sched_barrier(0);
+        if (!(ex & 256)) {
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+          for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = EL::mma(bf1[tn], af1[tm], acc[tm][tn]);
+            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = EL::mma(bf1[tn], af1[tm], acc[tm][tn]);
+        } else {
+          asm volatile("" ::"v"(af1[0]), "v"(bf1[0]), "v"(af0[0]), "v"(bf0[0]));
+        }
         __syncthreads();
       }
     }

@@ -43,6 +43,15 @@ def run(cfg, dtype, M, K, N, y_f32, resid, act, reps=0):
 
 
 bf = torch.bfloat16
+if os.environ.get("ITTS_BIG_EXP"):
+    # ablations of the 256 x 128 kernel (results are wrong by construction; only the time is of interest)
+    for ex in [int(v) for v in os.environ["ITTS_BIG_EXP"].split(",")]:
+        nat.debug_set(5, ex)
+        for cfg in (9, 11):
+            _, us = run(cfg, bf, 4544, 1280, 5120, False, False, 1, reps=20)
+            print(f"exp {ex:5d} cfg {cfg}: {us:7.1f} us", flush=True)
+    nat.debug_set(5, 0)
+    sys.exit(0)
 for dtype, M, K, N, y_f32, resid, act in [(bf, 2016, 1280, 3840, False, False, 0), (bf, 2016, 1280, 1280, True, True, 0),
                                            (bf, 2016, 1280, 5120, False, False, 1), (bf, 2016, 5120, 1280, True, True, 0),
                                            (bf, 4544, 1280, 3840, False, False, 0), (bf, 4544, 1280, 1280, True, True, 0),
