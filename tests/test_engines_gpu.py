@@ -490,8 +490,9 @@ def test_request_pool_matches_serial_infer_batch():
         RequestPool(insts, cu_masks=[even])
 
 
+@pytest.mark.parametrize("lens", [[17, 3, 9, 12, 1], [3, 12, 17, 1, 9]])   # element 0 the longest (pad 0) / not (pad 14)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_prefill_computes_the_shared_conditioning_rows_once(dtype):
+def test_prefill_computes_the_shared_conditioning_rows_once(dtype, lens):
     """prefill(shared_rows=32): the 32 conditioning latents every element of a one-prompt batch starts with go through the
     blocks once, each element contributes only its text rows, their attention reads the shared block out of the same qkv
     buffer.  Logits, the whole KV cache region the decode loop reads, and the decoded tokens are those of the plain packed
@@ -501,7 +502,6 @@ def test_prefill_computes_the_shared_conditioning_rows_once(dtype):
     rng = np.random.default_rng(31)
     cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
     conds = m.get_conditioning(cond_mel, None)
-    lens = [17, 3, 9, 12, 1]
     L = max(lens)
     text = torch.full((len(lens), L), m.stop_text_token, dtype=torch.int32)
     for i, n in enumerate(lens):
@@ -517,7 +517,8 @@ def test_prefill_computes_the_shared_conditioning_rows_once(dtype):
         kc, vc = eng.kc[:, :B, :, :S].clone(), eng.vc[:, :B, :, :S].clone()
         codes = eng.decode(12, sp)
         got[shared] = (logits, kc, vc, codes.clone())
-    assert eng.share_prefix
+    assert eng.share_prefix and eng.share_kv_reads
+    assert int(eng.kv_share.item()) == ((int(pad[0]) << 8) | 32)     # the decode attention was told where row 0 keeps the block
     for a, b in zip(got[0], got[32]):
         assert torch.equal(a, b)
     for b_, p_ in enumerate(pad.tolist()):                # (the comparison above is not vacuous: the prompt region is filled)
