@@ -48,7 +48,7 @@ extern "C" {
 #define ITTS_BF16 1
 #define ITTS_F16 2
 
-#define ITTS_ABI_VERSION 6 /* 6: per-row clocks (row_step0) in itts_embed_step / itts_sample_args (slot refill), itts_attn_prefill_prefix / _shared, kv_share in itts_attn_decode; 5: itts_ln_reduce takes up to 6 slabs */
+#define ITTS_ABI_VERSION 7 /* 7: LayerNorm folded into the consuming skinny GEMM (ln_c), residual epilogue with a packed T copy, rows_per_wg / wide_wg, bump words in itts_gemm_skinny / itts_embed_step (+ clamp, packed copy); the reducer tail is gone; 6: per-row clocks (row_step0) in itts_embed_step / itts_sample_args (slot refill), itts_attn_prefill_prefix / _shared, kv_share in itts_attn_decode; 5: itts_ln_reduce takes up to 6 slabs */
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -87,7 +87,7 @@ int itts_aa_snake_fwd(const void* x, void* y, const float* alpha_log, const floa
  *     element (m, k) at  ((k / KS * MTP + m / 16) * 64 + (k % KS) / E * 16 + m % 16) * E + k % E,   MTP = ceil(M / 16),
  *     KS = 32, E = 8 (bf16/f16) or KS = 16, E = 4 (f32); the buffer holds K/KS * MTP KiB (rows up to 16*MTP exist).
  * The GEMM then reads a fragment as one contiguous 1-KiB wave-load instead of 16 rows x 64 bytes.  Producers that can
- * write it: itts_ln_reduce (y_packed), itts_attn_decode (out_packed), itts_gemm_skinny (y_packed, tail_y_packed).
+ * write it: itts_ln_reduce (y_packed), itts_attn_decode (out_packed), itts_gemm_skinny (y_packed), itts_embed_step (h_packed).
  * ------------------------------------------------------------------------------------------------------------------ */
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -98,11 +98,12 @@ int itts_aa_snake_fwd(const void* x, void* y, const float* alpha_log, const floa
  * ------------------------------------------------------------------------------------------------------------------ */
 #define ITTS_EPI_STORE 0      /* y (T [M][N]) = v */
 #define ITTS_EPI_GELU_STORE 1 /* y (T [M][N]) = gelu_new(v) */
-#define ITTS_EPI_RESID_F32 2  /* yf (fp32 [M][N]) += v              (residual stream update) */
+#define ITTS_EPI_RESID_F32 2  /* yf (fp32 [M][N]) += v   (residual stream update; ksplit 1: one owner per element); if y != NULL
+                                 the new values are also stored as T in y ([M][N], or packed with y_packed) */
 #define ITTS_EPI_QKV_CACHE 3  /* cols [0,D): y (T [M][D]) = v ; [D,2D): K cache ; [2D,3D): V cache, at position *pos */
 #define ITTS_EPI_STORE_F32 4  /* yf (fp32 [M][N]) = v               (logits) */
 #define ITTS_EPI_SLAB_F32 5   /* yf (fp32 [ksplit][M][N]): slice ks stores its partial product (bias added by slice 0);
-                                 the slabs are summed in order by itts_ln_reduce, or by this launch's reducer tail */
+                                 the slabs are summed in order by itts_ln_reduce */
 
 typedef struct itts_skinny_args {
   int dtype;
@@ -118,38 +119,28 @@ typedef struct itts_skinny_args {
   const int32_t* pos; /* device scalar: cache row to write */
   int heads, smax;
   int ksplit; /* split-K over workgroups (grid.y); > 1 only with ITTS_EPI_SLAB_F32 */
-  /* Reducer tail (tail_h != NULL; needs ITTS_EPI_SLAB_F32, ksplit <= 4, N % 4 == 0, N <= 2048, all M rows in ONE launch and
-   * M <= workgroups <= 256).  After a workgroup has stored its slab tile (write-through) it signals: one agent-scope add
-   * into shard (workgroup id % 8) of tail_counter[8].  Workgroups 0..M-1 then wait until every workgroup of the launch
-   * has signalled, and workgroup r reduces row r:
-   *     tail_h[row][:] += tail_bias[:] + slab[0][row][:] + ... + slab[ksplit-1][row][:]      (fixed order, in place)
-   *     tail_y[row][:]  = LN(tail_h[row]; tail_w, tail_b)   (then LN(.; tail_w2, tail_b2) if tail_w2 != NULL),  T [M][N]
-   * bit for bit what itts_ln_reduce computes in a launch of its own.  Counter protocol: the 8 shards are monotonic and
-   * never reset by the kernel; a launch waits until shard s holds e * W_s, where e = *tail_epoch (a device word the
-   * caller advances once per use of this launch site, e.g. once per decode step) and W_s = workgroups of the launch
-   * with id % 8 == s; start from counters = 0, epoch = 1.  A reducer that waits too long sets *tail_err = 1, shards
-   * beyond the expected value (a lost or repeated launch) set it to 2 (sticky): the caller checks it when it next
-   * synchronises.  tail_acquire != 0 adds an agent-scope acquire fence after the wait (the slab bytes are read with
-   * L1-bypassing loads either way). */
-  float* tail_h;
-  const float* tail_bias;
-  const float* tail_w;
-  const float* tail_b;
-  const float* tail_w2;
-  const float* tail_b2;
-  void* tail_y;
-  int32_t* tail_counter; /* [8] shards */
-  const int32_t* tail_epoch;
-  int32_t* tail_err;
-  int tail_acquire;
+  /* LayerNorm folded into this GEMM (ln_c != NULL; bf16 / f16, ksplit 1, N % 4 == 0, storing epilogues):
+   *     v = rstd[m] * ( (x @ wp)[m][n] - mean[m] * ln_c[n] ) + bias[n]
+   * with mean / rstd the LayerNorm statistics (eps = ln_eps, 0 = 1e-5) of row m of x itself, computed by the kernel from the
+   * operand fragments.  For wp = pack(gamma . W), ln_c[n] = sum_k (gamma . W)[k][n] (of the T-rounded values),
+   * bias[n] = sum_k beta[k] W[k][n] + b[n] this equals LN(x; gamma, beta) @ W + b: HF GPT2Block's ln_1 -> c_attn and
+   * ln_2 -> c_fc (indextts/gpt/model.py:163-193) without a LayerNorm launch in front of the GEMM. */
+  const float* ln_c;
+  float ln_eps;
+  int32_t* bump; /* device word incremented once by the launch, or NULL (the decode loop's step counter: a launch that does
+                    not read it advances it) */
+  /* geometry hints (results differ only in the summation order): rows_per_wg 0 = every workgroup covers all rows of a
+   * <= 96-row chunk; 16 / 32 = the row tiles are dealt to grid.z (more, lighter workgroups for GEMMs that run without
+   * split-K).  wide_wg != 0: 16-wave workgroups where that keeps a long K to one pass (16 rows per workgroup only). */
+  int rows_per_wg, wide_wg;
   /* Packed-activation layout (see "Packed activation layout" above): x_packed -- x is packed [K/KS][ceil(M/16)][64][E];
-   * y_packed -- y (ITTS_EPI_STORE / ITTS_EPI_GELU_STORE, N % KS == 0) is written packed; tail_y_packed -- the tail's y. */
-  int x_packed, y_packed, tail_y_packed;
+   * y_packed -- y (ITTS_EPI_STORE / ITTS_EPI_GELU_STORE / ITTS_EPI_RESID_F32, N % KS == 0) is written packed. */
+  int x_packed, y_packed;
 } itts_skinny_args;
 int itts_gemm_skinny(const itts_skinny_args* a, void* stream);
-/* launch geometry itts_gemm_skinny would use: out6 = {grid.x, grid.y, waves per workgroup, column tiles per workgroup,
- * k-steps per wave, dynamic LDS bytes} (host-only, launches nothing) */
-int itts_skinny_plan(int dtype, int M, int N, int K, int ksplit, int* out6);
+/* launch geometry itts_gemm_skinny would use: out8 = {grid.x, grid.y, waves per workgroup, column tiles per workgroup,
+ * k-steps per wave, dynamic LDS bytes, grid.z, row tiles per workgroup} (host-only, launches nothing) */
+int itts_skinny_plan(int dtype, int M, int N, int K, int ksplit, int rows_per_wg, int wide_wg, int fold, int* out8);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Tiled MFMA GEMM / 1-D convolution, channels-last.
@@ -220,12 +211,16 @@ typedef struct itts_ln_reduce_args {
 } itts_ln_reduce_args;
 int itts_ln_reduce(const itts_ln_reduce_args* a, void* stream);
 
-/* h[b][:] = table[tokens[b]][:] + pos_table[*step - row_step0[b] + pos_add][:]   (fp32 tables, fp32 h).  If epoch != NULL,
- * *epoch is incremented once (the first launch of a decode step advances the epoch of that step's reducer tails).
+/* h[b][:] = table[tokens[b]][:] + pos_table[p][:],  p = clamp(*step - row_step0[b] + pos_add, 0, pos_rows - 1)
+ * (fp32 tables, fp32 h; pos_rows = rows of pos_table: a finished slot that keeps stepping never reads past the table).
+ * bump (device word or NULL) is incremented once by the launch: the decode loop's cache position, which this launch does
+ * not read.  h_packed (T, packed activation layout for M = B rows, or NULL): a T-typed copy of the same rows -- the operand
+ * of the first LayerNorm-folded GEMM of the step.
  * row_step0 (int32 [B] on the device or NULL = zeros): the loop step at which row b started decoding -- a decode slot that
  * was refilled with a new utterance in the middle of the loop counts its mel positions from its own first token. */
 int itts_embed_step(const int32_t* tokens, const float* table, const float* pos_table, const int32_t* step, int pos_add,
-                    float* h, int B, int D, int32_t* epoch, const int32_t* row_step0, void* stream);
+                    float* h, int B, int D, int32_t* bump, const int32_t* row_step0, int pos_rows, void* h_packed, int dtype,
+                    void* stream);
 
 /* Single-query attention over the KV cache (decode).  q,out: T [B][H*64]; caches T [B][H][smax][64];
  * keys j in [pad[b], *pos] are visible (the key at *pos was just appended).  scale 1/8.  out_packed != 0: out is written in

@@ -392,20 +392,39 @@ static int launch_ln_reduce(const itts_ln_reduce_args& a, hipStream_t s) {
   return check_launch("itts_ln_reduce");
 }
 
+// h[b] = table[tokens[b]] + pos_table[p], p = *step - row_step0[b] + pos_add clamped to the table (a slot whose row has
+// finished keeps stepping formally until the loop ends; its value is discarded, its read must stay inside the table).
+// hp (optional): the same rows as T in the packed activation layout -- what the LayerNorm-folded QKV GEMM multiplies.
+template <typename T>
 __global__ __launch_bounds__(256) void embed_step_kernel(const int32_t* __restrict__ tokens, const float* __restrict__ table,
                                                           const float* __restrict__ pos_table,
                                                           const int32_t* __restrict__ step, int pos_add,
-                                                          float* __restrict__ h, int D, int32_t* __restrict__ epoch,
-                                                          const int32_t* __restrict__ row_step0) {
+                                                          float* __restrict__ h, int D, int32_t* __restrict__ bump,
+                                                          const int32_t* __restrict__ row_step0, int pos_rows,
+                                                          T* __restrict__ hp, int mtp) {
+  constexpr int E = Elem<T>::E;
   int b = blockIdx.x;
-  if (epoch != nullptr && b == 0 && threadIdx.x == 0) epoch[0] = epoch[0] + 1;  // read by LATER launches of this step only
   int tok = tokens[b];
   const int32_t* s0p = row_step0 != nullptr ? row_step0 + b : step;   // a readable word either way (no branch around the load)
   const int s0 = row_step0 != nullptr ? *s0p : 0;
   int p = step[0] - s0 + pos_add;
+  p = min(max(p, 0), pos_rows - 1);
   const float* e = table + (int64_t)tok * D;
   const float* pe = pos_table + (int64_t)p * D;
-  for (int i = threadIdx.x; i < D; i += 256) h[(int64_t)b * D + i] = e[i] + pe[i];
+  for (int c = threadIdx.x; c < D / E; c += 256) {
+    float v[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) v[i] = e[c * E + i] + pe[c * E + i];
+#pragma unroll
+    for (int i = 0; i < E; ++i) h[(int64_t)b * D + c * E + i] = v[i];
+    if (hp != nullptr) {
+      T* dst = hp + pa_off<T>(b, c * E, mtp);
+#pragma unroll
+      for (int i = 0; i < E; ++i) dst[i] = Elem<T>::from_f(v[i]);
+    }
+  }
+  // the loop-state word this launch advances (the cache position: nothing here reads it)
+  if (bump != nullptr && b == 0 && threadIdx.x == 0) bump[0] += 1;
 }
 
 template <typename T>
@@ -542,10 +561,29 @@ extern "C" int itts_ln_reduce(const itts_ln_reduce_args* a, void* stream) {
 }
 
 extern "C" int itts_embed_step(const int32_t* tokens, const float* table, const float* pos_table, const int32_t* step,
-                               int pos_add, float* h, int B, int D, int32_t* epoch, const int32_t* row_step0, void* stream) {
-  ITTS_REQUIRE(tokens && table && pos_table && step && h && B > 0 && D > 0, "itts_embed_step: bad arguments");
-  hipLaunchKernelGGL(embed_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, tokens, table, pos_table, step, pos_add, h, D,
-                     epoch, row_step0);
+                               int pos_add, float* h, int B, int D, int32_t* bump, const int32_t* row_step0, int pos_rows,
+                               void* h_packed, int dtype, void* stream) {
+  ITTS_REQUIRE(tokens && table && pos_table && step && h && B > 0 && D > 0 && pos_rows > 0, "itts_embed_step: bad arguments");
+  ITTS_REQUIRE(D % 8 == 0, "itts_embed_step: D=%d must be a multiple of 8", D);
+  if (h_packed != nullptr) ITTS_REQUIRE(D % (dtype == ITTS_F32 ? 16 : 32) == 0, "itts_embed_step: a packed copy needs D %% k-step == 0");
+  hipStream_t s = (hipStream_t)stream;
+  const int mtp = (B + 15) / 16;
+  switch (dtype) {
+    case ITTS_F32:
+      hipLaunchKernelGGL(embed_step_kernel<float>, dim3(B), dim3(256), 0, s, tokens, table, pos_table, step, pos_add, h, D, bump,
+                         row_step0, pos_rows, (float*)h_packed, mtp);
+      break;
+    case ITTS_BF16:
+      hipLaunchKernelGGL(embed_step_kernel<bf16_t>, dim3(B), dim3(256), 0, s, tokens, table, pos_table, step, pos_add, h, D, bump,
+                         row_step0, pos_rows, (bf16_t*)h_packed, mtp);
+      break;
+    case ITTS_F16:
+      hipLaunchKernelGGL(embed_step_kernel<f16_t>, dim3(B), dim3(256), 0, s, tokens, table, pos_table, step, pos_add, h, D, bump,
+                         row_step0, pos_rows, (f16_t*)h_packed, mtp);
+      break;
+    default:
+      ITTS_REQUIRE(false, "itts_embed_step: unknown dtype %d", dtype);
+  }
   return check_launch("itts_embed_step");
 }
 

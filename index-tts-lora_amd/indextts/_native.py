@@ -28,10 +28,8 @@ class SkinnyArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("wp", C.c_void_p),
                 ("bias", C.c_void_p), ("x", C.c_void_p), ("epi", C.c_int), ("y", C.c_void_p), ("yf", C.c_void_p),
                 ("kcache", C.c_void_p), ("vcache", C.c_void_p), ("pos", C.c_void_p), ("heads", C.c_int),
-                ("smax", C.c_int), ("ksplit", C.c_int), ("tail_h", C.c_void_p), ("tail_bias", C.c_void_p),
-                ("tail_w", C.c_void_p), ("tail_b", C.c_void_p), ("tail_w2", C.c_void_p), ("tail_b2", C.c_void_p),
-                ("tail_y", C.c_void_p), ("tail_counter", C.c_void_p), ("tail_epoch", C.c_void_p), ("tail_err", C.c_void_p),
-                ("tail_acquire", C.c_int), ("x_packed", C.c_int), ("y_packed", C.c_int), ("tail_y_packed", C.c_int)]
+                ("smax", C.c_int), ("ksplit", C.c_int), ("ln_c", C.c_void_p), ("ln_eps", C.c_float), ("bump", C.c_void_p),
+                ("rows_per_wg", C.c_int), ("wide_wg", C.c_int), ("x_packed", C.c_int), ("y_packed", C.c_int)]
 
 
 class LnReduceArgs(C.Structure):
@@ -81,13 +79,13 @@ _SIGNATURES = {
     "itts_aa_snake_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "itts_gemm_skinny": (C.c_int, [C.POINTER(SkinnyArgs), C.c_void_p]),
-    "itts_skinny_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "itts_skinny_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "itts_gemm_conv": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "itts_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_ln_reduce": (C.c_int, [C.POINTER(LnReduceArgs), C.c_void_p]),
     "itts_embed_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
-                                  C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                  C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "itts_attn_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "itts_attn_prefill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -123,7 +121,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.itts_abi_version() != 6:
+        if L.itts_abi_version() != 7:
             raise NativeError("libindextts_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -205,21 +203,19 @@ def aa_snake(x, alpha_log, beta_log, up_f, down_f, layout=0, out=None, valid_row
 
 
 def gemm_skinny(dtype, M, N, K, wp, bias=None, x=None, epi=EPI_STORE, y=None, yf=None, kcache=None, vcache=None, pos=None,
-                heads=0, smax=0, ksplit=1, tail=None, x_packed=False, y_packed=False):
-    """tail = dict(h, w, b, y, counter, epoch, err[, bias, w2, b2, acquire]): reducer tail of a split-K launch --
-    h += bias + slabs, y = LN(h) computed by the last M arriving workgroups of the same launch (see itts_skinny_args)."""
+                heads=0, smax=0, ksplit=1, x_packed=False, y_packed=False, ln_c=None, ln_eps=1e-5, bump=None, rows_per_wg=0,
+                wide_wg=False):
+    """ln_c fp32 [N]: LayerNorm folded into the GEMM -- x holds the RAW rows, wp = pack(gamma . W), bias = beta W + b
+    (see itts_skinny_args).  EPI_RESID_F32: yf += x W + bias, and y (optional, T) receives a copy of the new rows.
+    bump: int32 device word the launch increments.  rows_per_wg / wide_wg: launch-geometry hints."""
     a = SkinnyArgs()
-    if tail is not None:
-        a.tail_h, a.tail_w, a.tail_b, a.tail_y = _p(tail["h"]), _p(tail["w"]), _p(tail["b"]), _p(tail["y"])
-        a.tail_bias, a.tail_w2, a.tail_b2 = _p(tail.get("bias")), _p(tail.get("w2")), _p(tail.get("b2"))
-        a.tail_counter, a.tail_epoch, a.tail_err = _p(tail["counter"]), _p(tail["epoch"]), _p(tail["err"])
-        a.tail_acquire = int(tail.get("acquire", 0))
-        a.tail_y_packed = int(bool(tail.get("y_packed", False)))
     a.dtype, a.M, a.N, a.K = dt(dtype), M, N, K
     a.wp, a.bias, a.x = _p(wp), _p(bias), _p(x)
     a.epi, a.y, a.yf = epi, _p(y), _p(yf)
     a.kcache, a.vcache, a.pos, a.heads, a.smax, a.ksplit = _p(kcache), _p(vcache), _p(pos), heads, smax, ksplit
     a.x_packed, a.y_packed = int(bool(x_packed)), int(bool(y_packed))
+    a.ln_c, a.ln_eps, a.bump = _p(ln_c), float(ln_eps), _p(bump)
+    a.rows_per_wg, a.wide_wg = int(rows_per_wg), int(bool(wide_wg))
     _check(lib().itts_gemm_skinny(C.byref(a), _stream()), "itts_gemm_skinny")
 
 
@@ -249,11 +245,13 @@ def unpack_activation(xp: torch.Tensor, M: int, K: int) -> torch.Tensor:
     return v[:M]
 
 
-def skinny_plan(dtype, M, N, K, ksplit=1) -> dict:
+def skinny_plan(dtype, M, N, K, ksplit=1, rows_per_wg=0, wide_wg=False, fold=False) -> dict:
     """Launch geometry itts_gemm_skinny would use (host-only)."""
-    out = (C.c_int * 6)()
-    _check(lib().itts_skinny_plan(dt(dtype), M, N, K, ksplit, out), "itts_skinny_plan")
-    return dict(grid=(out[0], out[1]), waves=out[2], tiles_per_wg=out[3], ksteps_per_wave=out[4], lds=out[5])
+    out = (C.c_int * 8)()
+    _check(lib().itts_skinny_plan(dt(dtype), M, N, K, ksplit, int(rows_per_wg), int(bool(wide_wg)), int(bool(fold)), out),
+           "itts_skinny_plan")
+    return dict(grid=(out[0], out[1], out[6]), waves=out[2], tiles_per_wg=out[3], ksteps_per_wave=out[4], lds=out[5],
+                row_tiles_per_wg=out[7])
 
 
 def gemm_conv(dtype, B, Tin, Tout, Cin, N, wp, x, y, taps=1, off0=0, dil=1, x_bstride=None, bias=None, bias2=None,
@@ -303,12 +301,14 @@ def ln_reduce(h, w, b, out, slab=None, nslab=0, bias=None, w2=None, b2=None, sta
     return out
 
 
-def embed_step(tokens, table, pos_table, step, pos_add, h, epoch=None, row_step0=None):
-    """epoch (int32 device word or None) is incremented once: the reducer tails of this decode step expect it.
-    row_step0 (int32 [B] or None): the loop step at which each row started (slot refill)."""
+def embed_step(tokens, table, pos_table, step, pos_add, h, bump=None, row_step0=None, h_packed=None):
+    """bump (int32 device word or None) is incremented once (the decode loop's cache position).
+    row_step0 (int32 [B] or None): the loop step at which each row started (slot refill).
+    h_packed (T, packed activation layout, or None): T-typed copy of the rows for the LayerNorm-folded QKV GEMM."""
     B, D = h.shape
-    _check(lib().itts_embed_step(_p(tokens), _p(table), _p(pos_table), _p(step), pos_add, _p(h), B, D, _p(epoch), _p(row_step0),
-                                 _stream()), "itts_embed_step")
+    d = F32 if h_packed is None else dt(h_packed.dtype)
+    _check(lib().itts_embed_step(_p(tokens), _p(table), _p(pos_table), _p(step), pos_add, _p(h), B, D, _p(bump), _p(row_step0),
+                                 pos_table.shape[0], _p(h_packed), d, _stream()), "itts_embed_step")
 
 
 def attn_decode(q, kcache, vcache, out, pad, pos, B, H, smax, out_packed=False, kv_rows=None, kv_step=None, skip_rows=None,

@@ -37,18 +37,23 @@ class GPTEngine:
             return nat.pack_weight(w_kn.detach().to(dev, dtype).contiguous())
 
         # Decode-step structure:
-        #   "launch" (default): every [residual-reduce + LayerNorm] is a launch of its own -- 7 launches per block
-        #   "tail":  the split-K out-projection / FC2 launches end with a reducer tail -- workgroups 0..M-1 wait for the
-        #            launch's arrival signals, fold the slabs into the residual stream and write LayerNorm(row) for the next
-        #            GEMM -- 5 launches per block.  Same bits as "launch" (tests/test_kernels_gpu.py).
-        # Measured on MI355X (B=32, bf16, profiles/README.md round 2): launch 1.09 ms/token, tail 1.18 ms: the in-launch
-        # hand-off (store drain, signal, poll, slab read-back: ~5.4 us on the split-K launches) costs more than the
-        # ~3.5 us the removed launch took.  Forms removed in round 1: LayerNorm in the consumer GEMM's prologue, LN rows
-        # produced by extra workgroups of the CONSUMER's launch.
-        self.decode_mode = os.environ.get("ITTS_DECODE_MODE", "launch")
-        if self.decode_mode not in ("tail", "launch"):
-            raise ValueError("ITTS_DECODE_MODE must be 'tail' or 'launch'")
-        self.tail_acquire = int(os.environ.get("ITTS_TAIL_ACQUIRE", "0"))
+        #   "fold" (default for bf16 / f16): LayerNorm folded into the consuming GEMM -- 5 launches per block.  The QKV and FC
+        #            GEMMs multiply the RAW residual rows (a T-typed packed copy `hb` of h) by gamma . W and apply the row
+        #            statistics, which they compute themselves on the matrix pipe, in their epilogue (csrc/gemm_skinny.hip);
+        #            the out-projection and FC2 run without split-K and add into h in their epilogue (one owner per element,
+        #            deterministic), storing hb beside it.  One [LayerNorm + LayerNorm] launch per token is left (ln_f, final_norm).
+        #   "launch": every [residual-reduce + LayerNorm] is a launch of its own behind a split-K GEMM -- 7 launches per block.
+        #            fp32 parity mode and engines with runtime LoRA adapters (whose (x A) B term rides on the reduce launch).
+        # Forms measured and removed in rounds 1-3: LayerNorm in the consumer GEMM's PROLOGUE, LN rows produced by extra
+        # workgroups of the consumer's launch, a reducer tail inside the split-K launches.
+        self.decode_mode = os.environ.get("ITTS_DECODE_MODE", "fold" if dtype != torch.float32 else "launch")
+        if self.decode_mode not in ("fold", "launch"):
+            raise ValueError("ITTS_DECODE_MODE must be 'fold' or 'launch'")
+        if dtype == torch.float32:
+            self.decode_mode = "launch"
+        # launch geometry of the two GEMMs that run without split-K in "fold" mode (rows per workgroup, 16-wave workgroups)
+        self.fold_rows = [int(v) for v in os.environ.get("ITTS_FOLD_ROWS", "16,16").split(",")]   # out-projection, FC2
+        self.fold_wide = os.environ.get("ITTS_FOLD_WIDE", "1") == "1"
         # T-typed activations of the decode step (xn, attention output, MLP hidden) live in the packed fragment layout
         # (include/indextts_hip.h): the GEMMs read them as contiguous 1-KiB blocks.  ITTS_PACKED_ACT=0: row-major (same bits).
         self.pa = os.environ.get("ITTS_PACKED_ACT", "1") == "1"
@@ -67,6 +72,16 @@ class GPTEngine:
         self._W = W          # kept (by reference) for attach_lora: the engine itself only holds packed copies
         self.lora = False
         self.layers = []
+
+        def folded(ln, wkey, bkey):
+            """LN(h; gamma, beta) W + b = rstd (h W' - mean c) + d:  W' = T(gamma . W) packed, c = column sums of the ROUNDED W'
+            (so that a constant row cancels exactly), d = beta W + b.  Sums in float64, stored fp32."""
+            Wm = W[wkey].detach().to(dev, torch.float64)
+            g, bt = ln[0].to(torch.float64), ln[1].to(torch.float64)
+            Wr = (g[:, None] * Wm).to(torch.float32).to(dtype)
+            c = Wr.to(torch.float64).sum(0).to(torch.float32).contiguous()
+            d = (bt @ Wm + W[bkey].detach().to(dev, torch.float64)).to(torch.float32).contiguous()
+            return nat.pack_weight(Wr.contiguous()), c, d
         for i in range(layers):
             p = f"gpt.h.{i}."
             d = dict(
@@ -77,6 +92,9 @@ class GPTEngine:
                 w_fc=packed(W[p + "mlp.c_fc.weight"]), b_fc=f32(p + "mlp.c_fc.bias"),
                 w_pr=packed(W[p + "mlp.c_proj.weight"]), b_pr=f32(p + "mlp.c_proj.bias"),
             )
+            if self.decode_mode == "fold":
+                d["wf_qkv"], d["c_qkv"], d["d_qkv"] = folded(d["ln1"], p + "attn.c_attn.weight", p + "attn.c_attn.bias")
+                d["wf_fc"], d["c_fc"], d["d_fc"] = folded(d["ln2"], p + "mlp.c_fc.weight", p + "mlp.c_fc.bias")
             self.layers.append(d)
         self.ln_f = (f32("gpt.ln_f.weight"), f32("gpt.ln_f.bias"))
         self.final_norm = (f32("final_norm.weight"), f32("final_norm.bias"))
@@ -98,10 +116,6 @@ class GPTEngine:
         self.share_kv_reads = os.environ.get("ITTS_SHARE_KV_READS", "1") != "0"   # ... and let the decode attention read them from row 0
         self.steps_per_graph = int(os.environ.get("ITTS_STEPS_PER_GRAPH", "1"))  # decode tokens per CUDA-graph replay; measured 1 > 2 > 4 > 8 (1297 / 1319 / 1342 / 1368 us per token)
         self._sink = torch.zeros(4, dtype=torch.int32, device=dev)
-        # arrival counters of the reducer tails: one per split-K launch site (2 per block), monotonic, never reset by the
-        # kernels; state[6] is the epoch the sites expect (advanced by embed_step once per decode step), state[7] the
-        # sticky error word of the tails
-        self.tail_cnt = torch.zeros(2 * layers, 8, dtype=torch.int32, device=dev)   # 8 shards per site
         self.weight_bytes = sum(t.numel() * t.element_size() for l in self.layers for t in
                                 (l["w_qkv"], l["w_o"], l["w_fc"], l["w_pr"])) + self.w_head.numel()
 
@@ -180,7 +194,6 @@ class GPTEngine:
         e._beam_cap = (0, 0, 0)
         e._kv_rows = None
         e._sink = torch.zeros(4, dtype=torch.int32, device=self.device)
-        e.tail_cnt = torch.zeros_like(self.tail_cnt)
         return e
 
     # ------------------------------------------------------------------------------------------------ buffers
@@ -201,6 +214,7 @@ class GPTEngine:
         self.a = torch.zeros(Bp, self.D, dtype=T, device=dev)
         self.f = torch.zeros(Bp, 4 * self.D, dtype=T, device=dev)
         self.xn = torch.zeros(Bp, self.D, dtype=T, device=dev)
+        self.hb = torch.zeros(Bp, self.D, dtype=T, device=dev)   # "fold" mode: T-typed packed copy of the residual rows
         self.slab = torch.zeros(self.KSPLIT, B, self.D + 64, dtype=torch.float32, device=dev)   # + runtime-LoRA columns
         self.logits = torch.zeros(B, self.V, dtype=torch.float32, device=dev)
         self.tokens = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -343,8 +357,7 @@ class GPTEngine:
             h = emb.view(B * S, D)[idx.to(dev)]
             h = self._blocks_full(h, B, S, None, True, row_off=row_off, cache_shift=self.pad[:B])
             self._head(h[last_rows].contiguous(), B)
-        self.state.zero_()                 # step, cache position, finished rows, ..., tail epoch [6], tail error [7]
-        self.tail_cnt.zero_()              # the reducer tails count from (epoch - 1) * workgroups: both restart together
+        self.state.zero_()                 # step, cache position, finished rows, arrival counter, seed (lo, hi)
         self.state[1] = S - 1
         self._pending_bump = False
         self.finished[:B] = 0
@@ -443,31 +456,48 @@ class GPTEngine:
                    self.stop_mel, dbg, no_advance=True, row_step0=self.row_step0)
         self._pending_bump = True
 
-    def _tail(self, site, h, xn, bias, ln, ln2=None):
-        t = dict(h=h, y=xn, bias=bias, w=ln[0], b=ln[1], counter=self.tail_cnt[site], epoch=self.state[6:7],
-                 err=self.state[7:8], acquire=self.tail_acquire, y_packed=self.pa)
-        if ln2 is not None:
-            t.update(w2=ln2[0], b2=ln2[1])
-        return t
+    def _fold_now(self, B):
+        return self.decode_mode == "fold" and not self.lora
 
     def _step_transformer(self, B, bump=None):
-        """(bump: advance step counter / cache position in this step's first LayerNorm launch; None = "a _sample call is
+        """(bump: advance step counter / cache position inside this step's first launches; None = "a _sample call is
         waiting for it", which is what the token loop wants; the beam step kernel advances the state itself.)
         Transformer part of one cached decode step (model.py:163-193): embed token k at mel position k+1, 24 blocks,
-        head.  "tail" form, 5 launches per block: QKV (+K/V append) -> attention -> out-proj (split-K slabs; tail: residual
-        update + LN2) -> FC + gelu -> FC2 (split-K slabs; tail: residual update + the NEXT block's LN1, or ln_f∘final_norm).
-        "launch" form, 7 per block: the two tails are itts_ln_reduce launches instead (same arithmetic, same bits)."""
+        head.  "fold" form, 5 launches per block: QKV' (LayerNorm folded in, + K/V append) -> attention -> out-projection
+        (+ residual update, T copy) -> FC' (folded, + gelu) -> FC2 (+ residual update, T copy); the loop state is advanced by
+        launches that do not read the word they bump (embed_step: cache position; the first QKV': step counter).
+        "launch" form, 7 per block: split-K slabs + [residual-reduce + LayerNorm] launches (itts_ln_reduce)."""
         T, D, H, KS = self.dtype, self.D, self.H, self.KSPLIT
         step, pos = self.state[0:1], self.state[1:2]
         h, xn, pa = self.h[:B], self.xn, self.pa   # xn / a / f: whole buffers (packed layout is addressed from the base)
-        slab = self.slab.view(-1)[: KS * B * D].view(KS, B, D)  # [ks][B][D] on a contiguous prefix of the buffer
-        tail = self.decode_mode == "tail" and B <= self.max_rows_per_launch and not self.lora   # tails carry no LoRA term
         if bump is None:
             bump = getattr(self, "_pending_bump", False)
         self._pending_bump = False
-        # mel position of token k is k + 1 (model.py:163-167); with a pending bump state[0] still holds k - 1
-        nat.embed_step(self.tokens, self.mel_emb, self.mel_pos, step, 2 if bump else 1, h, epoch=self.state[6:7],
-                       row_step0=self.row_step0 if self._kv_rows is None else None)
+        rs0 = self.row_step0 if self._kv_rows is None else None
+        if self._fold_now(B):
+            hb = self.hb
+            # mel position of token k is k + 1 (model.py:163-167); with a pending bump state[0] still holds k - 1
+            nat.embed_step(self.tokens, self.mel_emb, self.mel_pos, step, 2 if bump else 1, h, row_step0=rs0, h_packed=hb,
+                           bump=pos if bump else None)
+            r_o, r_p = self.fold_rows
+            for i, l in enumerate(self.layers):
+                nat.gemm_skinny(T, B, 3 * D, D, l["wf_qkv"], l["d_qkv"], x=hb, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
+                                vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s, x_packed=True, ln_c=l["c_qkv"],
+                                bump=step if (bump and i == 0) else None)
+                nat.attn_decode(self.q, self.kc[i], self.vc[i], self.a, self.pad, pos, B, H, self._cap_s, out_packed=pa,
+                                kv_rows=self._kv_rows, kv_step=step if self._kv_rows is not None else None,
+                                skip_rows=self.finished if self._kv_rows is None and self.skip_finished else None,
+                                kv_share=self.kv_share if self._kv_rows is None else None)
+                nat.gemm_skinny(T, B, D, D, l["w_o"], l["b_o"], x=self.a, epi=nat.EPI_RESID_F32, yf=h, y=hb, x_packed=pa,
+                                y_packed=True, rows_per_wg=r_o, wide_wg=self.fold_wide)
+                nat.gemm_skinny(T, B, 4 * D, D, l["wf_fc"], l["d_fc"], x=hb, epi=nat.EPI_GELU_STORE, y=self.f, x_packed=True,
+                                y_packed=pa, ln_c=l["c_fc"])
+                nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], l["b_pr"], x=self.f, epi=nat.EPI_RESID_F32, yf=h, y=hb, x_packed=pa,
+                                y_packed=True, rows_per_wg=r_p, wide_wg=self.fold_wide)
+            nat.ln_reduce(h, self.ln_f[0], self.ln_f[1], xn, w2=self.final_norm[0], b2=self.final_norm[1], y_packed=pa)
+            nat.gemm_skinny(T, B, self.V, D, self.w_head, self.b_head, x=self.xn, epi=nat.EPI_STORE_F32, yf=self.logits, x_packed=pa)
+            return
+        nat.embed_step(self.tokens, self.mel_emb, self.mel_pos, step, 2 if bump else 1, h, row_step0=rs0)
         nat.ln_reduce(h, self.layers[0]["ln1"][0], self.layers[0]["ln1"][1], xn, state_bump=self.state[0:2] if bump else None,
                       y_packed=pa)
         for i, l in enumerate(self.layers):
@@ -484,39 +514,28 @@ class GPTEngine:
                             kv_share=self.kv_share if self._kv_rows is None else None)
             nxt = self.ln_f if last else self.layers[i + 1]["ln1"]
             nxt2 = self.final_norm if last else None
-            if tail:
-                nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS, x_packed=pa,
-                                tail=self._tail(2 * i, h, xn, l["b_o"], l["ln2"]))
-                nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f, x_packed=pa, y_packed=pa)
-                nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], None, x=self.f, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS, x_packed=pa,
-                                tail=self._tail(2 * i + 1, h, xn, l["b_pr"], nxt, nxt2))
+            # out-projection: split-K slabs; with a runtime adapter the GEMM also produces x A in extra columns and the
+            # reduce launch adds (x A) B^T
+            sl_o = self.slab.view(-1)[: KS * B * n_o].view(KS, B, n_o)
+            nat.gemm_skinny(T, B, n_o, D, w_o, None, x=self.a, epi=nat.EPI_SLAB_F32, yf=sl_o, ksplit=KS,
+                            x_packed=pa)
+            nat.ln_reduce(h, l["ln2"][0], l["ln2"][1], xn, slab=sl_o, nslab=KS, bias=l["b_o"], y_packed=pa,
+                          slab_stride=n_o, lora_b=l.get("lora_b_o"))
+            nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f, x_packed=pa, y_packed=pa)
+            sl_p = self.slab.view(-1)[: KS * B * n_p].view(KS, B, n_p)
+            nat.gemm_skinny(T, B, n_p, 4 * D, w_pr, None, x=self.f, epi=nat.EPI_SLAB_F32, yf=sl_p, ksplit=KS,
+                            x_packed=pa)
+            if last:
+                nat.ln_reduce(h, nxt[0], nxt[1], xn, slab=sl_p, nslab=KS, bias=l["b_pr"], w2=nxt2[0], b2=nxt2[1], y_packed=pa,
+                              slab_stride=n_p, lora_b=l.get("lora_b_pr"))
             else:
-                # out-projection: split-K slabs; with a runtime adapter the GEMM also produces x A in extra columns and the
-                # reduce launch adds (x A) B^T
-                sl_o = self.slab.view(-1)[: KS * B * n_o].view(KS, B, n_o)
-                nat.gemm_skinny(T, B, n_o, D, w_o, None, x=self.a, epi=nat.EPI_SLAB_F32, yf=sl_o, ksplit=KS,
-                                x_packed=pa)
-                nat.ln_reduce(h, l["ln2"][0], l["ln2"][1], xn, slab=sl_o, nslab=KS, bias=l["b_o"], y_packed=pa,
-                              slab_stride=n_o, lora_b=l.get("lora_b_o"))
-                nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f, x_packed=pa, y_packed=pa)
-                sl_p = self.slab.view(-1)[: KS * B * n_p].view(KS, B, n_p)
-                nat.gemm_skinny(T, B, n_p, 4 * D, w_pr, None, x=self.f, epi=nat.EPI_SLAB_F32, yf=sl_p, ksplit=KS,
-                                x_packed=pa)
-                if last:
-                    nat.ln_reduce(h, nxt[0], nxt[1], xn, slab=sl_p, nslab=KS, bias=l["b_pr"], w2=nxt2[0], b2=nxt2[1], y_packed=pa,
-                                  slab_stride=n_p, lora_b=l.get("lora_b_pr"))
-                else:
-                    nat.ln_reduce(h, nxt[0], nxt[1], xn, slab=sl_p, nslab=KS, bias=l["b_pr"], y_packed=pa, slab_stride=n_p,
-                                  lora_b=l.get("lora_b_pr"))
+                nat.ln_reduce(h, nxt[0], nxt[1], xn, slab=sl_p, nslab=KS, bias=l["b_pr"], y_packed=pa, slab_stride=n_p,
+                              lora_b=l.get("lora_b_pr"))
         nat.gemm_skinny(T, B, self.V, D, self.w_head, self.b_head, x=self.xn, epi=nat.EPI_STORE_F32, yf=self.logits, x_packed=pa)
 
     def _poll(self):
-        """One host synchronisation of the token loop: (finished rows, raises if a reducer tail reported an error)."""
-        st = self.state.tolist()
-        if st[7] != 0:
-            raise nat.NativeError(f"decode step: reducer tail error {st[7]} (1 = a reducer waited too long for its launch's "
-                                  f"tickets, 2 = counter/epoch out of step); the generated tokens are invalid")
-        return st[2]
+        """One host synchronisation of the token loop: the number of finished rows."""
+        return int(self.state[2].item())
 
     def _step_kernels(self, B, sp):
         self._step_transformer(B)
@@ -524,32 +543,35 @@ class GPTEngine:
 
     def gemm_launches_of_step(self, B):
         """Measurement aid (bench.py): ONLY the skinny-GEMM launches of one decode step, with the step's real arguments
-        (97 launches: 4 per block + the head; in "tail" mode the split-K ones carry their reducer tails, and one
-        embed_step launch in front advances the tails' epoch).  Returns (GEMM launch count, algorithmic bytes: weights
-        once + activations; the tails add the residual rows they read and write)."""
+        (97 launches: 4 per block + the head).  Returns (GEMM launch count, algorithmic bytes: weights once + activations in
+        and out; "fold" mode: the residual rows the two epilogues read and write and their T copy; "launch" mode: the slabs)."""
         T, D, H, KS = self.dtype, self.D, self.H, self.KSPLIT
         pos = self.state[1:2]
         h, xn, pa = self.h[:B], self.xn, self.pa
-        slab = self.slab.view(-1)[: KS * B * D].view(KS, B, D)
         es = 4 if T == torch.float32 else 2
-        tail = self.decode_mode == "tail" and B <= self.max_rows_per_launch
+        fold = self._fold_now(B)
         nbytes, n = 0, 0
-        if tail:
-            nat.embed_step(self.tokens, self.mel_emb, self.mel_pos, self.state[0:1], 1, h, epoch=self.state[6:7])
+        slab = self.slab.view(-1)[: KS * B * D].view(KS, B, D)
+        r_o, r_p = self.fold_rows
         for i, l in enumerate(self.layers):
-            last = i + 1 == self.L
-            nxt = self.ln_f if last else self.layers[i + 1]["ln1"]
-            nxt2 = self.final_norm if last else None
-            nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv"], l["b_qkv"], x=xn, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
-                            vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s, x_packed=pa)
-            nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS, x_packed=pa,
-                            tail=self._tail(2 * i, h, xn, l["b_o"], l["ln2"]) if tail else None)
-            nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f, x_packed=pa, y_packed=pa)
-            nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], None, x=self.f, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS, x_packed=pa,
-                            tail=self._tail(2 * i + 1, h, xn, l["b_pr"], nxt, nxt2) if tail else None)
-            nbytes += 12 * D * D * es + B * D * es * (1 + 1 + 1 + 4) + B * es * (3 * D + 4 * D) + 2 * KS * B * D * 4
-            if tail:
-                nbytes += 2 * (KS * B * D * 4 + 2 * B * D * 4 + B * D * es)   # slabs read back, h read + written, xn written
+            if fold:
+                hb = self.hb
+                nat.gemm_skinny(T, B, 3 * D, D, l["wf_qkv"], l["d_qkv"], x=hb, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
+                                vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s, x_packed=True, ln_c=l["c_qkv"])
+                nat.gemm_skinny(T, B, D, D, l["w_o"], l["b_o"], x=self.a, epi=nat.EPI_RESID_F32, yf=h, y=hb, x_packed=pa,
+                                y_packed=True, rows_per_wg=r_o, wide_wg=self.fold_wide)
+                nat.gemm_skinny(T, B, 4 * D, D, l["wf_fc"], l["d_fc"], x=hb, epi=nat.EPI_GELU_STORE, y=self.f, x_packed=True,
+                                y_packed=pa, ln_c=l["c_fc"])
+                nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], l["b_pr"], x=self.f, epi=nat.EPI_RESID_F32, yf=h, y=hb, x_packed=pa,
+                                y_packed=True, rows_per_wg=r_p, wide_wg=self.fold_wide)
+                nbytes += 12 * D * D * es + B * D * es * (1 + 1 + 1 + 4) + B * es * (3 * D + 4 * D) + 2 * (2 * B * D * 4 + B * D * es)
+            else:
+                nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv"], l["b_qkv"], x=xn, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
+                                vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s, x_packed=pa)
+                nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS, x_packed=pa)
+                nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f, x_packed=pa, y_packed=pa)
+                nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], None, x=self.f, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS, x_packed=pa)
+                nbytes += 12 * D * D * es + B * D * es * (1 + 1 + 1 + 4) + B * es * (3 * D + 4 * D) + 2 * KS * B * D * 4
             n += 4
         nat.gemm_skinny(T, B, self.V, D, self.w_head, self.b_head, x=self.xn, epi=nat.EPI_STORE_F32, yf=self.logits, x_packed=pa)
         nbytes += self.V * D * es + B * D * es + B * self.V * 4
@@ -704,8 +726,11 @@ class GPTEngine:
         if self._shared_prefix is not None or self._kv_rows is not None:
             raise ValueError("decode_refill(): num_beams = 1 only")
         limit = self._cap_s if positions is None else min(self._cap_s, int(positions))
-        if S + max_new + 1 > limit:
-            raise ValueError("decode_refill(): the position budget does not hold one utterance of max_new tokens")
+        if S + max_new + check_every > limit:
+            # the loop runs whole blocks of check_every steps before it looks at the flags again: the last rows can take
+            # the loop check_every - 1 steps past max_new, and every step appends one K / V position for every slot
+            raise ValueError("decode_refill(): the position budget must hold max_new + check_every positions behind the prompt "
+                             "(prefill(max_new + check_every))")
         dev = self.device
         fs = [-1] * B if force_stop is None else [int(v) for v in force_stop]
         fs = [max_new - 1 if v < 0 else min(v, max_new - 1) for v in fs]

@@ -667,7 +667,8 @@ class IndexTTS:
         while queue:
             first, queue = queue[:slots], queue[slots:]
             emb, pad = prefixes(first)
-            eng.prefill(emb, pad, max(max_mel_tokens + 2, int(cache_positions) - emb.shape[1] - 2),
+            # the loop runs whole blocks of check_every steps: the cache has to hold that many positions past max_mel_tokens
+            eng.prefill(emb, pad, max(max_mel_tokens + int(check_every) + 1, int(cache_positions) - emb.shape[1] - 2),
                         shared_rows=int(conds.shape[1]) if conds.shape[0] == 1 else 0)
             entered = list(first)
 
@@ -682,7 +683,7 @@ class IndexTTS:
                 return [(e[j, p[j]:], stops[i]) for j, i in enumerate(take)]
 
             codes, leftover = eng.decode_refill(max_mel_tokens, sp, feed, force_stop=[stops[i] for i in first],
-                                                positions=max(int(cache_positions), eng._S + max_mel_tokens + 2),
+                                                positions=max(int(cache_positions), eng._S + max_mel_tokens + int(check_every) + 1),
                                                 check_every=int(check_every), staged=bool(staged))
             if leftover:                                               # fed but not placed: back to the head of the queue
                 back = entered[len(entered) - len(leftover):]

@@ -682,9 +682,9 @@ def test_beam_graphs_follow_their_buffers(gpt_small_fp32):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_packed_activations_and_tail_mode_give_the_same_bits(dtype):
-    """The decode loop's variants -- packed vs row-major activations, [reduce + LayerNorm] as launches vs as reducer tails
-    of the split-K GEMMs -- are re-arrangements of the same arithmetic: identical logits and codes, step for step."""
+def test_packed_and_row_major_activations_give_the_same_bits(dtype):
+    """Packed vs row-major activations in the 7-launch decode step are re-arrangements of the same arithmetic: identical
+    logits and codes, step for step."""
     m = make_gpt(2, dtype)
     eng = m.engine
     g = np.load(os.path.join(G, "gpt_small.npz"))
@@ -695,13 +695,70 @@ def test_packed_activations_and_tail_mode_give_the_same_bits(dtype):
     pad = (mask == 0).sum(1).to(torch.int32)
     sp = dict(do_sample=True, top_p=0.8, top_k=30, temperature=1.0, repetition_penalty=10.0, seed=9)
     outs = []
-    for pa, mode in ((True, "launch"), (False, "launch"), (True, "tail"), (False, "tail")):
-        eng.pa, eng.decode_mode = pa, mode
+    eng.decode_mode = "launch"
+    for pa in (True, False):
+        eng.pa = pa
         eng._graphs.clear()
         eng.prefill(emb, pad, 20)
         outs.append(eng.decode(20, sp, return_logits=True))
     for codes, logits in outs[1:]:
         assert torch.equal(codes, outs[0][0]) and torch.equal(logits, outs[0][1])
+
+
+def test_folded_decode_step_tracks_the_seven_launch_form():
+    """bf16 decode loop, LayerNorm folded into the QKV / FC GEMMs (5 launches per block, the default) against the 7-launch form
+    on the same weights, teacher-forced with the 7-launch form's greedy codes: the two differ only in where values are rounded
+    to bf16 (raw residual rows vs normalised rows; gamma . W vs W), so the logits agree within the bf16 noise floor of either --
+    measured against the fp32 engine on the same inputs, the folded form must not be further away than the 7-launch form by more
+    than a small factor.  Also: graph replay == eager launches bit for bit in the folded form, geometry hints do not change
+    the codes' validity, and the loop state (step, cache position) advances exactly once per token."""
+    steps = 24
+    m32, m16 = make_gpt(2, torch.float32), make_gpt(2, torch.bfloat16)
+    g = np.load(os.path.join(G, "gpt_small.npz"))
+    cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
+    text = torch.from_numpy(g["text"]).to(DEV)
+    sp = dict(do_sample=False, top_p=1.0, top_k=0, temperature=1.0, repetition_penalty=10.0, seed=0)
+
+    from indextts.utils.accuracy import teacher_forced_logits
+
+    def run(m, mode, force=None, use_graph=False):
+        eng = m.engine
+        eng.decode_mode = mode
+        eng._graphs.clear()
+        conds = m.get_conditioning(cond_mel, None)
+        _, emb, mask = m.prepare_gpt_inputs(conds, text)
+        pad = (mask == 0).sum(1).to(torch.int32)
+        if force is None:
+            eng.prefill(emb, pad, steps + 2)
+            codes, logits = eng.decode(steps, sp, return_logits=True, use_graph=use_graph)
+        else:
+            codes, logits = force, teacher_forced_logits(eng, emb, pad, force, steps)
+            eng._sample(eng._B, eng._seed_to_state(sp))
+        torch.cuda.synchronize()
+        return codes, logits, eng.state.tolist()
+
+    c32, l32, _ = run(m32, "launch")
+    _, l_launch, st_l = run(m16, "launch", force=c32)
+    _, l_fold, st_f = run(m16, "fold", force=c32)
+    assert st_l[:2] == st_f[:2]                                   # same step counter and cache position after the same steps
+    assert l_launch.shape == l_fold.shape == l32.shape
+    e_launch = (l_launch - l32).abs().max().item()
+    e_fold = (l_fold - l32).abs().max().item()
+    assert e_fold < max(2.0 * e_launch, 0.05), (e_fold, e_launch)
+    rms_l = (l_launch - l32).pow(2).mean().sqrt().item()
+    rms_f = (l_fold - l32).pow(2).mean().sqrt().item()
+    assert rms_f < 1.6 * rms_l + 1e-3, (rms_f, rms_l)
+    # free-running: graph replay == eager, both modes agree on the greedy codes wherever the fp32 margin is not tiny
+    ce, le, _ = run(m16, "fold")
+    cg, lg, stg = run(m16, "fold", use_graph=True)
+    assert torch.equal(ce, cg) and torch.equal(le, lg)
+    assert stg[0] == steps - 1 and stg[1] == m16.engine._S - 1 + steps - 1
+    for rows in ((0, 0), (16, 16), (32, 16)):
+        for wide in (False, True):
+            m16.engine.fold_rows, m16.engine.fold_wide = list(rows), wide
+            _, lv, _ = run(m16, "fold", force=c32)
+            assert (lv - l32).abs().max().item() < max(2.0 * e_launch, 0.05)
+    m16.engine.fold_rows, m16.engine.fold_wide = [16, 16], True
 
 
 def test_runtime_lora_equals_merged_checkpoint():

@@ -109,6 +109,10 @@ def test_gemm_skinny_plain(nat, dtype, M, N, K):
     assert (yf - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
     h0 = rnd(M, N, seed=13)
     hres = h0.clone()
+    if N % 4:   # the residual epilogue moves whole 16-byte groups (documented): refused, nothing launched
+        with pytest.raises(nat.NativeError):
+            nat.gemm_skinny(dtype, M, N, K, wp, None, x=x, epi=nat.EPI_RESID_F32, yf=hres)
+        return
     nat.gemm_skinny(dtype, M, N, K, wp, None, x=x, epi=nat.EPI_RESID_F32, yf=hres)
     assert (hres - (h0 + x.float() @ w.float())).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
 
@@ -585,7 +589,7 @@ def test_gemm_skinny_many_rows_one_weight_pass(nat, dtype, M, N, K):
 @pytest.mark.parametrize("dtype,M", [(torch.bfloat16, 32), (torch.bfloat16, 13), (torch.bfloat16, 96), (torch.float32, 32), (torch.float16, 40)])
 def test_packed_activation_layout_end_to_end(nat, dtype, M):
     """The packed activation layout (include/indextts_hip.h) through its producers and its consumer: itts_ln_reduce
-    (y_packed), itts_attn_decode (out_packed), itts_gemm_skinny (x_packed, y_packed with gelu, tail_y_packed) give the SAME
+    (y_packed), itts_attn_decode (out_packed), itts_gemm_skinny (x_packed, y_packed with gelu) give the SAME
     BITS as the row-major forms, and the packing matches the documented index formula (nat.pack_activation)."""
     D, H = 1280, 20
     # the layout itself: element (m, k) where the header says
@@ -615,7 +619,7 @@ def test_packed_activation_layout_end_to_end(nat, dtype, M):
     nat.gemm_skinny(dtype, M, 4 * D, D, wp, bias, x=y_rm, epi=nat.EPI_GELU_STORE, y=f_rm)
     nat.gemm_skinny(dtype, M, 4 * D, D, wp, bias, x=y_pk, epi=nat.EPI_GELU_STORE, y=f_pk, x_packed=True, y_packed=True)
     assert torch.equal(nat.unpack_activation(f_pk, M, 4 * D), f_rm)
-    # split-K slabs from a packed operand, and the reducer tail writing a packed y
+    # split-K slabs from a packed operand
     w2 = (rnd(4 * D, D, seed=206) * 0.03).to(dtype)
     wp2 = nat.pack_weight(w2)
     KSP = 3
@@ -623,16 +627,6 @@ def test_packed_activation_layout_end_to_end(nat, dtype, M):
     nat.gemm_skinny(dtype, M, D, 4 * D, wp2, None, x=f_rm, epi=nat.EPI_SLAB_F32, yf=slab_rm, ksplit=KSP)
     nat.gemm_skinny(dtype, M, D, 4 * D, wp2, None, x=f_pk, epi=nat.EPI_SLAB_F32, yf=slab_pk, ksplit=KSP, x_packed=True)
     assert torch.equal(slab_pk, slab_rm)
-    if M <= (16 if dtype == torch.float32 else 96):
-        h_ref, xn_ref = h.clone(), torch.empty(M, D, dtype=dtype, device=DEV)
-        nat.ln_reduce(h_ref, lw, lb, xn_ref, slab=slab_rm, nslab=KSP, bias=bias[:D].contiguous())
-        cnt, st = torch.zeros(8, dtype=torch.int32, device=DEV), torch.zeros(8, dtype=torch.int32, device=DEV)
-        st[6] = 1
-        h_t, xn_t = h.clone(), torch.zeros(mtp * 16 * D, dtype=dtype, device=DEV)
-        nat.gemm_skinny(dtype, M, D, 4 * D, wp2, None, x=f_pk, epi=nat.EPI_SLAB_F32, yf=slab_pk, ksplit=KSP, x_packed=True,
-                        tail=dict(h=h_t, y=xn_t, bias=bias[:D].contiguous(), w=lw, b=lb, counter=cnt, epoch=st[6:7], err=st[7:8], y_packed=True))
-        torch.cuda.synchronize()
-        assert st[7].item() == 0 and torch.equal(h_t, h_ref) and torch.equal(nat.unpack_activation(xn_t, M, D), xn_ref)
     # decode attention producer
     smax, ctx = 64, 41
     q = rnd(M, D, seed=207).to(dtype)
@@ -712,56 +706,130 @@ def test_gemm_skinny_qkv_cache_epilogue_many_rows(nat):
     assert kc.abs().max().item() == 0 and vc.abs().max().item() == 0
 
 
-@pytest.mark.parametrize("dtype,M", [(torch.bfloat16, 32), (torch.bfloat16, 96), (torch.bfloat16, 5), (torch.float32, 16), (torch.float16, 48)])
-@pytest.mark.parametrize("K,two", [(1280, False), (5120, True)])
-def test_gemm_skinny_reducer_tail_equals_ln_reduce_launch(nat, dtype, M, K, two):
-    """Split-K launch with the reducer tail (slab tiles stored write-through, arrival tickets, the last M arrivals reduce
-    one row each) against the two-launch form itts_gemm_skinny(slabs) -> itts_ln_reduce: residual stream, normalised rows
-    and slabs must be IDENTICAL BITS, many rounds in a row on the same buffers (the reducers' caches hold the previous
-    round's slab lines: a stale read shows as a mismatch), with a streaming kernel queued in between to perturb arrival
-    order.  Counter protocol: monotonic counter, epoch advanced once per round."""
-    N, KS = 1280, 3
-    w = (rnd(K, N, seed=150) * 0.03).to(dtype)
+@pytest.mark.parametrize("dtype,M", [(torch.bfloat16, 32), (torch.bfloat16, 96), (torch.bfloat16, 5), (torch.float16, 48)])
+@pytest.mark.parametrize("N,epi", [(3840, "qkv"), (5120, "gelu"), (256, "store")])
+def test_gemm_skinny_layernorm_folded_into_the_gemm(nat, dtype, M, N, epi):
+    """LN(h; gamma, beta) W + b with the LayerNorm folded into the GEMM (itts_skinny_args.ln_c): the kernel multiplies the RAW
+    rows by pack(gamma . W), takes mean / rstd of the rows from its own operand fragments (matrix pipe) and applies
+    rstd (acc - mean c) + d in the epilogue.  Held against (a) the exact fp32 formula on the T-rounded rows -- what the kernel
+    computes, up to fp32 summation order -- and (b) the two-launch form it replaces (LayerNorm launch -> plain GEMM), whose
+    only difference is WHERE the rounding to T happens.  Rows with a large common offset (|mean| = 8 sigma) included: the
+    cancellation in acc - mean c is the risk of this form."""
+    D, H = 1280, 20
+    if epi == "qkv":
+        N = 3 * D
+    h = rnd(M, D, seed=400, scale=1.5)
+    h[M // 2] += 12.0                                   # |mean| >> sigma on one row
+    h[0, 7] = 60.0                                      # an outlier feature
+    gamma, beta = 1.0 + 0.2 * rnd(D, seed=401), 0.2 * rnd(D, seed=402)
+    W = rnd(D, N, seed=403) * 0.03
+    b = rnd(N, seed=404)
+    hb = h.to(dtype)
+    Wr = (gamma[:, None] * W).to(dtype)
+    c = Wr.double().sum(0).float().contiguous()
+    d = (beta.double() @ W.double() + b.double()).float().contiguous()
+    wp = nat.pack_weight(Wr.contiguous())
+    x_pk = nat.pack_activation(hb)
+    # exact formula on the rounded operands
+    hd = hb.double()
+    mean, var = hd.mean(1, keepdim=True), hd.var(1, unbiased=False, keepdim=True)
+    ref = ((hd - mean) / torch.sqrt(var + 1e-5)) @ Wr.double() + d.double()
+    if epi == "gelu":
+        ref = F.gelu(ref, approximate="tanh")
+    ref = ref.float()
+    mtp = (M + 15) // 16
+    if epi == "qkv":
+        smax, pos = 64, 9
+        q = torch.empty(M, D, dtype=dtype, device=DEV)
+        kc = torch.zeros(M, H, smax, 64, dtype=dtype, device=DEV)
+        vc = torch.zeros_like(kc)
+        posd = torch.tensor([pos], dtype=torch.int32, device=DEV)
+        word = torch.zeros(1, dtype=torch.int32, device=DEV)
+        nat.gemm_skinny(dtype, M, N, D, wp, d, x=x_pk, epi=nat.EPI_QKV_CACHE, y=q, kcache=kc, vcache=vc, pos=posd, heads=H, smax=smax,
+                        x_packed=True, ln_c=c, bump=word)
+        assert word.item() == 1                          # the launch advances the word it was given, once
+        got = torch.cat([q.float(), kc[:, :, pos].reshape(M, D).float(), vc[:, :, pos].reshape(M, D).float()], 1)
+    else:
+        y = torch.zeros(mtp * 16 * N, dtype=dtype, device=DEV)
+        nat.gemm_skinny(dtype, M, N, D, wp, d, x=x_pk, epi=nat.EPI_GELU_STORE if epi == "gelu" else nat.EPI_STORE, y=y,
+                        x_packed=True, y_packed=True, ln_c=c)
+        got = nat.unpack_activation(y, M, N).float()
+        # the row-major operand gives the same bits
+        y2 = torch.empty(M, N, dtype=dtype, device=DEV)
+        nat.gemm_skinny(dtype, M, N, D, wp, d, x=hb, epi=nat.EPI_GELU_STORE if epi == "gelu" else nat.EPI_STORE, y=y2, ln_c=c)
+        assert torch.equal(y2, nat.unpack_activation(y, M, N))
+    # (a) the kernel's own arithmetic: only the output rounding to T (2^-9 relative) and fp32 summation order separate them
+    err = (got - ref).abs()
+    assert (err / (ref.abs() + 1.0)).max().item() < 6e-3, (err.max().item(), ref.abs().max().item())
+    # (b) the form it replaces: LayerNorm launch (rounds LN(h) to T) -> GEMM on W (rounded to T)
+    xn = torch.empty(M, D, dtype=dtype, device=DEV)
+    nat.ln_reduce(h.clone(), gamma, beta, xn)
+    old = xn.float() @ W.to(dtype).float() + b
+    if epi == "gelu":
+        old = F.gelu(old, approximate="tanh")
+    ref_true = F.layer_norm(h, (D,), gamma, beta, 1e-5) @ W + b
+    if epi == "gelu":
+        ref_true = F.gelu(ref_true, approximate="tanh")
+    e_new = (got - ref_true).pow(2).mean().sqrt().item()
+    e_old = (old - ref_true).pow(2).mean().sqrt().item()
+    assert e_new < 2.5 * e_old + 1e-3, (e_new, e_old)    # same accuracy class as the two-launch form
+
+
+@pytest.mark.parametrize("dtype,M", [(torch.bfloat16, 32), (torch.bfloat16, 96), (torch.bfloat16, 21), (torch.float32, 16), (torch.float16, 40)])
+@pytest.mark.parametrize("K", [1280, 5120])
+@pytest.mark.parametrize("rows_per_wg,wide", [(0, False), (16, False), (16, True), (32, True)])
+def test_gemm_skinny_residual_epilogue_with_packed_copy(nat, dtype, M, K, rows_per_wg, wide):
+    """h += x W + b in the GEMM's epilogue (ITTS_EPI_RESID_F32, no split-K: one owner per element) with a T-typed packed copy of
+    the new rows beside it -- the producer side of the LayerNorm-folded decode block -- in every launch geometry (rows dealt
+    to grid.z, 16-wave workgroups).  The fp32 result equals the split-K + itts_ln_reduce form up to summation order."""
+    N = 1280
+    x = rnd(M, K, seed=410).to(dtype)
+    w = (rnd(K, N, seed=411) * 0.03).to(dtype)
     wp = nat.pack_weight(w)
-    ob = rnd(N, seed=151)
-    lw, lb = 1.0 + 0.1 * rnd(N, seed=152), 0.1 * rnd(N, seed=153)
-    lw2, lb2 = (1.0 + 0.1 * rnd(N, seed=154), 0.1 * rnd(N, seed=155)) if two else (None, None)
-    cnt = torch.zeros(8, dtype=torch.int32, device=DEV)     # arrival counter, 8 shards
-    st = torch.zeros(8, dtype=torch.int32, device=DEV)      # [6] epoch, [7] error
-    slab_a = torch.zeros(KS, M, N, device=DEV)
-    slab_b = torch.zeros(KS, M, N, device=DEV)
-    h_a, xn_a = torch.zeros(M, N, device=DEV), torch.zeros(M, N, dtype=dtype, device=DEV)
-    big = torch.zeros(64 << 20, device=DEV)
-    plan = nat.skinny_plan(dtype, M, N, K, KS)
-    W = plan["grid"][0] * plan["grid"][1]
-    assert M <= W <= 256
-    for it in range(12):
-        x = rnd(M, K, seed=160 + it).to(dtype)
-        h0 = rnd(M, N, seed=180 + it, scale=2.0) + 0.3
-        # launch form
-        h_b, xn_b = h0.clone(), torch.empty(M, N, dtype=dtype, device=DEV)
-        nat.gemm_skinny(dtype, M, N, K, wp, None, x=x, epi=nat.EPI_SLAB_F32, yf=slab_b, ksplit=KS)
-        nat.ln_reduce(h_b, lw, lb, xn_b, slab=slab_b, nslab=KS, bias=ob, w2=lw2, b2=lb2)
-        # tail form, same buffers every round
-        h_a.copy_(h0)
-        xn_a.fill_(7.0)
-        st[6] += 1
-        if it % 2:
-            big.add_(1.0)                                    # 256 MiB of streaming traffic right in front of the launch
-        tail = dict(h=h_a, y=xn_a, bias=ob, w=lw, b=lb, counter=cnt, epoch=st[6:7], err=st[7:8], acquire=it % 3 == 2)
-        if two:
-            tail.update(w2=lw2, b2=lb2)
-        nat.gemm_skinny(dtype, M, N, K, wp, None, x=x, epi=nat.EPI_SLAB_F32, yf=slab_a, ksplit=KS, tail=tail)
-        torch.cuda.synchronize()
-        assert st[7].item() == 0
-        assert cnt.sum().item() == (it + 1) * W and cnt.max().item() - cnt.min().item() <= it + 1
-        assert torch.equal(slab_a, slab_b), f"round {it}: slabs"
-        assert torch.equal(h_a, h_b), f"round {it}: residual stream"
-        assert torch.equal(xn_a, xn_b), f"round {it}: LayerNorm rows"
-    # a launch whose epoch was not advanced finds the shards beyond their expected value: flagged, not silently wrong
-    nat.gemm_skinny(dtype, M, N, K, wp, None, x=x, epi=nat.EPI_SLAB_F32, yf=slab_a, ksplit=KS, tail=tail)
-    torch.cuda.synchronize()
-    assert st[7].item() == 2
+    b = rnd(N, seed=412)
+    h0 = rnd(M, N, seed=413, scale=2.0)
+    mtp = (M + 15) // 16
+    h = h0.clone()
+    hb = torch.zeros(mtp * 16 * N, dtype=dtype, device=DEV)
+    nat.gemm_skinny(dtype, M, N, K, wp, b, x=nat.pack_activation(x), epi=nat.EPI_RESID_F32, yf=h, y=hb, x_packed=True, y_packed=True,
+                    rows_per_wg=rows_per_wg, wide_wg=wide)
+    ref = h0.double() + x.double() @ w.double() + b.double()
+    assert (h.double() - ref).abs().max().item() < (2e-4 if dtype == torch.float32 else 2e-3)
+    assert torch.equal(nat.unpack_activation(hb, M, N), h.to(dtype))          # the copy is the rounded new row
+    if M % 16:
+        assert nat.unpack_activation(hb, mtp * 16, N)[M:].float().abs().max().item() == 0   # padding rows untouched
+    # row-major copy, no copy
+    h2, hb2 = h0.clone(), torch.empty(M, N, dtype=dtype, device=DEV)
+    nat.gemm_skinny(dtype, M, N, K, wp, b, x=x, epi=nat.EPI_RESID_F32, yf=h2, y=hb2, rows_per_wg=rows_per_wg, wide_wg=wide)
+    assert torch.equal(h2, h) and torch.equal(hb2, h.to(dtype))
+    h3 = h0.clone()
+    nat.gemm_skinny(dtype, M, N, K, wp, b, x=x, epi=nat.EPI_RESID_F32, yf=h3, rows_per_wg=rows_per_wg, wide_wg=wide)
+    assert torch.equal(h3, h)
+    plan = nat.skinny_plan(dtype, M, N, K, 1, rows_per_wg, wide)
+    assert plan["grid"][2] * plan["row_tiles_per_wg"] * 16 >= min(M, 16 if dtype == torch.float32 else 96) and plan["waves"] in (8, 16)
+
+
+def test_embed_step_packed_copy_bump_and_position_clamp(nat):
+    """itts_embed_step: fp32 rows + the T-typed packed copy, the word it advances, per-row clocks, and the clamp of the
+    position index (a finished slot that keeps stepping must not read past the table)."""
+    B, D, V, P = 21, 1280, 50, 12
+    table, ptab = rnd(V, D, seed=420), rnd(P, D, seed=421)
+    tokens = torch.arange(B, dtype=torch.int32, device=DEV) % V
+    step = torch.tensor([5], dtype=torch.int32, device=DEV)
+    word = torch.tensor([40], dtype=torch.int32, device=DEV)
+    step0 = torch.zeros(B, dtype=torch.int32, device=DEV)
+    step0[3] = 4
+    step0[4] = -100                                       # position 107 -> clamped to the last row
+    step0[5] = 50                                         # negative position -> clamped to row 0
+    for dtype in (torch.bfloat16, torch.float32):
+        h = torch.zeros(B, D, device=DEV)
+        hp = torch.zeros(nat.packed_rows(B) * D, dtype=dtype, device=DEV)
+        nat.embed_step(tokens, table, ptab, step, 2, h, bump=word, row_step0=step0, h_packed=hp)
+        pos = (5 - step0 + 2).clamp(0, P - 1).long()
+        ref = table[tokens.long()] + ptab[pos]
+        assert torch.equal(h, ref)
+        assert torch.equal(nat.unpack_activation(hp, B, D), ref.to(dtype))
+    assert word.item() == 42 and step.item() == 5
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Microseconds per decode token of the GPT engine alone (BASELINE config 3 shape: 24 layers, bf16, 32 rows, ~72-position
 prompt, 140 tokens, graph replay).  Appends to gpurun_out/token_time.txt.
-usage: decode_token_time.py [label ...]   (labels only tag the output lines; engine knobs come from the environment, e.g.
-ITTS_KSPLIT, ITTS_DECODE_MODE; ITTS_TOKENS shortens the run)"""
+usage: decode_token_time.py [setting ...]   A setting is a label, or engine attributes to set for that arm in the SAME process,
+same box:  mode=launch   mode=fold,rows=16:16,wide=1   mode=fold,rows=0:16,wide=0   (decode_mode, fold_rows = out-projection :
+FC2 rows per workgroup, fold_wide).  Other knobs come from the environment (ITTS_KSPLIT ...); ITTS_TOKENS shortens the run."""
 import os
 import sys
 import time
@@ -29,6 +30,15 @@ out = open(os.path.join(ROOT, "gpurun_out", "token_time.txt"), "a")
 ref = None
 for rep in range(2):
     for st in settings:
+        for kv in st.split(","):
+            if "=" in kv:
+                k, v = kv.split("=", 1)
+                if k == "mode":
+                    eng.decode_mode = v
+                elif k == "rows":
+                    eng.fold_rows = [int(x) for x in v.split(":")]
+                elif k == "wide":
+                    eng.fold_wide = v == "1"
         eng._graphs.clear()
         eng.prefill(prefix, pad, NEW + 2)
         codes = eng.decode(NEW, sp, force_stop=[NEW - 1] * B)   # warm-up + capture
@@ -41,7 +51,7 @@ for rep in range(2):
         if ref is None:
             ref = codes.clone()
         same = bool((codes == ref).all())
-        line = f"{st:10s} {us:8.1f} us/token  codes_equal_to_first={same}"
+        line = f"{st:32s} {us:8.1f} us/token  codes_equal_to_first={same}"
         print(line, flush=True)
         out.write(line + "\n")
         out.flush()

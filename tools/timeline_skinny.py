@@ -11,7 +11,7 @@ Printed per GEMM kind (median over the step's launches of that kind, us): dispat
 segment medians over workgroups, kernel span (first entry to last exit), and the gap to the NEXT kernel's first entry.
 Read the SHARES, not the lengths: the diagnostic waits forbid overlaps the product kernel has.
 
-    ITTS_HIP_LIB=index-tts-lora_amd/indextts/_lib/libindextts_hip_diag.so python tools/timeline_skinny.py [--mode tail|launch]
+    ITTS_HIP_LIB=index-tts-lora_amd/indextts/_lib/libindextts_hip_diag.so python tools/timeline_skinny.py [--mode fold|launch]
 """
 import argparse
 import ctypes
@@ -30,7 +30,7 @@ import torch  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", default="tail")
+    ap.add_argument("--mode", default="fold")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--layers", type=int, default=24)
     ap.add_argument("--out", default=None)
