@@ -179,12 +179,25 @@ def make_workload(config: int, world: int):
     return texts, stops
 
 
+def host_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup's CPU quota (a GPU box's per-GPU CPU share is
+    smaller than the mask of the whole host: more threads than that only oversubscribe)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(gsd, bsd, cond_conds, texts, rows=4, n_tokens=MEL_TOKENS, seed=2000):
     """Oracle (oracle/*.py, fp32, torch CPU) on `rows` of the benched utterances as ONE left-padded batch, the benched
     sampling settings (repetition penalty 10, top-k 30, top-p 0.8, Philox draw), n_tokens acoustic tokens each:
     prefix -> prefill -> cached sampling loop -> latent pass -> BigVGAN.  Returns (audio_s_per_s, cores, description)."""
     from oracle import bigvgan_ref, gpt_ref, sampling_ref
-    cores = len(os.sched_getaffinity(0))   # every core the affinity mask gives this process (BASELINE.md section 4)
+    cores = host_cores()   # every core this process may use (BASELINE.md section 4): affinity mask, capped by the cgroup quota
     torch.set_num_threads(cores)
     W = {k: v.float() for k, v in gsd.items() if k.startswith(("gpt.", "final_norm", "mel_", "text_"))}
     sel = texts[:rows]
@@ -210,6 +223,8 @@ def cpu_baseline(gsd, bsd, cond_conds, texts, rows=4, n_tokens=MEL_TOKENS, seed=
             codes[b].append(tok)
         if s == n_tokens:
             break
+        if s % 35 == 0:
+            log(f"[bench] cpu baseline: token {s} / {n_tokens} ({time.perf_counter() - t0:.1f}s)")
         mask = torch.cat([mask, torch.ones(rows, 1, dtype=torch.bool)], 1)
         lg, past = gpt_ref.decode_step(torch.tensor(toks), s, mask, past, W)
     n_audio = 0
@@ -219,7 +234,7 @@ def cpu_baseline(gsd, bsd, cond_conds, texts, rows=4, n_tokens=MEL_TOKENS, seed=
         n_audio += wav.shape[-1]
     dt = time.perf_counter() - t0
     return n_audio / 24000.0 / dt, cores, (
-        f"oracle fp32 on {cores} host threads: {rows} of the 32 benched rows as one batch, top-k/top-p sampling, {n_tokens} "
+        f"oracle fp32 on {cores} host threads (affinity mask {len(os.sched_getaffinity(0))}, cgroup quota applied): {rows} of the 32 benched rows as one batch, top-k/top-p sampling, {n_tokens} "
         f"acoustic tokens each (prefix + prefill + cached sampling loop + latent pass + BigVGAN), {dt:.1f}s of CPU work")
 
 
@@ -282,6 +297,7 @@ def stub_main(args, rank, world):
         emit_json({"metric": "stub", "value": round(audio_s_job * args.steps / elapsed, 2), "unit": "audio-seconds/sec",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
                           "scaling": "weak", "data": "stub", "ranks_seen": ranks_seen, "per_rank": per_rank,
+                          "tail_imbalance": round(max(p["seconds"] for p in per_rank) / (sum(p["seconds"] for p in per_rank) / len(per_rank)), 4),
                           "audio_seconds_per_step_job": audio_s_job, "config": {"workload": f"stub of config {args.config}"}})
     if world > 1:
         dist.barrier()

@@ -27,6 +27,10 @@
 #include "common.h"
 #include "ln_math.h"
 
+#ifndef ITTS_FOLD_ORDER
+#define ITTS_FOLD_ORDER 0   // build-time A/B of the LayerNorm-folded form: 0 = activations requested first, statistics MFMAs under the weight
+                            // stream; 1 = weights first, statistics MFMAs behind the main ones
+#endif
 #ifndef ITTS_NT_WEIGHTS
 #define ITTS_NT_WEIGHTS 0   // build-time A/B: non-temporal policy for the once-read weight blocks (measured neutral)
 #endif
@@ -60,6 +64,9 @@ struct SkinnyParams {
   int mtp, row0;           // row tiles of the WHOLE operand, first row of this launch (a multiple of 16)
 #if ITTS_STAMPS
   unsigned long long* stamps;
+#endif
+#if ITTS_DIAG
+  int exp;   // diagnostic ablations: bit 0 = every activation fragment is k-step 0's (L1-resident), bit 1 = every weight block is block 0
 #endif
 };
 
@@ -186,13 +193,19 @@ __global__ __launch_bounds__(MAXW * 64) void gemm_skinny_kernel(SkinnyParams p) 
   for (int mt = 0; mt < (FOLD ? MT : 1); ++mt) s1[mt] = s2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const frag ones = ones_frag<frag>();
 
-  auto x_frag = [&](const int s, const int mt) -> frag {
+  auto x_frag = [&](int s, const int mt) -> frag {
     const int row = (mt0 + mt) * 16 + r;
+#if ITTS_DIAG
+    if (p.exp & 1) s = s < s_end ? 0 : s;
+#endif
     if (p.x_pa)   // one contiguous 1-KiB block per (k-step, row tile); padding rows exist and are never stored
       return (s < s_end) ? ld16<frag>(X + (((int64_t)s * p.mtp + (p.row0 >> 4) + mt0 + mt) * 64 + lane) * E) : zero_frag<frag>();
     return (s < s_end && row < p.M) ? ld16<frag>(X + (int64_t)row * p.K + s * KS + g * E) : zero_frag<frag>();
   };
-  auto w_frag = [&](const int s, const int t) -> frag {
+  auto w_frag = [&](int s, const int t) -> frag {
+#if ITTS_DIAG
+    if (p.exp & 2) s = s < s_end ? 0 : s;
+#endif
     return (s < s_end && nt0 + t < NTtot) ? ldw<frag>(bp + ((int64_t)t * KT + s) * 1024) : zero_frag<frag>();
   };
 
@@ -204,7 +217,7 @@ __global__ __launch_bounds__(MAXW * 64) void gemm_skinny_kernel(SkinnyParams p) 
     frag bf[NTB][SPW];
     if constexpr (MT <= 2) {
       frag af[SPW][MT];
-      if constexpr (FOLD) {
+      if constexpr (FOLD && ITTS_FOLD_ORDER == 0) {
         // activations FIRST (vmcnt retires in issue order): the statistics MFMAs below need only them and run while the
         // weight blocks, the long pole from HBM, are still in flight
 #pragma unroll
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(MAXW * 64) void gemm_skinny_kernel(SkinnyParams p) 
       for (int t = 0; t < NTB; ++t)
 #pragma unroll
         for (int i = 0; i < SPW; ++i) bf[t][i] = w_frag(base + i, t);
-      if constexpr (!FOLD) {
+      if constexpr (!FOLD || ITTS_FOLD_ORDER != 0) {
 #pragma unroll
         for (int i = 0; i < SPW; ++i)
 #pragma unroll
@@ -227,7 +240,7 @@ __global__ __launch_bounds__(MAXW * 64) void gemm_skinny_kernel(SkinnyParams p) 
       ITTS_STAMP_DRAIN();
       ITTS_STAMP(2);
 #endif
-      if constexpr (FOLD) {
+      auto stats = [&]() {
 #pragma unroll
         for (int i = 0; i < SPW; ++i)
 #pragma unroll
@@ -235,7 +248,8 @@ __global__ __launch_bounds__(MAXW * 64) void gemm_skinny_kernel(SkinnyParams p) 
             s1[mt] = EL::mma(ones, af[i][mt], s1[mt]);
             s2[mt] = EL::mma(af[i][mt], af[i][mt], s2[mt]);
           }
-      }
+      };
+      if constexpr (FOLD && ITTS_FOLD_ORDER == 0) stats();
 #pragma unroll
       for (int i = 0; i < SPW; ++i) {
 #pragma unroll
@@ -243,6 +257,7 @@ __global__ __launch_bounds__(MAXW * 64) void gemm_skinny_kernel(SkinnyParams p) 
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) acc[t][mt] = EL::mma(bf[t][i], af[i][mt], acc[t][mt]);  // weights = A operand
       }
+      if constexpr (FOLD && ITTS_FOLD_ORDER != 0) stats();
     } else {
       // more than 32 rows: the activation fragments (L2-resident, shared by every workgroup) are fetched row tile by row
       // tile behind the weight blocks; the unrolled loop lets the loads of tile mt+1 fly under the MFMAs of tile mt
@@ -405,6 +420,7 @@ struct SkinnyPlan {
 
 #if ITTS_DIAG
 int g_tune_ntb = 0, g_tune_nw = 0;  // diagnostic build: itts_debug_set(1|2, v) overrides (0 = heuristic)
+int g_skinny_exp = 0;               // itts_debug_set(6, bits): load ablations of the skinny GEMM (SkinnyParams::exp)
 #endif
 
 // MTall = 16-row tiles of the launch; rows_per_wg (0 = all of them in every workgroup, else 16 / 32: the row tiles are dealt
@@ -568,6 +584,9 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
 #if ITTS_STAMPS
     p.stamps = g_stamp_buf;
 #endif
+#if ITTS_DIAG
+    p.exp = g_skinny_exp;
+#endif
     int rc;
     if (a->dtype == ITTS_F32) rc = launch_skinny<float>(p, a->rows_per_wg, a->wide_wg != 0, s);
     else if (a->dtype == ITTS_BF16) rc = launch_skinny<bf16_t>(p, a->rows_per_wg, a->wide_wg != 0, s);
@@ -597,6 +616,7 @@ extern "C" int itts_debug_set(int key, int value) {
   else if (key == 3) itts::g_conv_cfg = value;
   else if (key == 4) itts::g_attn_waves = (value == 8) ? 8 : 4;
   else if (key == 5) itts::g_conv_exp = value;
+  else if (key == 6) itts::g_skinny_exp = value;
   else return ITTS_ERR_INVALID;
   return ITTS_OK;
 }

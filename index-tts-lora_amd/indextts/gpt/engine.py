@@ -53,7 +53,7 @@ class GPTEngine:
             self.decode_mode = "launch"
         # launch geometry of the two GEMMs that run without split-K in "fold" mode (rows per workgroup, 16-wave workgroups)
         self.fold_rows = [int(v) for v in os.environ.get("ITTS_FOLD_ROWS", "16,16").split(",")]   # out-projection, FC2
-        self.fold_wide = os.environ.get("ITTS_FOLD_WIDE", "1") == "1"
+        self.fold_wide = os.environ.get("ITTS_FOLD_WIDE", "0") == "1"   # measured equal (836.7 / 840.6 us per token)
         # T-typed activations of the decode step (xn, attention output, MLP hidden) live in the packed fragment layout
         # (include/indextts_hip.h): the GEMMs read them as contiguous 1-KiB blocks.  ITTS_PACKED_ACT=0: row-major (same bits).
         self.pa = os.environ.get("ITTS_PACKED_ACT", "1") == "1"
@@ -577,13 +577,9 @@ class GPTEngine:
         nbytes += self.V * D * es + B * D * es + B * self.V * 4
         return n + 1, nbytes
 
-    def decode(self, max_new: int, sp: dict, force_stop=None, use_graph=True, check_every=16, return_logits=False,
-               logits_hook=None):
+    def decode(self, max_new: int, sp: dict, force_stop=None, use_graph=True, check_every=16, return_logits=False):
         """Run the sampling loop after prefill().  Returns codes int64 [B, n] padded with the stop token
-        (HF generate semantics: rows that emitted EOS keep emitting pad = EOS).
-        logits_hook(logits fp32 [B, V] (modified in place), history int32 [B, k] of the tokens generated so far): an extra
-        logits processor run on the device in front of the sampling kernel at every step (typical sampling); the loop then
-        launches eagerly, one host call per step."""
+        (HF generate semantics: rows that emitted EOS keep emitting pad = EOS)."""
         B = self._B
         if self._shared_prefix is not None:
             raise ValueError("decode(): prefill(beams=n) cached the prompt once per batch element; only decode_beam() can follow it")
@@ -595,21 +591,11 @@ class GPTEngine:
             self.force_stop[:B] = torch.as_tensor(force_stop, dtype=torch.int32).to(self.device)
         logits_trace = [self.logits[:B].clone()] if return_logits else None
         sp = self._seed_to_state(sp)
-        if logits_hook is not None:
-            use_graph = False
-            logits_hook(self.logits[:B], self.history[:B, :0])
         self._sample(B, sp)  # token 1 from the prefill logits
         n = 1
         G = 1 if return_logits else self.steps_per_graph
         while n < max_new:
-            if logits_hook is not None:
-                k = 1
-                self._step_transformer(B)
-                if return_logits:
-                    logits_trace.append(self.logits[:B].clone())      # the trace holds what the model produced, not the hook's edit
-                logits_hook(self.logits[:B], self.history[:B, :n])
-                self._sample(B, sp)
-            elif use_graph and not self.force_eager and n >= 2:
+            if use_graph and not self.force_eager and n >= 2:
                 k = G if n + G <= max_new else 1          # several tokens per replay while they fit
                 self._get_graph(B, sp, k).replay()
             else:
@@ -617,7 +603,7 @@ class GPTEngine:
                 self._step_kernels(B, sp)                 # eager: first step doubles as the warm-up before capture
             prev = n
             n += k
-            if return_logits and logits_hook is None:
+            if return_logits:
                 logits_trace.append(self.logits[:B].clone())
             if n // check_every != prev // check_every and self._poll() >= B:
                 break
@@ -880,6 +866,7 @@ class GPTEngine:
         if self._S + max_new + 1 > self._cap_s:
             raise ValueError("decode_beam(): max_new exceeds the capacity reserved by prefill()")
         self._ensure_beam(B, nb)
+        self.kv_share.zero_()       # beam reorders (copy mode) move cache rows: the promise behind the shared reads does not hold
         self.b_scores.zero_()
         self.b_scores.view(B, nb)[:, 1:] = -1e9
         self.b_hist.zero_()
@@ -905,7 +892,8 @@ class GPTEngine:
         sp = self._seed_to_state(sp)
         self._beam_select(B, nb, sp)  # token 1 from the prefill logits
         n = 1
-        key = ("beam", B, nb, self.beam_kv, tuple(sorted(sp.items())))
+        key = ("beam", B, nb, self.beam_kv, self.decode_mode, self.lora, tuple(self.fold_rows), self.fold_wide, self.pa, self.KSPLIT,
+               tuple(sorted(sp.items())))
         while n < max_new:
             if use_graph and not self.force_eager and n >= 2:
                 g = self._graphs.get(key)
@@ -966,7 +954,10 @@ class GPTEngine:
         return out
 
     def _get_graph(self, B, sp, nsteps=1):
-        key = (B, nsteps, tuple(sorted(sp.items())))
+        # everything the captured launches depend on besides the buffers: a knob toggled after a capture must not replay the
+        # old variant (skip_finished: whether the attention is given the finished flags)
+        key = (B, nsteps, self.skip_finished, self.decode_mode, self.lora, tuple(self.fold_rows), self.fold_wide, self.pa, self.KSPLIT,
+               self.share_kv_reads, tuple(sorted(sp.items())))
         g = self._graphs.get(key)
         if g is None:
             g = torch.cuda.CUDAGraph()

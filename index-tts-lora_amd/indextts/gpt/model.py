@@ -169,10 +169,8 @@ class UnifiedVoice:
             raise NotImplementedError("input_tokens (continuing a given code prefix) is off the infer.py path")
         num_beams = int(hf.pop("num_beams", 1))
         if typical_sampling:
-            if not 0.0 < typical_mass < 1.0:
-                raise ValueError(f"`typical_mass` has to be in (0, 1), got {typical_mass}")   # model.py:705-706
-            if num_beams > 1:
-                raise NotImplementedError("typical_sampling is implemented for num_beams = 1")
+            # model.py:704-708; never enabled by infer.py / cli.py / api.py (out of scope)
+            raise NotImplementedError("typical_sampling is off the infer.py path and not built (oracle/sampling_ref.typical restates it)")
         nrs = int(num_return_sequences)
         if nrs < 1 or (num_beams > 1 and nrs > num_beams):
             raise ValueError("num_return_sequences has to be in [1, num_beams]")
@@ -211,31 +209,8 @@ class UnifiedVoice:
             emb, pad = emb.repeat_interleave(nrs, dim=0), pad.repeat_interleave(nrs)
             if force_stop is not None:
                 force_stop = [v for v in force_stop for _ in range(nrs)]
-        hook = None
-        if typical_sampling:
-            # model.py:704-708: TypicalLogitsWarper goes into `logits_processor`, i.e. behind the repetition penalty and in front
-            # of temperature / top-k / top-p.  Run here on the device in plain torch (repetition penalty first, then the warper),
-            # the sampling kernel then gets penalty 1.0 and the remaining warpers.  Removed tokens get -1e30 (probability 0).
-            rp, mass = float(sp["repetition_penalty"]), float(typical_mass)
-            sp = dict(sp, repetition_penalty=1.0)
-            extra = self.engine.extra_ids.long()
-
-            def hook(logits, hist):
-                ids = torch.cat([extra.expand(logits.shape[0], -1), hist.long()], 1)
-                if rp != 1.0:
-                    sc = logits.gather(1, ids)
-                    logits.scatter_(1, ids, torch.where(sc < 0, sc * rp, sc / rp))
-                lp = logits.log_softmax(-1)
-                ent = -(lp * lp.exp()).nansum(-1, keepdim=True)
-                shifted = (-lp - ent).abs()
-                srt, idx = shifted.sort(-1)
-                cum = logits.gather(1, idx).softmax(-1).cumsum(-1)
-                last = (cum < mass).sum(1).clamp(max=logits.shape[1] - 1)
-                remove_sorted = srt > srt.gather(1, last[:, None])
-                remove_sorted[:, :1] = False                                   # min_tokens_to_keep = 1 (no beams)
-                logits.masked_fill_(torch.zeros_like(remove_sorted).scatter(1, idx, remove_sorted), -1e30)
         self.engine.prefill(emb, pad, max_new, shared_rows=shared)
-        out = self.engine.decode(max_new, sp, force_stop=force_stop, return_logits=return_logits, logits_hook=hook)
+        out = self.engine.decode(max_new, sp, force_stop=force_stop, return_logits=return_logits)
         return out
 
     def attach_lora(self, adapters: dict | None, scaling: float = 1.0):

@@ -819,14 +819,11 @@ class BatchPipeline:
     to infer_batch(): the two stages share only read-only weights (the latent pass and the vocoder allocate their
     activations per call from the stream-aware allocator, the decode loop owns the KV cache and its state)."""
 
-    def __init__(self, tts: "IndexTTS", cu_mask_b=None):
-        """cu_mask_b: optional uint32 words (bit i = CU i) restricting stage B's stream to a subset of the compute units
-        (hipExtStreamCreateWithCUMask), so that its thousand-workgroup launches leave CUs to the token loop."""
+    def __init__(self, tts: "IndexTTS"):
         self.tts = tts
         lo, hi = 0, -1
         self.stream_a = torch.cuda.Stream(device=tts.device, priority=hi)   # latency-critical token loop
-        self.stream_b = (torch.cuda.Stream(device=tts.device, priority=lo) if cu_mask_b is None   # throughput work
-                         else stream_with_cu_mask(tts.device, cu_mask_b))
+        self.stream_b = torch.cuda.Stream(device=tts.device, priority=lo)   # throughput work
         self._jobs: "queue.Queue" = queue.Queue()
         self._inflight: List[BatchTicket] = []
         self._thread = threading.Thread(target=self._worker, name="itts-stage-b", daemon=True)
@@ -876,29 +873,6 @@ class BatchPipeline:
         self._thread.join()
 
 
-def stream_with_cu_mask(device, words):
-    """A HIP stream restricted to the compute units whose bits are set in `words` (uint32 list, bit i of word w = CU 32*w + i),
-    wrapped for torch.  Created through the HIP runtime this process has already loaded (the one torch and the kernel library
-    launch through)."""
-    import ctypes
-    path = None
-    with open("/proc/self/maps") as f:
-        for line in f:
-            if "libamdhip64.so" in line:
-                path = line.split()[-1]
-                break
-    if path is None:
-        raise RuntimeError("stream_with_cu_mask: the HIP runtime is not loaded in this process")
-    hip = ctypes.CDLL(path)
-    handle = ctypes.c_void_p()
-    arr = (ctypes.c_uint32 * len(words))(*[int(w) & 0xFFFFFFFF for w in words])
-    torch.cuda.set_device(device)
-    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(len(words)), arr)
-    if rc != 0 or not handle.value:
-        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed (error {rc})")
-    return torch.cuda.ExternalStream(handle.value, device=device)
-
-
 class RequestPool:
     """Serving concurrency (not in the reference API): several independent utterance batches in flight on one GPU, each on
     its own IndexTTS instance, host thread and HIP stream.  A single request's token loop is a chain of ~170 dependent
@@ -918,17 +892,23 @@ class RequestPool:
             return self.out
 
     @classmethod
-    def of(cls, tts: "IndexTTS", inflight: int = 2, cu_masks=None) -> "RequestPool":
-        return cls([tts] + [tts.replica() for _ in range(max(1, inflight) - 1)], cu_masks=cu_masks)
+    def of(cls, tts: "IndexTTS", inflight: int = 2) -> "RequestPool":
+        return cls([tts] + [tts.replica() for _ in range(max(1, inflight) - 1)])
 
-    def __init__(self, instances: List["IndexTTS"], cu_masks=None):
-        """cu_masks: optional, one entry per instance: None (an ordinary stream) or a list of uint32 words, bit i = compute
-        unit i may run this instance's work (hipExtStreamCreateWithCUMask).  Measured on MI355X (tools/pool_cu_masks.py,
-        profiles/): partitioning the CUs between two requests is SLOWER than letting the dispatcher interleave them."""
+    def __init__(self, instances: List["IndexTTS"]):
+        """Every instance gets an ordinary HIP stream of its own (streams restricted to disjoint CU subsets were measured in
+        round 3 and never beat letting the dispatcher interleave the requests: profiles/r03_pool_cu_masks.txt).  The HIP runtime
+        multiplexes a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4, read when the runtime initialises):
+        with more requests in flight than queues two of them share one and run back to back -- export GPU_MAX_HW_QUEUES >=
+        len(instances) before the process first touches the GPU (bench.py does for its 4-deep leg: 1 740 instead of 1 400
+        audio-s/s)."""
         assert instances, "need at least one instance"
-        assert cu_masks is None or len(cu_masks) == len(instances), "one CU mask (or None) per instance"
         self.instances = list(instances)
-        self._cu_masks = list(cu_masks) if cu_masks is not None else [None] * len(instances)
+        hwq = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)
+        if len(self.instances) > hwq:
+            warnings.warn(f"RequestPool: {len(self.instances)} requests in flight over GPU_MAX_HW_QUEUES={hwq} hardware queues: "
+                          f"some request streams will share a queue (export GPU_MAX_HW_QUEUES={len(self.instances)} before the "
+                          f"process initialises the GPU)", RuntimeWarning)
         self._queues = [queue.Queue() for _ in self.instances]
         self._threads = [threading.Thread(target=self._run, args=(i,), name=f"itts-request-{i}", daemon=True)
                          for i in range(len(self.instances))]
@@ -939,10 +919,7 @@ class RequestPool:
     def _run(self, i):
         inst, q = self.instances[i], self._queues[i]
         torch.cuda.set_device(inst.device)
-        if self._cu_masks[i] is None:
-            stream = torch.cuda.Stream(device=inst.device)
-        else:
-            stream = stream_with_cu_mask(inst.device, self._cu_masks[i])
+        stream = torch.cuda.Stream(device=inst.device)
         while True:
             item = q.get()
             if item is None:

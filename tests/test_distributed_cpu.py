@@ -145,6 +145,30 @@ def test_bench_self_launch_two_ranks_stub():
     assert a[0] != a[1] and all(32 * 40 * 1024 / 24000 <= x <= 32 * 400 * 1024 / 24000 for x in a)
 
 
+def test_bench_eight_ranks_config4_stub():
+    """BASELINE config 4's real shape, rehearsed on CPU so that the first 8-GPU run is not also the first 8-rank run:
+    `bench.py --gpus 8 --config 4` (self-launch, gloo, stub engine) -- 256 mixed-length utterances from ONE global list, eight
+    disjoint shards of 32 (the serpentine longest-first deal of indextts/utils/dist.py), every rank reports, the shards carry
+    different amounts of audio, the aggregate is their sum and the tail imbalance is in the line."""
+    rc, js, err = _run_bench(["--gpus", "8", "--stub", "--steps", "1", "--warmup", "0", "--config", "4"])
+    assert rc == 0, err[-2000:]
+    assert js["n_gpus"] == 8 and js["scaling"] == "weak"
+    assert sorted(r["rank"] for r in js["ranks_seen"]) == list(range(8))
+    assert len({r["uuid"] for r in js["ranks_seen"]}) == 8
+    rows = [set(p["rows"]) for p in sorted(js["per_rank"], key=lambda p: p["rank"])]
+    assert all(len(r) == 32 for r in rows)
+    assert set().union(*rows) == set(range(256)) and sum(len(r) for r in rows) == 256, "eight disjoint shards of one list"
+    audio = [p["audio_s_per_step"] for p in js["per_rank"]]
+    assert len(set(audio)) > 1 and all(32 * 40 * 1024 / 24000 <= a <= 32 * 400 * 1024 / 24000 for a in audio)
+    assert abs(js["audio_seconds_per_step_job"] - sum(audio)) < 1e-6
+    assert js["tail_imbalance"] >= 1.0
+    # the deal balances what is known up front (text length): no shard holds more than a few per cent more text than another
+    import bench
+    texts, _ = bench.make_workload(4, 8)
+    load = [sum(int(texts[i].numel()) for i in r) for r in rows]
+    assert max(load) / min(load) < 1.05, load
+
+
 def test_bench_under_torchrun_two_ranks_stub():
     rc, js, err = _run_bench(["--gpus", "2", "--stub", "--steps", "1", "--warmup", "0"], launcher=True)
     assert rc == 0, err[-2000:]

@@ -189,36 +189,13 @@ def test_latent_pass_reuses_the_cached_prompt(dtype):
     assert all(torch.equal(a, b) for a, b in zip(full, off))
 
 
-def test_typical_sampling_follows_the_oracle_warper(gpt_small_fp32):
-    """inference_speech(typical_sampling=True) (model.py:704-708): at every step the sampled token lies in the set that
-    repetition penalty -> TypicalLogitsWarper -> top-k -> top-p keeps (oracle/sampling_ref.py, the warper pinned against
-    transformers), recomputed from the logits the device produced; the set differs from the plain top-k / top-p set on at
-    least some steps (the warper does something), and the run is reproducible."""
-    from oracle import sampling_ref
-    m = gpt_small_fp32
+def test_typical_sampling_is_refused(gpt_small_fp32):
+    """model.py:704-708's optional warper is never enabled by infer.py / cli.py / api.py (out of
+    scope) and is not built: asking for it fails loudly instead of sampling from another distribution."""
     g = np.load(os.path.join(G, "gpt_small.npz"))
     cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
-    text = torch.from_numpy(g["text"]).to(DEV)
-    kw = dict(do_sample=True, top_p=0.95, top_k=50, temperature=1.0, num_beams=1, repetition_penalty=10.0,
-              max_generate_length=12, seed=11, typical_sampling=True, typical_mass=0.6)
-    codes, logits = m.inference_speech(cond_mel, text, return_logits=True, **kw)
-    codes2 = m.inference_speech(cond_mel, text, **kw)
-    assert torch.equal(codes, codes2)
-    codes, lg = codes.cpu().numpy(), logits.float().cpu().numpy()
-    narrower = 0
-    for s in range(codes.shape[1]):
-        hist = np.concatenate([np.array([[1, 8192]] * codes.shape[0]), codes[:, :s]], axis=1)
-        pen = sampling_ref.repetition_penalty(lg[s], hist, 10.0)
-        kept = sampling_ref.top_p(sampling_ref.top_k(sampling_ref.typical(pen, 0.6, 1), 50), 0.95)
-        plain = sampling_ref.top_p(sampling_ref.top_k(pen, 50), 0.95)
-        for b in range(codes.shape[0]):
-            assert np.isfinite(kept[b, codes[b, s]]), (s, b, int(codes[b, s]))
-        narrower += int((np.isfinite(kept) != np.isfinite(plain)).any())
-    assert narrower > 0
-    with pytest.raises(ValueError):
-        m.inference_speech(cond_mel, text, typical_sampling=True, typical_mass=1.5, max_generate_length=2)
     with pytest.raises(NotImplementedError):
-        m.inference_speech(cond_mel, text, typical_sampling=True, num_beams=3, max_generate_length=2)
+        gpt_small_fp32.inference_speech(cond_mel, torch.from_numpy(g["text"]).to(DEV), typical_sampling=True, max_generate_length=2)
 
 
 def test_gpt_bf16_tracks_fp32():
@@ -476,18 +453,6 @@ def test_request_pool_matches_serial_infer_batch():
         for a, b in zip(want, got):
             assert a.shape == b.shape and torch.equal(a, b)
     pool.close()
-    # the same on streams restricted to disjoint halves of the compute units (hipExtStreamCreateWithCUMask)
-    ncu = torch.cuda.get_device_properties(0).multi_processor_count
-    nw = (ncu + 31) // 32
-    even, odd = [0x55555555] * nw, [0xAAAAAAAA] * nw
-    pool = RequestPool(insts, cu_masks=[even, odd])
-    jobs = [pool.submit(cond_mel, b, seed=300 + i, **kw, **gen) for i, b in enumerate(batches)]
-    for want, job in zip(serial, jobs):
-        for a, b in zip(want, job.result()):
-            assert torch.equal(a, b)
-    pool.close()
-    with pytest.raises(AssertionError):
-        RequestPool(insts, cu_masks=[even])
 
 
 @pytest.mark.parametrize("lens", [[17, 3, 9, 12, 1], [3, 12, 17, 1, 9]])   # element 0 the longest (pad 0) / not (pad 14)

@@ -5,8 +5,7 @@ Needs libindextts_hip_diag.so (make -C index-tts-lora_amd/csrc diag).  A full-si
 then ONE decode step is captured into a graph with a distinct stamp area per skinny-GEMM launch and replayed; the stamps of
 the last replay are read back.  Per launch, every workgroup recorded (include/indextts_hip_diag.h):
   s_memtime at  0 entry | 1 all loads issued | 2 operands landed (vmcnt(0), diagnostic wait) | 3 MFMAs done |
-                4 cross-wave barrier passed | 5 epilogue stores issued | 6 stores drained + barrier | 7 ticket drawn |
-                8 all tickets seen | 9 row reduced | 10 exit;  s_memrealtime (100 MHz) at entry / exit;  XCC id.
+                4 cross-wave barrier passed | 5 epilogue stores issued | 10 exit;  s_memrealtime (100 MHz) at entry / exit;  XCC id.
 Printed per GEMM kind (median over the step's launches of that kind, us): dispatch skew (first to last workgroup entry),
 segment medians over workgroups, kernel span (first entry to last exit), and the gap to the NEXT kernel's first entry.
 Read the SHARES, not the lengths: the diagnostic waits forbid overlaps the product kernel has.
@@ -73,8 +72,9 @@ def main():
         i = len(kinds)
         L.itts_debug_stamps(ctypes.c_void_p(stamps[i].data_ptr()))
         kinds.append({(3840, 1280): "qkv", (1280, 1280): "out_proj", (5120, 1280): "fc", (1280, 5120): "fc2"}.get((N, K), "head"))
-        pl = nat.skinny_plan(dtype, M, N, K, k.get("ksplit", 1))
-        geo.append(pl["grid"][0] * pl["grid"][1])
+        pl = nat.skinny_plan(dtype, M, N, K, k.get("ksplit", 1), k.get("rows_per_wg", 0), k.get("wide_wg", False),
+                             k.get("ln_c") is not None)
+        geo.append(pl["grid"][0] * pl["grid"][1] * pl["grid"][2])
         return orig(dtype, M, N, K, *a, **k)
 
     sps = eng._seed_to_state(sp)
