@@ -48,7 +48,7 @@ extern "C" {
 #define ITTS_BF16 1
 #define ITTS_F16 2
 
-#define ITTS_ABI_VERSION 7 /* 7: LayerNorm folded into the consuming skinny GEMM (ln_c), residual epilogue with a packed T copy, rows_per_wg / wide_wg, bump words in itts_gemm_skinny / itts_embed_step (+ clamp, packed copy); the reducer tail is gone; 6: per-row clocks (row_step0) in itts_embed_step / itts_sample_args (slot refill), itts_attn_prefill_prefix / _shared, kv_share in itts_attn_decode; 5: itts_ln_reduce takes up to 6 slabs */
+#define ITTS_ABI_VERSION 7 /* 7: LayerNorm folded into the consuming skinny GEMM (ln_c), residual epilogue with a packed T copy, rows_per_wg / wide_wg, bump words in itts_gemm_skinny / itts_embed_step (+ clamp, packed copy); the reducer tail is gone; paged KV cache (kv_tab / kv_bs); 6: per-row clocks (row_step0) in itts_embed_step / itts_sample_args (slot refill), itts_attn_prefill_prefix / _shared, kv_share in itts_attn_decode; 5: itts_ln_reduce takes up to 6 slabs */
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -89,6 +89,20 @@ int itts_aa_snake_fwd(const void* x, void* y, const float* alpha_log, const floa
  * The GEMM then reads a fragment as one contiguous 1-KiB wave-load instead of 16 rows x 64 bytes.  Producers that can
  * write it: itts_ln_reduce (y_packed), itts_attn_decode (out_packed), itts_gemm_skinny (y_packed), itts_embed_step (h_packed).
  * ------------------------------------------------------------------------------------------------------------------ */
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Paged KV cache (optional, per call: kv_tab != NULL).  The contiguous cache of one layer is T [rows][H][smax][64].  The paged
+ * form is a pool T [blocks][H][kv_bs][64], kv_bs in {16, 32, 64} positions per block, plus a block table int32
+ * [rows][ITTS_KV_TAB] on the device: position j of cache row r lives in block kv_tab[r][(j / kv_bs) % ITTS_KV_TAB], offset
+ * j % kv_bs.  The table is a RING over the position index: the decode loop's shared write position only grows, a row's live
+ * window [pad_r, pos] must stay under (ITTS_KV_TAB - 2) * kv_bs positions, and the caller (GPTEngine) deals blocks to rows as
+ * the loop advances and takes them back when a row has stopped -- a refilled decode slot reclaims the blocks of the row that
+ * left.  Every table entry must always name a block of the pool (rows past their window point at a scratch block): the
+ * kernels read clamped / masked positions without branching.  `smax` is ignored in the paged form.
+ * Entry points that take (kv_tab, kv_bs): itts_gemm_skinny (QKV epilogue: append), itts_attn_decode, itts_attn_prefill_packed /
+ * _prefix / _shared (prompt rows in, cached prefix out).  Beam search keeps the contiguous form (its per-position row table).
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define ITTS_KV_TAB 64
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Skinny GEMM for the decode step: Y[M][N] = epi( X[M][K] @ W[K][N] + bias ), up to 96 rows (bf16/f16; 16 in fp32) per
@@ -133,6 +147,9 @@ typedef struct itts_skinny_args {
    * <= 96-row chunk; 16 / 32 = the row tiles are dealt to grid.z (more, lighter workgroups for GEMMs that run without
    * split-K).  wide_wg != 0: 16-wave workgroups where that keeps a long K to one pass (16 rows per workgroup only). */
   int rows_per_wg, wide_wg;
+  /* ITTS_EPI_QKV_CACHE into a paged cache (see "Paged KV cache"): block table and block size, or NULL / 0 */
+  const int32_t* kv_tab;
+  int kv_bs;
   /* Packed-activation layout (see "Packed activation layout" above): x_packed -- x is packed [K/KS][ceil(M/16)][64][E];
    * y_packed -- y (ITTS_EPI_STORE / ITTS_EPI_GELU_STORE / ITTS_EPI_RESID_F32, N % KS == 0) is written packed. */
   int x_packed, y_packed;
@@ -237,7 +254,8 @@ int itts_embed_step(const int32_t* tokens, const float* table, const float* pos_
  * of B copies from HBM).  0 = no sharing.  Ignored with kv_rows. */
 int itts_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, const int32_t* pad,
                      const int32_t* pos, int B, int H, int smax, int dtype, int out_packed, const int32_t* kv_rows,
-                     const int32_t* kv_step, const int32_t* skip_rows, const int32_t* kv_share, void* stream);
+                     const int32_t* kv_step, const int32_t* skip_rows, const int32_t* kv_share, const int32_t* kv_tab, int kv_bs,
+                     void* stream);
 
 /* Causal self-attention over a whole (left-padded) sequence.  qkv: T [B][S][3*H*64] (q|k|v); out: T [B][S][H*64];
  * query i sees key j iff pad[b] <= j <= i; rows with no visible key produce zeros.  If kcache/vcache are non-NULL the
@@ -250,7 +268,8 @@ int itts_attn_prefill(const void* qkv, void* out, void* kcache, void* vcache, co
  * local row i of element b is written to cache row cache_shift[b] + i (cache_shift NULL = 0): with cache_shift = the
  * element's left padding this reproduces the cache layout of the padded form. */
 int itts_attn_prefill_packed(const void* qkv, void* out, void* kcache, void* vcache, const int32_t* row_off,
-                             const int32_t* cache_shift, int B, int Smax, int H, int smax, int dtype, void* stream);
+                             const int32_t* cache_shift, int B, int Smax, int H, int smax, int dtype, const int32_t* kv_tab,
+                             int kv_bs, void* stream);
 
 /* Packed rows behind a CACHED PREFIX (the teacher-forced latent pass, model.py:459-474 / 548-597, for a batch whose prompt the
  * decode loop has cached): element b's sequence is  pre_len[b] keys / values read from cache row pre_row[b], positions
@@ -260,7 +279,7 @@ int itts_attn_prefill_packed(const void* qkv, void* out, void* kcache, void* vca
  * itts_attn_prefill_packed produces when the prefix's k / v rows are part of qkv. */
 int itts_attn_prefill_prefix(const void* qkv, void* out, const void* kcache, const void* vcache, const int32_t* row_off,
                              const int32_t* pre_len, const int32_t* pre_row, const int32_t* pre_pos0, int B, int Smax, int H,
-                             int smax, int dtype, void* stream);
+                             int smax, int dtype, const int32_t* kv_tab, int kv_bs, void* stream);
 
 /* Packed rows behind a prefix that is SHARED and computed in the same pass (the prefill of a batch whose elements all start
  * with the same conditioning latents, model.py:606-667 with one prompt: those rows see only themselves, so their hidden states
@@ -272,7 +291,7 @@ int itts_attn_prefill_prefix(const void* qkv, void* out, const void* kcache, con
  * block's cache rows to the other elements' cache rows). */
 int itts_attn_prefill_shared(const void* qkv, void* out, void* kcache, void* vcache, const int32_t* row_off,
                              const int32_t* pre_len, const int32_t* pre_row0, const int32_t* w_row, const int32_t* w_pos0,
-                             int E, int Smax, int H, int smax, int dtype, void* stream);
+                             int E, int Smax, int H, int smax, int dtype, const int32_t* kv_tab, int kv_bs, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Token selection for one decode step, on device (no host sync in the loop).

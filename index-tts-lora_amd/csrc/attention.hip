@@ -30,14 +30,18 @@ __device__ __forceinline__ void softmax_merge(float& m, float& l, float m2, floa
 
 // IND: beam search -- key/value position j of logical row b lives in physical cache row kv_rows[parity][b][j] (a table
 // that itts_beam_step permutes instead of copying cache rows); parity = *kv_step & 1.
-template <typename T, int NWV, bool IND>
+// PAGED: the cache is a block pool behind a per-row block table (include/indextts_hip.h, "Paged KV cache"): lane t of every
+// wave keeps table entry t of the row (64 entries, requested with the query), and a key's block id comes out of that
+// register with one cross-lane read per K / V request -- no dependent memory access in front of the K / V stream.
+template <typename T, int NWV, bool IND, bool PAGED>
 __global__ __launch_bounds__(NWV * 64) void attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ kc,
                                                            const T* __restrict__ vc, T* __restrict__ out,
                                                            const int32_t* __restrict__ pad, const int32_t* __restrict__ pos,
                                                            int H, int smax, int out_mtp, const int32_t* __restrict__ kv_rows,
                                                            const int32_t* __restrict__ kv_step, int rows_total,
                                                            const int32_t* __restrict__ skip_rows,
-                                                           const int32_t* __restrict__ kv_share) {
+                                                           const int32_t* __restrict__ kv_share,
+                                                           const int32_t* __restrict__ kv_tab, int bs_log2) {
   typedef Elem<T> EL;
   typedef typename EL::frag frag;
   constexpr int E = EL::E;
@@ -55,6 +59,12 @@ __global__ __launch_bounds__(NWV * 64) void attn_decode_kernel(const T* __restri
   // soon as the scalars are back; the query is converted only after those have been issued.  (The first version read the
   // stop flag, branched, read pad / pos, waited for q and only then requested K / V: in-kernel latency chain of ~4 trips.)
   const frag qv = ld16<frag>(q + ((int64_t)b * H + h) * HD + part * E);
+  int tabv = 0, tab0v = 0;             // PAGED: this row's block table (entry = lane), and row 0's for the shared first keys
+  if constexpr (PAGED) {
+    tabv = kv_tab[b * ITTS_KV_TAB + lane];
+    tab0v = kv_tab[lane];
+  }
+  const int bsm = (1 << bs_log2) - 1;
   const int32_t* skip_ptr = skip_rows != nullptr ? skip_rows + b : pos;   // a readable word either way: no branch around the load
   const int skip_raw = *skip_ptr;
   const int j0 = pad[b];
@@ -73,8 +83,8 @@ __global__ __launch_bounds__(NWV * 64) void attn_decode_kernel(const T* __restri
   int pos0 = pos[0];
   asm volatile("" : "+s"(pos0));              // (keeps the load here: the compiler would otherwise load it only for rows that need it)
   const int ctx = skipped ? j0 : pos0 + 1;    // keys [j0, ctx)
-  const T* kb = kc + ((int64_t)b * H + h) * smax * HD + part * E;
-  const T* vb = vc + ((int64_t)b * H + h) * smax * HD + part * E;
+  const T* kb = kc + (PAGED ? 0 : ((int64_t)b * H + h) * smax * HD) + part * E;
+  const T* vb = vc + (PAGED ? 0 : ((int64_t)b * H + h) * smax * HD) + part * E;
   const int64_t sh_off = ((int64_t)h * smax + (share_w >> 8)) * HD + part * E;   // row 0, head h, position p0
   const int32_t* tab = nullptr;
   if constexpr (IND) tab = kv_rows + ((int64_t)(kv_step[0] & 1) * rows_total + b) * smax;
@@ -87,6 +97,11 @@ __global__ __launch_bounds__(NWV * 64) void attn_decode_kernel(const T* __restri
   // one pass over 4 * RPW * AD_CH keys; the FIRST pass (typical contexts need no other) converts the query behind its K / V
   // requests -- written as a separate instance so that the compiler cannot hoist that conversion, and with it the wait for
   // the query, in front of the requests
+  // Key groups are cut from a position that is a multiple of RPW (the left padding rounded down; the rows in front of pad_b
+  // are masked): a wave-load's RPW consecutive keys then never straddle a cache block (block sizes are multiples of RPW), so
+  // in the paged form the block id of a request is WAVE-UNIFORM -- one v_readlane out of the table register per request, no
+  // per-lane lookup in front of the K / V stream.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   auto key_pass = [&](const int base, auto first_tag) {
     constexpr bool FIRST = decltype(first_tag)::value;
     frag kf[CH], vf[CH];
@@ -102,14 +117,26 @@ __global__ __launch_bounds__(NWV * 64) void attn_decode_kernel(const T* __restri
     }
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-      int j = min(base + (i * NWV + wave) * RPW + rg, ctx - 1);
+      // first key of this wave-load (wave-uniform); groups past the context fall onto the group of its last key, and the rows
+      // past it onto that key (same cache lines, one block)
+      const int jf = min(base + (i * NWV + wave_u) * RPW, (ctx - 1) & ~(RPW - 1));
+      int j = min(jf + rg, ctx - 1);
       int64_t ro = (int64_t)j * HD;
       if constexpr (IND) ro += (int64_t)(prow[i] - b) * H * smax * HD;   // same head, same position, another row
+      if constexpr (PAGED) {
+        const int blk = __builtin_amdgcn_readlane(tabv, (jf >> bs_log2) & (ITTS_KV_TAB - 1));
+        ro = ((((int64_t)blk * H + h) << bs_log2) + (j & bsm)) * HD;
+      }
       const T* kp = kb + ro;
       const T* vp = vb + ro;
       if constexpr (!IND) {
         const bool sh = (unsigned)(j - j0) < (unsigned)shC;   // a select, not a branch (also false for j < j0: skipped rows)
-        const int64_t so = sh_off + (int64_t)(j - j0) * HD;
+        int64_t so = sh_off + (int64_t)(j - j0) * HD;
+        if constexpr (PAGED) {
+          const int ps = (share_w >> 8) + (j - j0);            // the same key in row 0's window (its block: a per-lane lookup)
+          const int blk0 = __shfl(tab0v, (ps >> bs_log2) & (ITTS_KV_TAB - 1), 64);
+          so = ((((int64_t)blk0 * H + h) << bs_log2) + (ps & bsm)) * HD + part * E;
+        }
         kp = sh ? kc + so : kp;
         vp = sh ? vc + so : vp;
       }
@@ -132,7 +159,7 @@ __global__ __launch_bounds__(NWV * 64) void attn_decode_kernel(const T* __restri
 #pragma unroll
       for (int off = 1; off < LPR; off <<= 1) d += __shfl_xor(d, off, 64);
       int j = base + (i * NWV + wave) * RPW + rg;
-      sc[i] = (j < ctx) ? d : -INFINITY;
+      sc[i] = (j >= j0 && j < ctx) ? d : -INFINITY;
       cmax = fmaxf(cmax, sc[i]);
     }
     {
@@ -156,8 +183,9 @@ __global__ __launch_bounds__(NWV * 64) void attn_decode_kernel(const T* __restri
   };
   constexpr int PASS = 4 * RPW * AD_CH;
   if (j0 < ctx) {
-    key_pass(j0, std::true_type{});
-    for (int base = j0 + PASS; base < ctx; base += PASS) key_pass(base, std::false_type{});
+    const int b0 = j0 & ~(RPW - 1);
+    key_pass(b0, std::true_type{});
+    for (int base = b0 + PASS; base < ctx; base += PASS) key_pass(base, std::false_type{});
   }
   // merge across the row groups of the wave (lanes that share `part`)
 #pragma unroll
@@ -216,7 +244,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const T* __restrict__
                                                             const int32_t* __restrict__ pre_row,
                                                             const int32_t* __restrict__ pre_pos0, int pre_qkv,
                                                             T* wkc, T* wvc, const int32_t* __restrict__ w_row,
-                                                            const int32_t* __restrict__ w_pos0) {
+                                                            const int32_t* __restrict__ w_pos0,
+                                                            const int32_t* __restrict__ kv_tab, int bs_log2) {
   typedef Elem<T> EL;
   typedef typename EL::frag frag;
   constexpr int E = EL::E, KS = EL::KS, NKS = HD / KS;
@@ -248,17 +277,20 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const T* __restrict__
   const int64_t pbase = pkc == nullptr ? 0
                         : pre_qkv      ? (int64_t)pre_pos0[b] * 3 * D + h * HD
                                        : (((int64_t)pre_row[b] * H + h) * smax + pre_pos0[b]) * HD;
+  // (paged cache: a cached prefix key is addressed through the block table, see kv_elem_off)
+  const int p_row = (pkc != nullptr && !pre_qkv) ? pre_row[b] : 0, p_pos0 = (pkc != nullptr && !pre_qkv) ? pre_pos0[b] : 0;
   const int Stot = pl + S;
   // cache append of the prefix form: this workgroup's own 64 rows go to cache row w_row[b], positions w_pos0[b] + local row
   if (wkc != nullptr) {
-    const int64_t wbase = (((int64_t)w_row[b] * H + h) * smax + w_pos0[b]) * HD;
+    const int wr = w_row[b], wp0 = w_pos0[b];
     for (int ch = tid; ch < 64 * CPR; ch += 256) {
       const int kk = ch / CPR, dc = ch - kk * CPR;
       const int q = q0 + kk;
       if (q < S) {
         const T* src = base + (int64_t)q * 3 * D + D + h * HD + dc * E;
-        st16(wkc + wbase + (int64_t)q * HD + dc * E, ld16<frag>(src));
-        st16(wvc + wbase + (int64_t)q * HD + dc * E, ld16<frag>(src + D));
+        const int64_t o = kv_elem_off(kv_tab, bs_log2, wr, wp0 + q, H, h, smax) + dc * E;
+        st16(wkc + o, ld16<frag>(src));
+        st16(wvc + o, ld16<frag>(src + D));
       }
     }
   }
@@ -286,14 +318,16 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const T* __restrict__
       const int key = jt + kk;
       frag kv = zero_frag<frag>(), vv = zero_frag<frag>();
       if (key < pl) {
-        kv = ld16<frag>(pkc + pbase + (int64_t)key * pstr + dc * E);
-        vv = ld16<frag>(pvc + pbase + (int64_t)key * pstr + dc * E);
+        const int64_t po = (kv_tab != nullptr && !pre_qkv) ? kv_elem_off(kv_tab, bs_log2, p_row, p_pos0 + key, H, h, smax) + dc * E
+                                                           : pbase + (int64_t)key * pstr + dc * E;
+        kv = ld16<frag>(pkc + po);
+        vv = ld16<frag>(pvc + po);
       } else if (key < Stot) {
         const T* src = base + (int64_t)(key - pl) * 3 * D + D + h * HD + dc * E;
         kv = ld16<frag>(src);
         vv = ld16<frag>(src + D);
         if (kc != nullptr && jt == q0) {
-          const int64_t o = (((int64_t)b * H + h) * smax + key + cshift) * HD + dc * E;
+          const int64_t o = kv_elem_off(kv_tab, bs_log2, b, key + cshift, H, h, smax) + dc * E;
           st16(kc + o, kv);
           st16(vc + o, vv);
         }
@@ -392,22 +426,29 @@ namespace itts { constexpr int g_attn_waves = 4; }  // measured equal to 8; the 
 
 extern "C" int itts_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, const int32_t* pad,
                                 const int32_t* pos, int B, int H, int smax, int dtype, int out_packed, const int32_t* kv_rows,
-                                const int32_t* kv_step, const int32_t* skip_rows, const int32_t* kv_share, void* stream) {
+                                const int32_t* kv_step, const int32_t* skip_rows, const int32_t* kv_share, const int32_t* kv_tab,
+                                int kv_bs, void* stream) {
   const int out_mtp = out_packed ? (B + 15) / 16 : 0;
   ITTS_REQUIRE(q && kcache && vcache && out && pad && pos, "itts_attn_decode: null pointer");
-  ITTS_REQUIRE(B > 0 && H > 0 && smax > 0 && smax <= AD_MAXCTX, "itts_attn_decode: bad shape B=%d H=%d smax=%d (max %d)", B, H,
+  const bool paged = kv_tab != nullptr;
+  ITTS_REQUIRE(B > 0 && H > 0 && (paged || (smax > 0 && smax <= AD_MAXCTX)), "itts_attn_decode: bad shape B=%d H=%d smax=%d (max %d)", B, H,
                smax, AD_MAXCTX);
+  ITTS_REQUIRE(!paged || ((kv_bs == 16 || kv_bs == 32 || kv_bs == 64) && kv_rows == nullptr),
+               "itts_attn_decode: a paged cache needs kv_bs in {16, 32, 64} and no beam row table");
+  const int bs_log2 = kv_bs == 64 ? 6 : kv_bs == 32 ? 5 : 4;
   ITTS_REQUIRE((kv_rows == nullptr) == (kv_step == nullptr), "itts_attn_decode: pass both or neither of kv_rows / kv_step");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(H, B), block(g_attn_waves * 64);
   const bool ind = kv_rows != nullptr;
-#define ITTS_AD(TT_, NW_, IND_)                                                                                             \
-  hipLaunchKernelGGL((attn_decode_kernel<TT_, NW_, IND_>), grid, block, 0, s, (const TT_*)q, (const TT_*)kcache,           \
-                     (const TT_*)vcache, (TT_*)out, pad, pos, H, smax, out_mtp, kv_rows, kv_step, B, skip_rows, kv_share)
+#define ITTS_AD(TT_, NW_, IND_, PG_)                                                                                        \
+  hipLaunchKernelGGL((attn_decode_kernel<TT_, NW_, IND_, PG_>), grid, block, 0, s, (const TT_*)q, (const TT_*)kcache,      \
+                     (const TT_*)vcache, (TT_*)out, pad, pos, H, smax, out_mtp, kv_rows, kv_step, B, skip_rows, kv_share, \
+                     kv_tab, bs_log2)
 #define ITTS_AD_T(TT_)                                                            \
   do {                                                                            \
-    if (g_attn_waves == 8) { if (ind) ITTS_AD(TT_, 8, true); else ITTS_AD(TT_, 8, false); } \
-    else { if (ind) ITTS_AD(TT_, 4, true); else ITTS_AD(TT_, 4, false); }          \
+    if (paged) { if (g_attn_waves == 8) ITTS_AD(TT_, 8, false, true); else ITTS_AD(TT_, 4, false, true); } \
+    else if (g_attn_waves == 8) { if (ind) ITTS_AD(TT_, 8, true, false); else ITTS_AD(TT_, 8, false, false); } \
+    else { if (ind) ITTS_AD(TT_, 4, true, false); else ITTS_AD(TT_, 4, false, false); }          \
   } while (0)
   switch (dtype) {
     case ITTS_F32:
@@ -432,8 +473,11 @@ static int attn_prefill_impl(const void* qkv, void* out, void* kcache, void* vca
                              const void* pkc = nullptr, const void* pvc = nullptr, const int32_t* pre_len = nullptr,
                              const int32_t* pre_row = nullptr, const int32_t* pre_pos0 = nullptr, int pre_qkv = 0,
                              void* wkc = nullptr, void* wvc = nullptr, const int32_t* w_row = nullptr,
-                             const int32_t* w_pos0 = nullptr) {
+                             const int32_t* w_pos0 = nullptr, const int32_t* kv_tab = nullptr, int kv_bs = 0) {
   ITTS_REQUIRE(qkv && out, "itts_attn_prefill: null pointer");
+  ITTS_REQUIRE(kv_tab == nullptr || kv_bs == 16 || kv_bs == 32 || kv_bs == 64, "itts_attn_prefill: kv_bs must be 16, 32 or 64");
+  const int bs_log2 = kv_bs == 64 ? 6 : kv_bs == 32 ? 5 : 4;
+  if (kv_tab != nullptr && kcache != nullptr) smax = S > smax ? S : smax;   // (no per-row capacity in the paged form)
   ITTS_REQUIRE((kcache == nullptr) == (vcache == nullptr), "itts_attn_prefill: pass both caches or neither");
   ITTS_REQUIRE(B > 0 && S > 0 && H > 0 && (!kcache || S <= smax), "itts_attn_prefill: bad shape B=%d S=%d H=%d smax=%d", B, S, H, smax);
   ITTS_REQUIRE(B <= 65535 && H <= 65535, "itts_attn_prefill: grid too large");
@@ -442,15 +486,15 @@ static int attn_prefill_impl(const void* qkv, void* out, void* kcache, void* vca
   switch (dtype) {
     case ITTS_F32:
       hipLaunchKernelGGL(attn_prefill_kernel<float>, grid, block, 0, s, (const float*)qkv, (float*)out, (float*)kcache, (float*)vcache, pad, S, H, smax, row_off, cache_shift,
-                         (const float*)pkc, (const float*)pvc, pre_len, pre_row, pre_pos0, pre_qkv, (float*)wkc, (float*)wvc, w_row, w_pos0);
+                         (const float*)pkc, (const float*)pvc, pre_len, pre_row, pre_pos0, pre_qkv, (float*)wkc, (float*)wvc, w_row, w_pos0, kv_tab, bs_log2);
       break;
     case ITTS_BF16:
       hipLaunchKernelGGL(attn_prefill_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, (bf16_t*)kcache, (bf16_t*)vcache, pad, S, H, smax, row_off, cache_shift,
-                         (const bf16_t*)pkc, (const bf16_t*)pvc, pre_len, pre_row, pre_pos0, pre_qkv, (bf16_t*)wkc, (bf16_t*)wvc, w_row, w_pos0);
+                         (const bf16_t*)pkc, (const bf16_t*)pvc, pre_len, pre_row, pre_pos0, pre_qkv, (bf16_t*)wkc, (bf16_t*)wvc, w_row, w_pos0, kv_tab, bs_log2);
       break;
     case ITTS_F16:
       hipLaunchKernelGGL(attn_prefill_kernel<f16_t>, grid, block, 0, s, (const f16_t*)qkv, (f16_t*)out, (f16_t*)kcache, (f16_t*)vcache, pad, S, H, smax, row_off, cache_shift,
-                         (const f16_t*)pkc, (const f16_t*)pvc, pre_len, pre_row, pre_pos0, pre_qkv, (f16_t*)wkc, (f16_t*)wvc, w_row, w_pos0);
+                         (const f16_t*)pkc, (const f16_t*)pvc, pre_len, pre_row, pre_pos0, pre_qkv, (f16_t*)wkc, (f16_t*)wvc, w_row, w_pos0, kv_tab, bs_log2);
       break;
     default:
       ITTS_REQUIRE(false, "itts_attn_prefill: unknown dtype %d", dtype);
@@ -465,15 +509,16 @@ extern "C" int itts_attn_prefill(const void* qkv, void* out, void* kcache, void*
 
 extern "C" int itts_attn_prefill_prefix(const void* qkv, void* out, const void* kcache, const void* vcache, const int32_t* row_off,
                                         const int32_t* pre_len, const int32_t* pre_row, const int32_t* pre_pos0, int B, int Smax,
-                                        int H, int smax, int dtype, void* stream) {
+                                        int H, int smax, int dtype, const int32_t* kv_tab, int kv_bs, void* stream) {
   ITTS_REQUIRE(row_off && kcache && vcache && pre_len && pre_row && pre_pos0, "itts_attn_prefill_prefix: null pointer");
   return attn_prefill_impl(qkv, out, nullptr, nullptr, nullptr, B, Smax, H, smax, dtype, row_off, nullptr, stream, kcache, vcache,
-                           pre_len, pre_row, pre_pos0);
+                           pre_len, pre_row, pre_pos0, 0, nullptr, nullptr, nullptr, nullptr, kv_tab, kv_bs);
 }
 
 extern "C" int itts_attn_prefill_shared(const void* qkv, void* out, void* kcache, void* vcache, const int32_t* row_off,
                                         const int32_t* pre_len, const int32_t* pre_row0, const int32_t* w_row,
-                                        const int32_t* w_pos0, int E, int Smax, int H, int smax, int dtype, void* stream) {
+                                        const int32_t* w_pos0, int E, int Smax, int H, int smax, int dtype, const int32_t* kv_tab,
+                                        int kv_bs, void* stream) {
   ITTS_REQUIRE(qkv && row_off && pre_len && pre_row0 && (kcache == nullptr) == (vcache == nullptr) &&
                    (kcache == nullptr || (w_row && w_pos0)), "itts_attn_prefill_shared: null pointer");
   const int D = H * 64;
@@ -481,11 +526,13 @@ extern "C" int itts_attn_prefill_shared(const void* qkv, void* out, void* kcache
   const char* q = (const char*)qkv;
   return attn_prefill_impl(qkv, out, nullptr, nullptr, nullptr, E, Smax, H, smax, dtype, row_off, nullptr, stream,
                            q + (int64_t)D * es, q + (int64_t)2 * D * es, pre_len, pre_len /* unused */, pre_row0, 1, kcache, vcache,
-                           w_row, w_pos0);
+                           w_row, w_pos0, kv_tab, kv_bs);
 }
 
 extern "C" int itts_attn_prefill_packed(const void* qkv, void* out, void* kcache, void* vcache, const int32_t* row_off,
-                                        const int32_t* cache_shift, int B, int Smax, int H, int smax, int dtype, void* stream) {
+                                        const int32_t* cache_shift, int B, int Smax, int H, int smax, int dtype,
+                                        const int32_t* kv_tab, int kv_bs, void* stream) {
   ITTS_REQUIRE(row_off, "itts_attn_prefill_packed: row_off is null");
-  return attn_prefill_impl(qkv, out, kcache, vcache, nullptr, B, Smax, H, smax, dtype, row_off, cache_shift, stream);
+  return attn_prefill_impl(qkv, out, kcache, vcache, nullptr, B, Smax, H, smax, dtype, row_off, cache_shift, stream, nullptr, nullptr,
+                           nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, kv_tab, kv_bs);
 }

@@ -139,6 +139,17 @@ __device__ __forceinline__ int64_t pa_off(int m, int k, int mtp) {
   return ((((int64_t)(k / KS) * mtp + (m >> 4)) * 64 + ((k % KS) / E) * 16 + (m & 15)) * E) + (k % E);
 }
 
+// KV cache addressing.  Contiguous form (tab == NULL): caches T [rows][H][smax][64], position j of cache row `row`.  Paged form:
+// a pool T [blocks][H][bs][64] (bs = 1 << bs_log2 positions per block) and a block table int32 [rows][ITTS_KV_TAB]; position j
+// of row `row` lives in block tab[row][(j >> bs_log2) % ITTS_KV_TAB] -- a RING over the position index, so a decode loop whose
+// shared write position only ever grows keeps addressing a bounded table (a row's live window must stay under
+// (ITTS_KV_TAB - 2) * bs positions).  Returns the ELEMENT offset of (row, head h, position j, dim 0).
+__device__ __forceinline__ int64_t kv_elem_off(const int32_t* __restrict__ tab, int bs_log2, int row, int j, int H, int h, int smax) {
+  if (tab == nullptr) return (((int64_t)row * H + h) * smax + j) * 64;
+  const int blk = tab[row * ITTS_KV_TAB + ((j >> bs_log2) & (ITTS_KV_TAB - 1))];
+  return ((((int64_t)blk * H + h) << bs_log2) + (j & ((1 << bs_log2) - 1))) * 64;
+}
+
 // transformers NewGELUActivation (gelu_new): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
 __device__ __forceinline__ float gelu_new(float x) {
   const float k = 0.7978845608028654f;

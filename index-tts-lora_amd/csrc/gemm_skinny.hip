@@ -26,6 +26,7 @@
 // indextts/gpt/model.py:163-193.
 #include "common.h"
 #include "ln_math.h"
+#include <type_traits>
 
 #ifndef ITTS_FOLD_ORDER
 #define ITTS_FOLD_ORDER 0   // build-time A/B of the LayerNorm-folded form: 0 = activations requested first, statistics MFMAs under the weight
@@ -57,6 +58,8 @@ struct SkinnyParams {
   int heads, smax;
   int ksplit;
   int slab_rows;
+  const int32_t* kv_tab;   // QKV epilogue into a paged cache: block table [rows][ITTS_KV_TAB], or NULL
+  int kv_bs_log2;
   const float* cvec;       // FOLD: c_j = sum_k gamma_k W_kj (bias then holds d_j)
   float ln_eps;
   int32_t* bump;           // one device word this launch increments (it must not read it)
@@ -213,7 +216,24 @@ __global__ __launch_bounds__(MAXW * 64) void gemm_skinny_kernel(SkinnyParams p) 
   // zeros): every wave executes one straight line -- operand requests, one wait, MFMAs -- with no join in front of the
   // requests (round 3: together with the branch-free bias preload and the LDS-only barrier, 5.65 -> 5.29 us per launch
   // over a block's four GEMMs against the round-2 kernel on the same box, tools/probes/ab_r02_gemm.py).
-  auto k_pass = [&](const int base) {
+  // paged KV cache (QKV epilogue): the block that holds the append position of each of this wave's output rows.  Requested
+  // BEHIND the first pass's operand requests (it needs the position word, and nothing before the epilogue needs it).
+  int blk_pre[UPRE];
+#pragma unroll
+  for (int ui = 0; ui < UPRE; ++ui) blk_pre[ui] = 0;
+  auto table_requests = [&]() {
+    const int32_t* tp = p.kv_tab != nullptr ? p.kv_tab : (const int32_t*)p.wp;   // a readable word either way: a select, no branch
+#pragma unroll
+    for (int ui = 0; ui < UPRE; ++ui) {
+      const int u = wave + ui * NW;
+      const int mt = u % MT;
+      const int row = (mt0 + mt) * 16 + r;
+      const int idx = (p.kv_tab != nullptr && row < p.M) ? (p.row0 + row) * ITTS_KV_TAB + ((pos_pre >> p.kv_bs_log2) & (ITTS_KV_TAB - 1)) : 0;
+      blk_pre[ui] = tp[idx];
+    }
+  };
+  auto k_pass = [&](const int base, auto first_tag) {
+    constexpr bool FIRST_PASS = decltype(first_tag)::value;
     frag bf[NTB][SPW];
     if constexpr (MT <= 2) {
       frag af[SPW][MT];
@@ -235,6 +255,7 @@ __global__ __launch_bounds__(MAXW * 64) void gemm_skinny_kernel(SkinnyParams p) 
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) af[i][mt] = x_frag(base + i, mt);
       }
+      if constexpr (FIRST_PASS) table_requests();
       ITTS_STAMP(1);
 #if ITTS_STAMPS
       ITTS_STAMP_DRAIN();
@@ -265,6 +286,7 @@ __global__ __launch_bounds__(MAXW * 64) void gemm_skinny_kernel(SkinnyParams p) 
       for (int t = 0; t < NTB; ++t)
 #pragma unroll
         for (int i = 0; i < SPW; ++i) bf[t][i] = w_frag(base + i, t);
+      if constexpr (FIRST_PASS) table_requests();
       ITTS_STAMP(1);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -286,8 +308,8 @@ __global__ __launch_bounds__(MAXW * 64) void gemm_skinny_kernel(SkinnyParams p) 
       ITTS_STAMP(2);
     }
   };
-  k_pass(s_begin);
-  for (int base = s_begin + SPW; base < s_end; base += SPW) k_pass(base);
+  k_pass(s_begin, std::true_type{});
+  for (int base = s_begin + SPW; base < s_end; base += SPW) k_pass(base, std::false_type{});
   ITTS_STAMP(3);
 
   // ---- cross-wave reduction, fixed order.  Lane (g, r) of a tile holds Y[row = mt*16 + r][col = tile*16 + 4g .. 4g+3].
@@ -314,7 +336,7 @@ __global__ __launch_bounds__(MAXW * 64) void gemm_skinny_kernel(SkinnyParams p) 
   asm volatile("" ::: "memory");
   ITTS_STAMP(4);
   // one output unit (column tile t, row tile mt): sum the waves' partial tiles, add the bias, apply the epilogue
-  auto unit = [&](const int u, const f32x4 bs, const f32x4 p2) {
+  auto unit = [&](const int u, const f32x4 bs, const f32x4 p2, const int blk) {
     const int t = u / MT, mt = u - t * MT;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     for (int w = 0; w < NW; ++w) v += ld16<f32x4>(red + (((w * NTB + t) * MT + mt) * 64 + lane) * 4);
@@ -370,7 +392,10 @@ __global__ __launch_bounds__(MAXW * 64) void gemm_skinny_kernel(SkinnyParams p) 
           T* cache = (T*)(cc < D ? p.kcache : p.vcache);
           if (cc >= D) cc -= D;
           const int hh = cc >> 6, dd = cc & 63;
-          store4<T>(cache + (((int64_t)row * p.heads + hh) * p.smax + pos_pre) * 64 + dd, v, nval);
+          const int64_t at = p.kv_tab == nullptr
+                                 ? (((int64_t)row * p.heads + hh) * p.smax + pos_pre) * 64
+                                 : ((((int64_t)blk * p.heads + hh) << p.kv_bs_log2) + (pos_pre & ((1 << p.kv_bs_log2) - 1))) * 64;
+          store4<T>(cache + at + dd, v, nval);
         }
       } break;
     }
@@ -378,7 +403,7 @@ __global__ __launch_bounds__(MAXW * 64) void gemm_skinny_kernel(SkinnyParams p) 
 #pragma unroll
   for (int ui = 0; ui < UPRE; ++ui) {
     const int u = wave + ui * NW;
-    if (u < NTB * MT) unit(u, bias_pre[ui], pre2[ui]);
+    if (u < NTB * MT) unit(u, bias_pre[ui], pre2[ui], blk_pre[ui]);
   }
   for (int u = wave + UPRE * NW; u < NTB * MT; u += NW) {   // fewer than 8 waves (tiny K): the remaining units
     f32x4 bs = {0.f, 0.f, 0.f, 0.f}, p2 = bs;
@@ -389,7 +414,10 @@ __global__ __launch_bounds__(MAXW * 64) void gemm_skinny_kernel(SkinnyParams p) 
       if constexpr (FOLD) p2 = load4f(p.cvec + col0, p.N - col0);
       else if (p.epi == ITTS_EPI_RESID_F32 && row < p.M) p2 = load4f(p.yf + (int64_t)row * p.N + col0, p.N - col0);
     }
-    unit(u, bs, p2);
+    int blk = 0;
+    if (p.kv_tab != nullptr && row < p.M)
+      blk = p.kv_tab[(p.row0 + row) * ITTS_KV_TAB + ((pos_pre >> p.kv_bs_log2) & (ITTS_KV_TAB - 1))];
+    unit(u, bs, p2, blk);
   }
   // the loop-state word this launch advances (nothing in this launch reads it)
   if (p.bump != nullptr && tid == 0 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0) p.bump[0] += 1;
@@ -535,8 +563,9 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
   ITTS_REQUIRE(ksplit <= a->K / ks && ksplit <= 64, "itts_gemm_skinny: ksplit=%d too large", ksplit);
   ITTS_REQUIRE(ksplit == 1 || a->epi == ITTS_EPI_SLAB_F32, "itts_gemm_skinny: ksplit > 1 requires the slab epilogue");
   if (a->epi == ITTS_EPI_QKV_CACHE)
-    ITTS_REQUIRE(a->y && a->kcache && a->vcache && a->pos && a->N % 3 == 0 && a->N / 3 == a->heads * 64 && a->smax > 0,
-                 "itts_gemm_skinny: bad QKV epilogue arguments");
+    ITTS_REQUIRE(a->y && a->kcache && a->vcache && a->pos && a->N % 3 == 0 && a->N / 3 == a->heads * 64 &&
+                     (a->kv_tab != nullptr ? (a->kv_bs == 16 || a->kv_bs == 32 || a->kv_bs == 64) : a->smax > 0),
+                 "itts_gemm_skinny: bad QKV epilogue arguments (paged cache: kv_bs must be 16, 32 or 64)");
   else if (a->epi == ITTS_EPI_RESID_F32 || a->epi == ITTS_EPI_STORE_F32 || a->epi == ITTS_EPI_SLAB_F32)
     ITTS_REQUIRE(a->yf, "itts_gemm_skinny: yf is null");
   else
@@ -571,8 +600,11 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
     p.y = a->y ? (a->y_packed ? (char*)a->y : (char*)a->y + (size_t)r0 * ycols * esz) : nullptr;
     p.yf = a->yf ? a->yf + (size_t)r0 * a->N : nullptr;
     const size_t crow = (size_t)a->heads * a->smax * 64 * esz;
-    p.kcache = a->kcache ? (char*)a->kcache + (size_t)r0 * crow : nullptr;
-    p.vcache = a->vcache ? (char*)a->vcache + (size_t)r0 * crow : nullptr;
+    const bool paged = a->kv_tab != nullptr;   // (the table row, not the cache pointer, carries the chunk's first row)
+    p.kcache = a->kcache ? (char*)a->kcache + (paged ? 0 : (size_t)r0 * crow) : nullptr;
+    p.vcache = a->vcache ? (char*)a->vcache + (paged ? 0 : (size_t)r0 * crow) : nullptr;
+    p.kv_tab = a->kv_tab;
+    p.kv_bs_log2 = a->kv_bs == 64 ? 6 : a->kv_bs == 32 ? 5 : 4;
     p.pos = a->pos;
     p.heads = a->heads;
     p.smax = a->smax;

@@ -29,7 +29,8 @@ class SkinnyArgs(C.Structure):
                 ("bias", C.c_void_p), ("x", C.c_void_p), ("epi", C.c_int), ("y", C.c_void_p), ("yf", C.c_void_p),
                 ("kcache", C.c_void_p), ("vcache", C.c_void_p), ("pos", C.c_void_p), ("heads", C.c_int),
                 ("smax", C.c_int), ("ksplit", C.c_int), ("ln_c", C.c_void_p), ("ln_eps", C.c_float), ("bump", C.c_void_p),
-                ("rows_per_wg", C.c_int), ("wide_wg", C.c_int), ("x_packed", C.c_int), ("y_packed", C.c_int)]
+                ("rows_per_wg", C.c_int), ("wide_wg", C.c_int), ("kv_tab", C.c_void_p), ("kv_bs", C.c_int),
+                ("x_packed", C.c_int), ("y_packed", C.c_int)]
 
 
 class LnReduceArgs(C.Structure):
@@ -87,15 +88,17 @@ _SIGNATURES = {
     "itts_embed_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                   C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "itts_attn_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_int, C.c_void_p]),
     "itts_attn_prefill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_attn_prefill_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "itts_attn_prefill_prefix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                           C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                                           C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "itts_attn_prefill_shared": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                           C.c_void_p]),
     "itts_sample": (C.c_int, [C.POINTER(SampleArgs), C.c_void_p]),
     "itts_beam_step": (C.c_int, [C.POINTER(BeamArgs), C.c_void_p]),
     "itts_beam_kv_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -204,7 +207,7 @@ def aa_snake(x, alpha_log, beta_log, up_f, down_f, layout=0, out=None, valid_row
 
 def gemm_skinny(dtype, M, N, K, wp, bias=None, x=None, epi=EPI_STORE, y=None, yf=None, kcache=None, vcache=None, pos=None,
                 heads=0, smax=0, ksplit=1, x_packed=False, y_packed=False, ln_c=None, ln_eps=1e-5, bump=None, rows_per_wg=0,
-                wide_wg=False):
+                wide_wg=False, kv_tab=None, kv_bs=0):
     """ln_c fp32 [N]: LayerNorm folded into the GEMM -- x holds the RAW rows, wp = pack(gamma . W), bias = beta W + b
     (see itts_skinny_args).  EPI_RESID_F32: yf += x W + bias, and y (optional, T) receives a copy of the new rows.
     bump: int32 device word the launch increments.  rows_per_wg / wide_wg: launch-geometry hints."""
@@ -216,6 +219,7 @@ def gemm_skinny(dtype, M, N, K, wp, bias=None, x=None, epi=EPI_STORE, y=None, yf
     a.x_packed, a.y_packed = int(bool(x_packed)), int(bool(y_packed))
     a.ln_c, a.ln_eps, a.bump = _p(ln_c), float(ln_eps), _p(bump)
     a.rows_per_wg, a.wide_wg = int(rows_per_wg), int(bool(wide_wg))
+    a.kv_tab, a.kv_bs = _p(kv_tab), int(kv_bs)
     _check(lib().itts_gemm_skinny(C.byref(a), _stream()), "itts_gemm_skinny")
 
 
@@ -312,12 +316,13 @@ def embed_step(tokens, table, pos_table, step, pos_add, h, bump=None, row_step0=
 
 
 def attn_decode(q, kcache, vcache, out, pad, pos, B, H, smax, out_packed=False, kv_rows=None, kv_step=None, skip_rows=None,
-                kv_share=None):
+                kv_share=None, kv_tab=None, kv_bs=0):
     """kv_rows int32 [2][B][smax] + kv_step (device word): beam-search row table instead of permuted cache rows.
     skip_rows int32 [B]: rows with a nonzero entry are left out (their slice of `out` is not written).
     kv_share (device word (p0 << 8) | C): the first C keys of every row equal cache row 0's positions [p0, p0 + C)."""
     _check(lib().itts_attn_decode(_p(q), _p(kcache), _p(vcache), _p(out), _p(pad), _p(pos), B, H, smax, dt(q.dtype),
-                                  int(bool(out_packed)), _p(kv_rows), _p(kv_step), _p(skip_rows), _p(kv_share), _stream()),
+                                  int(bool(out_packed)), _p(kv_rows), _p(kv_step), _p(skip_rows), _p(kv_share), _p(kv_tab), int(kv_bs),
+                                  _stream()),
            "itts_attn_decode")
 
 
@@ -326,28 +331,30 @@ def attn_prefill(qkv, out, kcache, vcache, pad, B, S, H, smax):
                                    _stream()), "itts_attn_prefill")
 
 
-def attn_prefill_packed(qkv, out, kcache, vcache, row_off, cache_shift, B, Smax, H, smax):
-    """Packed rows (no padding): row_off int32 [B+1]; cache row of local row i = cache_shift[b] + i."""
+def attn_prefill_packed(qkv, out, kcache, vcache, row_off, cache_shift, B, Smax, H, smax, kv_tab=None, kv_bs=0):
+    """Packed rows (no padding): row_off int32 [B+1]; cache row of local row i = cache_shift[b] + i.
+    kv_tab / kv_bs: the caches are a paged pool behind a block table (include/indextts_hip.h)."""
     _check(lib().itts_attn_prefill_packed(_p(qkv), _p(out), _p(kcache), _p(vcache), _p(row_off), _p(cache_shift), B, Smax, H,
-                                          smax, dt(qkv.dtype), _stream()), "itts_attn_prefill_packed")
+                                          smax, dt(qkv.dtype), _p(kv_tab), int(kv_bs), _stream()), "itts_attn_prefill_packed")
 
 
-def attn_prefill_prefix(qkv, out, kcache, vcache, row_off, pre_len, pre_row, pre_pos0, B, Smax, H, smax):
+def attn_prefill_prefix(qkv, out, kcache, vcache, row_off, pre_len, pre_row, pre_pos0, B, Smax, H, smax, kv_tab=None, kv_bs=0):
     """Packed query rows behind a cached prefix: element b = pre_len[b] keys of cache row pre_row[b] from position pre_pos0[b],
     then its rows of qkv (see include/indextts_hip.h)."""
     if not (kcache.is_contiguous() and vcache.is_contiguous()):
         raise NativeError("itts_attn_prefill_prefix: the caches must be contiguous [rows][H][smax][64] views")
     _check(lib().itts_attn_prefill_prefix(_p(qkv), _p(out), _p(kcache), _p(vcache), _p(row_off), _p(pre_len), _p(pre_row),
-                                          _p(pre_pos0), B, Smax, H, smax, dt(qkv.dtype), _stream()), "itts_attn_prefill_prefix")
+                                          _p(pre_pos0), B, Smax, H, smax, dt(qkv.dtype), _p(kv_tab), int(kv_bs), _stream()),
+           "itts_attn_prefill_prefix")
 
 
-def attn_prefill_shared(qkv, out, kcache, vcache, row_off, pre_len, pre_row0, w_row, w_pos0, E, Smax, H, smax):
+def attn_prefill_shared(qkv, out, kcache, vcache, row_off, pre_len, pre_row0, w_row, w_pos0, E, Smax, H, smax, kv_tab=None, kv_bs=0):
     """Packed elements behind a prefix block that lives in qkv itself (computed once, shared); own rows appended to the caches
     (see include/indextts_hip.h)."""
     if kcache is not None and not (kcache.is_contiguous() and vcache.is_contiguous()):
         raise NativeError("itts_attn_prefill_shared: the caches must be contiguous [rows][H][smax][64] views")
     _check(lib().itts_attn_prefill_shared(_p(qkv), _p(out), _p(kcache), _p(vcache), _p(row_off), _p(pre_len), _p(pre_row0),
-                                          _p(w_row), _p(w_pos0), E, Smax, H, smax, dt(qkv.dtype), _stream()),
+                                          _p(w_row), _p(w_pos0), E, Smax, H, smax, dt(qkv.dtype), _p(kv_tab), int(kv_bs), _stream()),
            "itts_attn_prefill_shared")
 
 

@@ -21,6 +21,79 @@ import torch
 from .. import _native as nat
 
 
+KV_TAB = 64   # ITTS_KV_TAB: ring entries of a row's block table
+
+
+class PagedKV:
+    """Paged KV cache of one engine (include/indextts_hip.h, "Paged KV cache"): a block pool per layer, K and V, T
+    [L][blocks][H][bs][64]; a block table int32 [rows][64] on the device with a host mirror; a free list.  Block 0 is the
+    scratch block: every table entry that maps no live position points at it (a row that has stopped keeps appending its
+    stop-token keys there; masked / clamped reads stay inside the pool).  Positions are the decode loop's global positions
+    (left-padded rows, one shared write position); the table is a ring over position / bs, so the position counter may grow
+    without bound while every row's live window stays under (64 - 2) * bs positions."""
+
+    def __init__(self, L, H, rows, blocks, bs, dtype, device):
+        assert bs in (16, 32, 64)
+        self.bs, self.shift, self.rows, self.blocks = bs, bs.bit_length() - 1, rows, blocks
+        self.kc = torch.zeros(L, blocks, H, bs, 64, dtype=dtype, device=device)
+        self.vc = torch.zeros(L, blocks, H, bs, 64, dtype=dtype, device=device)
+        self.tab = torch.zeros(rows, KV_TAB, dtype=torch.int32, device=device)
+        self.reset()
+
+    def reset(self):
+        import numpy as np
+        self.tab_h = np.zeros((self.rows, KV_TAB), dtype=np.int32)
+        self.free = list(range(self.blocks - 1, 0, -1))     # block 0 = scratch
+        self.span = [None] * self.rows                       # per row: [first, last + 1) block INDEX (position >> shift) mapped
+        self.dirty = True
+
+    @property
+    def window(self):
+        """Most positions a row may keep live."""
+        return (KV_TAB - 2) * self.bs
+
+    def cover(self, row, lo, hi):
+        """Map blocks for positions [lo, hi) of `row` (extends the row's span at its upper end; a new row starts a span)."""
+        b0, b1 = lo >> self.shift, ((hi - 1) >> self.shift) + 1
+        sp = self.span[row]
+        if sp is None:
+            sp = self.span[row] = [b0, b0]
+        if b1 - sp[0] > KV_TAB - 1:
+            raise ValueError(f"paged KV: row {row} would keep {(b1 - sp[0]) * self.bs} positions live (limit {self.window})")
+        while sp[1] < b1:
+            if not self.free:
+                raise RuntimeError("paged KV: the block pool is exhausted")
+            self.tab_h[row, sp[1] & (KV_TAB - 1)] = self.free.pop()
+            sp[1] += 1
+            self.dirty = True
+
+    def release(self, row):
+        """The row has left: its blocks go back to the pool, its entries to the scratch block."""
+        sp = self.span[row]
+        if sp is None:
+            return
+        for bi in range(sp[0], sp[1]):
+            self.free.append(int(self.tab_h[row, bi & (KV_TAB - 1)]))
+        self.tab_h[row, :] = 0
+        self.span[row] = None
+        self.dirty = True
+
+    def flush(self):
+        """Host mirror -> device table, on the current stream (ordered between the loop's graph replays)."""
+        if self.dirty:
+            self.tab.copy_(torch.from_numpy(self.tab_h))
+            self.dirty = False
+
+    def phys(self, rows, pos):
+        """(block, offset) numpy arrays of positions `pos` of table rows `rows` (numpy int arrays of equal length)."""
+        import numpy as np
+        rows, pos = np.asarray(rows, dtype=np.int64), np.asarray(pos, dtype=np.int64)
+        return self.tab_h[rows, (pos >> self.shift) & (KV_TAB - 1)].astype(np.int64), pos & (self.bs - 1)
+
+    def used_blocks(self):
+        return self.blocks - 1 - len(self.free)
+
+
 class GPTEngine:
     def __init__(self, W: dict, layers: int, model_dim: int, heads: int, dtype=torch.bfloat16, device="cuda",
                  start_mel_token=8192, stop_mel_token=8193):
@@ -60,6 +133,12 @@ class GPTEngine:
         # beam search: KV rows follow their beams through a row TABLE read by the attention kernel ("table", no cache bytes
         # move) or by permuting the cache rows in place ("copy": itts_beam_reorder_kv, the reference form of
         # GPT2InferenceModel._reorder_cache, model.py:207-218; 1 ms per token at 32 x 3 rows)
+        # num_beams = 1: the KV cache is PAGED (block pool + per-row block table, class PagedKV): rows hold only the blocks their
+        # own window needs, and continuous batching (decode_refill) hands the blocks of a row that has stopped to the utterance
+        # that takes its slot -- the loop runs for as long as the queue lasts inside a fixed pool.  ITTS_PAGED_KV=0: contiguous
+        # [rows][H][smax][64] strips (what beam search uses: its per-position row table addresses whole rows).
+        self.paged = os.environ.get("ITTS_PAGED_KV", "1") == "1"
+        self.kv = None            # PagedKV of the batch in flight (None: contiguous cache)
         self.beam_kv = os.environ.get("ITTS_BEAM_KV", "table")
         self._kv_rows = None   # the table of the beam decode in progress (None outside decode_beam)
         self._shared_prefix = None   # (B, num_beams) after prefill(beams=n): the prompt's K/V exists once per batch element
@@ -107,6 +186,7 @@ class GPTEngine:
         self.text_pos = f32("text_pos_embedding.emb.weight")
         self.extra_ids = torch.tensor([1, start_mel_token], dtype=torch.int32, device=dev)  # fake prefix ids (model.py:658-667)
         self._cap_b = self._cap_s = 0
+        self._kv_pool = None      # the PagedKV object kept across batches (re-made when it has to grow)
         self._graphs = {}
         # split-K of the two N=1280 GEMMs of a block (80 column tiles): 3 -> 80 x 3 = 240 workgroups of one tile; 6 -> 40 x 6 = 240
         # workgroups of TWO tiles, whose waves fetch each activation fragment once for both (a third less load traffic per CU)
@@ -190,6 +270,8 @@ class GPTEngine:
         e = copy.copy(self)
         e.layers = [dict(l) for l in self.layers]
         e._cap_b = e._cap_s = 0
+        e.kv = None
+        e._kv_pool = None
         e._graphs = {}
         e._beam_cap = (0, 0, 0)
         e._kv_rows = None
@@ -197,36 +279,75 @@ class GPTEngine:
         return e
 
     # ------------------------------------------------------------------------------------------------ buffers
-    def _ensure(self, B: int, smax: int):
-        if B <= self._cap_b and smax <= self._cap_s:
-            return
-        B = max(B, self._cap_b)
-        smax = max(smax, self._cap_s)
-        smax = (smax + 63) // 64 * 64
-        if smax > 16384:
-            raise ValueError(f"context {smax} exceeds the decode-attention limit of 16384 cache positions")
+    def _ensure(self, B: int, smax: int, paged=False, blocks=0, bs=16):
+        """Buffers for B rows.  Contiguous cache: smax positions per row.  Paged cache: a pool of `blocks` blocks of `bs`
+        positions (smax is then only the nominal window, nothing is sized by it)."""
         dev, T = self.device, self.dtype
-        self.kc = torch.zeros(self.L, B, self.H, smax, 64, dtype=T, device=dev)
-        self.vc = torch.zeros(self.L, B, self.H, smax, 64, dtype=T, device=dev)
-        self.h = torch.zeros(B, self.D, dtype=torch.float32, device=dev)
-        Bp = nat.packed_rows(B)   # the packed layout works in 16-row tiles
-        self.q = torch.zeros(B, self.D, dtype=T, device=dev)
-        self.a = torch.zeros(Bp, self.D, dtype=T, device=dev)
-        self.f = torch.zeros(Bp, 4 * self.D, dtype=T, device=dev)
-        self.xn = torch.zeros(Bp, self.D, dtype=T, device=dev)
-        self.hb = torch.zeros(Bp, self.D, dtype=T, device=dev)   # "fold" mode: T-typed packed copy of the residual rows
-        self.slab = torch.zeros(self.KSPLIT, B, self.D + 64, dtype=torch.float32, device=dev)   # + runtime-LoRA columns
-        self.logits = torch.zeros(B, self.V, dtype=torch.float32, device=dev)
-        self.tokens = torch.zeros(B, dtype=torch.int32, device=dev)
-        self.finished = torch.zeros(B, dtype=torch.int32, device=dev)
-        self.pad = torch.zeros(B, dtype=torch.int32, device=dev)
-        self.force_stop = torch.full((B,), -1, dtype=torch.int32, device=dev)
-        self.row_step0 = torch.zeros(B, dtype=torch.int32, device=dev)   # loop step at which each row started (decode_refill)
-        self.kv_share = torch.zeros(1, dtype=torch.int32, device=dev)    # (p0 << 8) | C: rows' first C keys == row 0's at p0 (itts_attn_decode)
-        self.state = torch.zeros(8, dtype=torch.int32, device=dev)
-        self.history = torch.zeros(B, 2048, dtype=torch.int32, device=dev)
-        self._cap_b, self._cap_s = B, smax
-        self._graphs.clear()
+        if B > self._cap_b:
+            B = max(B, self._cap_b)
+            self.h = torch.zeros(B, self.D, dtype=torch.float32, device=dev)
+            Bp = nat.packed_rows(B)   # the packed layout works in 16-row tiles
+            self.q = torch.zeros(B, self.D, dtype=T, device=dev)
+            self.a = torch.zeros(Bp, self.D, dtype=T, device=dev)
+            self.f = torch.zeros(Bp, 4 * self.D, dtype=T, device=dev)
+            self.xn = torch.zeros(Bp, self.D, dtype=T, device=dev)
+            self.hb = torch.zeros(Bp, self.D, dtype=T, device=dev)   # "fold" mode: T-typed packed copy of the residual rows
+            self.slab = torch.zeros(self.KSPLIT, B, self.D + 64, dtype=torch.float32, device=dev)   # + runtime-LoRA columns
+            self.logits = torch.zeros(B, self.V, dtype=torch.float32, device=dev)
+            self.tokens = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.finished = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.pad = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.force_stop = torch.full((B,), -1, dtype=torch.int32, device=dev)
+            self.row_step0 = torch.zeros(B, dtype=torch.int32, device=dev)   # loop step at which each row started (decode_refill)
+            self.kv_share = torch.zeros(1, dtype=torch.int32, device=dev)    # (p0 << 8) | C: rows' first C keys == row 0's at p0 (itts_attn_decode)
+            self.state = torch.zeros(8, dtype=torch.int32, device=dev)
+            self.history = torch.zeros(B, 2048, dtype=torch.int32, device=dev)
+            self._cap_b = B
+            self._cap_s = 0          # the contiguous cache follows the row buffers
+            self._kv_pool = None
+            self._graphs.clear()
+        if paged:
+            kv = self._kv_pool
+            if kv is None or kv.rows < self._cap_b or kv.blocks < blocks or kv.bs != bs:
+                kv = None
+                self.kv = self._kv_pool = None          # release the old pool before the new one is allocated
+                kv = self._kv_pool = PagedKV(self.L, self.H, self._cap_b, max(blocks, 2), bs, T, dev)
+                self._graphs.clear()
+            else:
+                kv.reset()
+            self.kv = kv
+            self.kc, self.vc = kv.kc, kv.vc
+            if self._cap_s:                              # a contiguous cache of an earlier (beam) batch: its graphs go with it
+                self._cap_s = 0
+                self._kc_rows = self._vc_rows = None
+                self._graphs.clear()
+            return
+        self.kv = None
+        if smax > self._cap_s:
+            smax = (smax + 63) // 64 * 64
+            if smax > 16384:
+                raise ValueError(f"context {smax} exceeds the decode-attention limit of 16384 cache positions")
+            self._kv_pool = None
+            self._kc_rows = torch.zeros(self.L, self._cap_b, self.H, smax, 64, dtype=T, device=dev)
+            self._vc_rows = torch.zeros(self.L, self._cap_b, self.H, smax, 64, dtype=T, device=dev)
+            self._cap_s = smax
+            self._graphs.clear()
+        self.kc, self.vc = self._kc_rows, self._vc_rows
+
+    def _kvargs(self):
+        """Keyword arguments that tell a kernel where position j of a cache row lives."""
+        return dict(kv_tab=self.kv.tab, kv_bs=self.kv.bs) if self.kv is not None else {}
+
+    def dense_kv(self, rows: int, S: int):
+        """(K, V) T [L, rows, H, S, 64] of cache positions [0, S): a dense copy whatever the cache layout (tests, tools)."""
+        if self.kv is None:
+            return self.kc[:, :rows, :, :S].clone(), self.vc[:, :rows, :, :S].clone()
+        import numpy as np
+        r, p = np.repeat(np.arange(rows), S), np.tile(np.arange(S), rows)
+        blk, off = (torch.from_numpy(a).to(self.device) for a in self.kv.phys(r, p))
+        k = self.kc[:, blk, :, off].view(rows, S, self.L, self.H, 64).permute(2, 0, 3, 1, 4).contiguous()
+        v = self.vc[:, blk, :, off].view(rows, S, self.L, self.H, 64).permute(2, 0, 3, 1, 4).contiguous()
+        return k, v
 
     # ------------------------------------------------------------------------------------------------ big-M passes
     def _blocks_full(self, h, B, S, pad, use_cache, row_off=None, cache_shift=None):
@@ -247,7 +368,8 @@ class GPTEngine:
             if row_off is None:
                 nat.attn_prefill(qkv, att, kc, vc, pad, B, S, H, self._cap_s)
             else:
-                nat.attn_prefill_packed(qkv, att, kc, vc, row_off, cache_shift, B, S, H, self._cap_s)
+                nat.attn_prefill_packed(qkv, att, kc, vc, row_off, cache_shift, B, S, H, self._cap_s,
+                                        **(self._kvargs() if use_cache else {}))
             nat.gemm_conv(T, 1, M, M, D, D, l.get("w_o_merged", l["w_o"]), att, h, bias=l["b_o"], y_f32=True, resid=h)
             nat.layernorm(h, l["ln2"][0], l["ln2"][1], xn)
             nat.gemm_conv(T, 1, M, M, D, 4 * D, l["w_fc"], xn, ff, bias=l["b_fc"], act=1)
@@ -303,18 +425,26 @@ class GPTEngine:
             nat.layernorm(h, l["ln1"][0], l["ln1"][1], xn)
             nat.gemm_conv(T, 1, M, M, D, 3 * D, l["w_qkv"], xn, qkv, bias=l["b_qkv"])
             nat.attn_prefill_shared(qkv, att, self.kc[i], self.vc[i], row_off, pre_len, pre_row0, w_row, w_pos0, E, Smax, H,
-                                    self._cap_s)
+                                    self._cap_s, **self._kvargs())
             nat.gemm_conv(T, 1, M, M, D, D, l.get("w_o_merged", l["w_o"]), att, h, bias=l["b_o"], y_f32=True, resid=h)
             nat.layernorm(h, l["ln2"][0], l["ln2"][1], xn)
             nat.gemm_conv(T, 1, M, M, D, 4 * D, l["w_fc"], xn, ff, bias=l["b_fc"], act=1)
             nat.gemm_conv(T, 1, M, M, 4 * D, D, l.get("w_pr_merged", l["w_pr"]), ff, h, bias=l["b_pr"], y_f32=True, resid=h)
         if B > 1:   # the shared block's keys / values: cache row 0 -> the same sequence positions of every other cache row
             p0 = pad_h[0]
-            self.kc[:, i_db, :, i_dp] = self.kc[:, 0, :, p0:p0 + C].permute(2, 0, 1, 3).repeat(B - 1, 1, 1, 1)
-            self.vc[:, i_db, :, i_dp] = self.vc[:, 0, :, p0:p0 + C].permute(2, 0, 1, 3).repeat(B - 1, 1, 1, 1)
+            if self.kv is None:
+                self.kc[:, i_db, :, i_dp] = self.kc[:, 0, :, p0:p0 + C].permute(2, 0, 1, 3).repeat(B - 1, 1, 1, 1)
+                self.vc[:, i_db, :, i_dp] = self.vc[:, 0, :, p0:p0 + C].permute(2, 0, 1, 3).repeat(B - 1, 1, 1, 1)
+            else:   # the same copy through the block table: (block, offset) of every source / destination position
+                sb, so = self.kv.phys(np.zeros((B - 1) * C, np.int64), np.tile(p0 + np.arange(C), B - 1))
+                db, do = self.kv.phys(dst_b, dst_p)
+                ix = torch.from_numpy(np.stack([sb, so, db, do])).to(dev)
+                self.kc[:, ix[2], :, ix[3]] = self.kc[:, ix[0], :, ix[1]]
+                self.vc[:, ix[2], :, ix[3]] = self.vc[:, ix[0], :, ix[1]]
         return h[last_rows].contiguous()
 
-    def prefill(self, prefix_emb: torch.Tensor, pad: torch.Tensor, max_new: int, beams: int = 1, shared_rows: int = 0):
+    def prefill(self, prefix_emb: torch.Tensor, pad: torch.Tensor, max_new: int, beams: int = 1, shared_rows: int = 0, paged=None,
+                slots_window: int = 0):
         """prefix_emb fp32 [B,P,D] (left-padded with zeros), pad int [B].  Runs prefix + start token (mel position 0,
         model.py:152-162), fills the KV cache rows [pad_b, P] of every element, leaves logits of the last position in
         self.logits.  The left-padding rows are never computed: the real rows are packed (one gather), the GEMMs run over
@@ -326,17 +456,37 @@ class GPTEngine:
         beams > 1 (beam search with the row table): HF expands every row to `beams` identical rows BEFORE the first forward;
         here the prompt is computed and cached ONCE per batch element (cache rows 0..B-1) and decode_beam() points the table
         entries of all its beams at that copy -- a third of the prefill work and prompt cache at 3 beams, identical values
-        (the expanded rows are bit-wise copies).  The engine then holds B*beams rows: logits and pad are expanded here."""
+        (the expanded rows are bit-wise copies).  The engine then holds B*beams rows: logits and pad are expanded here.
+        paged (default: the engine's setting for beams == 1, never with beams > 1): the cache is a block pool behind a block
+        table (class PagedKV).  Every row gets the blocks for its own window [pad_b, S + max_new]; a caller that goes on with
+        decode_beam() over expanded rows passes paged=False (beam search addresses whole contiguous rows).  slots_window > 0
+        (decode_refill's pool): size the pool for B rows of up to that many live positions each instead of this batch's."""
         B, P, D = prefix_emb.shape
         S = P + 1
         beams = int(beams)
         if beams > 1 and self.beam_kv != "table":
             raise ValueError("prefill(beams>1) needs the KV row table (beam_kv='table')")
-        self._ensure(B * beams, S + max_new + 1)
+        pad_h = [int(v) for v in torch.as_tensor(pad).tolist()]
+        use_pages = (self.paged if paged is None else bool(paged)) and beams == 1
+        if use_pages:
+            window = max(S + max_new + 1 - min(pad_h), int(slots_window))
+            bs = 16 if window <= (KV_TAB - 2) * 16 else 32 if window <= (KV_TAB - 2) * 32 else 64
+            if window > (KV_TAB - 2) * 64:
+                use_pages = False      # a window no block table of 64 entries covers: contiguous rows
+        if use_pages:
+            span = lambda lo, hi: ((hi - 1) // bs) - (lo // bs) + 1   # noqa: E731  blocks that cover positions [lo, hi)
+            need = sum(span(p, S + max_new + 1) for p in pad_h)
+            if slots_window:
+                need = max(need, B * (int(slots_window) // bs + 2))
+            self._ensure(B, S + max_new + 1, paged=True, blocks=need + 1, bs=bs)
+            for b, p in enumerate(pad_h):
+                self.kv.cover(b, p, S + max_new + 1)
+            self.kv.flush()
+        else:
+            self._ensure(B * beams, S + max_new + 1)
         dev = self.device
         start = self.mel_emb[self.start_mel] + self.mel_pos[0]
         emb = torch.cat([prefix_emb.to(dev, torch.float32), start.expand(B, 1, D)], dim=1).contiguous()
-        pad_h = [int(v) for v in torch.as_tensor(pad).tolist()]
         self._pad_host = pad_h             # latent_mel_rows() finds the prompt's K/V in the cache through it
         self.pad[:B] = torch.tensor(pad_h, dtype=torch.int32).to(dev)
         self.kv_share.zero_()
@@ -378,7 +528,8 @@ class GPTEngine:
         final_norm(ln_f(blocks(emb))) fp32 [B,S,D].  With `lengths` (host ints, real rows per element) only the real rows
         are computed (packed); the padding rows of the result are zero."""
         B, S, D = emb.shape
-        self._ensure(1, 64)
+        if self._cap_b == 0:
+            self._ensure(1, 64)
         dev = self.device
         src = emb.to(dev, torch.float32).contiguous().view(B * S, D)
         if lengths is None:
@@ -437,7 +588,8 @@ class GPTEngine:
             nat.layernorm(h, l["ln1"][0], l["ln1"][1], xn)
             nat.gemm_conv(T, 1, Mm, Mm, D, 3 * D, l["w_qkv"], xn, qkv, bias=l["b_qkv"])
             # the prompt's keys / values straight from the decode cache (itts_attn_prefill_prefix), the mel rows' from qkv
-            nat.attn_prefill_prefix(qkv, att, self.kc[i], self.vc[i], row_off, pre_len, pre_row, pre_pos0, B, max(m), H, self._cap_s)
+            nat.attn_prefill_prefix(qkv, att, self.kc[i], self.vc[i], row_off, pre_len, pre_row, pre_pos0, B, max(m), H, self._cap_s,
+                                    **self._kvargs())
             nat.gemm_conv(T, 1, Mm, Mm, D, D, l.get("w_o_merged", l["w_o"]), att, h, bias=l["b_o"], y_f32=True, resid=h)
             nat.layernorm(h, l["ln2"][0], l["ln2"][1], xn)
             nat.gemm_conv(T, 1, Mm, Mm, D, 4 * D, l["w_fc"], xn, ff, bias=l["b_fc"], act=1)
@@ -474,6 +626,7 @@ class GPTEngine:
             bump = getattr(self, "_pending_bump", False)
         self._pending_bump = False
         rs0 = self.row_step0 if self._kv_rows is None else None
+        kva = self._kvargs()
         if self._fold_now(B):
             hb = self.hb
             # mel position of token k is k + 1 (model.py:163-167); with a pending bump state[0] still holds k - 1
@@ -483,11 +636,11 @@ class GPTEngine:
             for i, l in enumerate(self.layers):
                 nat.gemm_skinny(T, B, 3 * D, D, l["wf_qkv"], l["d_qkv"], x=hb, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
                                 vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s, x_packed=True, ln_c=l["c_qkv"],
-                                bump=step if (bump and i == 0) else None)
+                                bump=step if (bump and i == 0) else None, **kva)
                 nat.attn_decode(self.q, self.kc[i], self.vc[i], self.a, self.pad, pos, B, H, self._cap_s, out_packed=pa,
                                 kv_rows=self._kv_rows, kv_step=step if self._kv_rows is not None else None,
                                 skip_rows=self.finished if self._kv_rows is None and self.skip_finished else None,
-                                kv_share=self.kv_share if self._kv_rows is None else None)
+                                kv_share=self.kv_share if self._kv_rows is None else None, **kva)
                 nat.gemm_skinny(T, B, D, D, l["w_o"], l["b_o"], x=self.a, epi=nat.EPI_RESID_F32, yf=h, y=hb, x_packed=pa,
                                 y_packed=True, rows_per_wg=r_o, wide_wg=self.fold_wide)
                 nat.gemm_skinny(T, B, 4 * D, D, l["wf_fc"], l["d_fc"], x=hb, epi=nat.EPI_GELU_STORE, y=self.f, x_packed=True,
@@ -507,11 +660,11 @@ class GPTEngine:
             w_o = l.get("w_o_lora", l["w_o"])
             w_pr = l.get("w_pr_lora", l["w_pr"])
             nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv"], l["b_qkv"], x=xn, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
-                            vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s, x_packed=pa)
+                            vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s, x_packed=pa, **kva)
             nat.attn_decode(self.q, self.kc[i], self.vc[i], self.a, self.pad, pos, B, H, self._cap_s, out_packed=pa,
                             kv_rows=self._kv_rows, kv_step=step if self._kv_rows is not None else None,
                             skip_rows=self.finished if self._kv_rows is None and self.skip_finished else None,
-                            kv_share=self.kv_share if self._kv_rows is None else None)
+                            kv_share=self.kv_share if self._kv_rows is None else None, **kva)
             nxt = self.ln_f if last else self.layers[i + 1]["ln1"]
             nxt2 = self.final_norm if last else None
             # out-projection: split-K slabs; with a runtime adapter the GEMM also produces x A in extra columns and the
@@ -557,7 +710,7 @@ class GPTEngine:
             if fold:
                 hb = self.hb
                 nat.gemm_skinny(T, B, 3 * D, D, l["wf_qkv"], l["d_qkv"], x=hb, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
-                                vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s, x_packed=True, ln_c=l["c_qkv"])
+                                vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s, x_packed=True, ln_c=l["c_qkv"], **self._kvargs())
                 nat.gemm_skinny(T, B, D, D, l["w_o"], l["b_o"], x=self.a, epi=nat.EPI_RESID_F32, yf=h, y=hb, x_packed=pa,
                                 y_packed=True, rows_per_wg=r_o, wide_wg=self.fold_wide)
                 nat.gemm_skinny(T, B, 4 * D, D, l["wf_fc"], l["d_fc"], x=hb, epi=nat.EPI_GELU_STORE, y=self.f, x_packed=True,
@@ -567,7 +720,7 @@ class GPTEngine:
                 nbytes += 12 * D * D * es + B * D * es * (1 + 1 + 1 + 4) + B * es * (3 * D + 4 * D) + 2 * (2 * B * D * 4 + B * D * es)
             else:
                 nat.gemm_skinny(T, B, 3 * D, D, l["w_qkv"], l["b_qkv"], x=xn, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
-                                vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s, x_packed=pa)
+                                vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s, x_packed=pa, **self._kvargs())
                 nat.gemm_skinny(T, B, D, D, l["w_o"], None, x=self.a, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS, x_packed=pa)
                 nat.gemm_skinny(T, B, 4 * D, D, l["w_fc"], l["b_fc"], x=xn, epi=nat.EPI_GELU_STORE, y=self.f, x_packed=pa, y_packed=pa)
                 nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], None, x=self.f, epi=nat.EPI_SLAB_F32, yf=slab, ksplit=KS, x_packed=pa)
@@ -583,8 +736,12 @@ class GPTEngine:
         B = self._B
         if self._shared_prefix is not None:
             raise ValueError("decode(): prefill(beams=n) cached the prompt once per batch element; only decode_beam() can follow it")
-        if self._S + max_new + 1 > self._cap_s:
+        if self.kv is None and self._S + max_new + 1 > self._cap_s:
             raise ValueError("decode(): max_new exceeds the capacity reserved by prefill()")
+        if self.kv is not None:
+            for b in range(B):                                   # (no-op when prefill() was given the same max_new)
+                self.kv.cover(b, self._pad_host[b], self._S + max_new + 1)
+            self.kv.flush()
         if force_stop is None:
             self.force_stop[:B] = -1
         else:
@@ -634,6 +791,8 @@ class GPTEngine:
         M = int(off[-1])
         slot = np.concatenate([np.full(L, r) for L, r in zip(lens, rows)])
         posi = np.concatenate([pd + np.arange(L) for L, pd in zip(lens, pads)])
+        if self.kv is not None:                            # paged cache: (block, offset) of every staged position (the caller
+            slot, posi = self.kv.phys(slot, posi)          # has dealt the new rows their blocks already)
         meta = torch.from_numpy(np.concatenate([slot, posi, off, off[1:] - 1, np.asarray(rows), np.asarray(pads),
                                                 np.asarray(stops)]).astype(np.int64)).to(dev)     # one upload
         st = {"k": k, "n": n, "i_b": meta[:M], "i_p": meta[M:2 * M],
@@ -672,7 +831,7 @@ class GPTEngine:
         running rows' logits stay --, and the per-row state: left padding, stop step, own clock row_step0 = n - 1 (mel
         positions, history index and the repetition-penalty window count from the row's own first token)."""
         k, n, dev = st["k"], st["n"], self.device
-        self.kc[:, st["i_b"], :, st["i_p"]] = st["kst"]    # [M, L, H, 64] -> positions [pad, S+n-2] of the slots
+        self.kc[:, st["i_b"], :, st["i_p"]] = st["kst"]    # [M, L, H, 64] -> positions [pad, S+n-2] of the slots (rows | blocks)
         self.vc[:, st["i_b"], :, st["i_p"]] = st["vst"]
         tok_t = torch.zeros(k, dtype=torch.int32, device=dev)
         hist_t = torch.zeros(k, 8, dtype=torch.int32, device=dev)
@@ -711,7 +870,15 @@ class GPTEngine:
         B, S = self._B, self._S
         if self._shared_prefix is not None or self._kv_rows is not None:
             raise ValueError("decode_refill(): num_beams = 1 only")
-        limit = self._cap_s if positions is None else min(self._cap_s, int(positions))
+        kv = self.kv
+        if kv is not None:
+            # paged cache: the loop's position counter may grow for as long as the queue lasts -- a row only has to keep its own
+            # window (prompt + max_new + the steps up to the next poll) inside the block table's ring
+            limit = (1 << 30) if positions is None else int(positions)
+            if max_new + 2 * check_every + 2 > kv.window:
+                raise ValueError("decode_refill(): max_new does not fit the block table's window")
+        else:
+            limit = self._cap_s if positions is None else min(self._cap_s, int(positions))
         if S + max_new + check_every > limit:
             # the loop runs whole blocks of check_every steps before it looks at the flags again: the last rows can take
             # the loop check_every - 1 steps past max_new, and every step appends one K / V position for every slot
@@ -730,6 +897,9 @@ class GPTEngine:
         side = torch.cuda.Stream(device=dev) if staged else None
         pending = None                                      # (staged rows, slots, event)
         stop_id = self.stop_mel
+        pads = list(self._pad_host[:B])                      # left padding per slot (paged cache: where a row's window starts)
+        if kv is not None:
+            stats["blocks"], stats["peak_blocks"] = kv.blocks - 1, kv.used_blocks()
         self._sample(B, sp)
         n = 1
         while True:
@@ -756,9 +926,21 @@ class GPTEngine:
                     fed_out = True
                 if items and limit - (S + n_join + 1) < max_new + check_every:    # steps the loop could still take
                     leftover, items, fed_out = items, [], True
+                if items and kv is not None:
+                    # blocks for the new rows' windows: prompt + start token in front of the join position, then max_new tokens
+                    # and the steps up to the poll after the row's last one
+                    end = S + n_join - 1
+                    need = sum((end + max_new + 2 * check_every) // kv.bs - (end - int(p.shape[0]) - 1) // kv.bs + 1 for p, _ in items)
+                    if need > len(kv.free):
+                        leftover, items, fed_out = items, [], True          # (a pool sized by prefill(slots_window=...) never gets here)
             if items:
                 rows = free[: len(items)]
                 stops = [max_new - 1 if int(v) < 0 else min(int(v), max_new - 1) for _, v in items]
+                if kv is not None:
+                    end = S + n_join - 1
+                    for r, (p, _) in zip(rows, items):
+                        pads[r] = end - (int(p.shape[0]) + 1)
+                        kv.cover(r, pads[r], end + check_every + 1)
                 stats["refill_calls"] += 1
                 stats["rows_refilled"] += len(rows)
                 if not staged:
@@ -772,7 +954,13 @@ class GPTEngine:
                     fed.record(main)                        # the prefix embeddings are complete on the loop's stream
             if fed_out and pending is None and not items and all(o is None for o in owner):
                 break
-            # ---- C: check_every steps of the loop
+            # ---- C: check_every steps of the loop (paged cache: every live row's blocks reach past the last of them)
+            if kv is not None:
+                for r in range(B):
+                    if owner[r] is not None and kv.span[r] is not None:
+                        kv.cover(r, pads[r], S + n - 1 + check_every + 1)
+                kv.flush()
+                stats["peak_blocks"] = max(stats["peak_blocks"], kv.used_blocks())
             todo = check_every
             while todo > 0:
                 G = self.steps_per_graph
@@ -809,6 +997,8 @@ class GPTEngine:
                     hit = (row == stop_id).nonzero()
                     codes[owner[r]] = row[: int(hit[0]) + 1] if hit.numel() else row
                     owner[r] = None
+                    if kv is not None:
+                        kv.release(r)      # its blocks go back to the pool; the slot's later (formal) appends land in the scratch block
         return [codes[i] for i in range(next_id)], leftover
 
     # ------------------------------------------------------------------------------------------------ beam search
@@ -859,6 +1049,8 @@ class GPTEngine:
         if not 1 <= int(num_return_sequences) <= nb:
             raise ValueError("num_return_sequences has to be in [1, num_beams]")   # generate() raises the same
         R = self._B
+        if self.kv is not None:
+            raise ValueError("decode_beam(): beam search addresses whole contiguous cache rows: prefill(..., paged=False) or prefill(beams=n)")
         if self._shared_prefix is not None and self._shared_prefix[1] != nb:
             raise ValueError("decode_beam(): prefill(beams=...) was given another beam count")
         assert R % nb == 0, "prefill() must have been given B*num_beams rows"
@@ -957,7 +1149,7 @@ class GPTEngine:
         # everything the captured launches depend on besides the buffers: a knob toggled after a capture must not replay the
         # old variant (skip_finished: whether the attention is given the finished flags)
         key = (B, nsteps, self.skip_finished, self.decode_mode, self.lora, tuple(self.fold_rows), self.fold_wide, self.pa, self.KSPLIT,
-               self.share_kv_reads, tuple(sorted(sp.items())))
+               self.share_kv_reads, None if self.kv is None else self.kv.bs, tuple(sorted(sp.items())))
         g = self._graphs.get(key)
         if g is None:
             g = torch.cuda.CUDAGraph()

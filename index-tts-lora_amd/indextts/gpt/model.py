@@ -201,7 +201,8 @@ class UnifiedVoice:
             if self.engine.beam_kv == "table":   # prompt computed and cached once per batch element (row table)
                 self.engine.prefill(emb, pad, max_new, beams=num_beams, shared_rows=shared)
             else:
-                self.engine.prefill(emb.repeat_interleave(num_beams, dim=0), pad.repeat_interleave(num_beams), max_new, shared_rows=shared)
+                self.engine.prefill(emb.repeat_interleave(num_beams, dim=0), pad.repeat_interleave(num_beams), max_new, shared_rows=shared,
+                                    paged=False)
             return self.engine.decode_beam(max_new, sp, num_beams, num_return_sequences=nrs)
         if nrs > 1:
             # sampling: generate() expands every row to num_return_sequences copies before the first forward

@@ -384,7 +384,7 @@ class IndexTTS:
         nb = int(gen.get("num_beams", 1))
         if nb > 1:  # beam search / beam-sample: every row becomes num_beams rows (HF generate semantics)
             sp["length_penalty"] = float(gen.get("length_penalty", 0.0))
-            g.engine.prefill(emb.repeat_interleave(nb, dim=0), pad.repeat_interleave(nb), max_mel_tokens, shared_rows=shared)
+            g.engine.prefill(emb.repeat_interleave(nb, dim=0), pad.repeat_interleave(nb), max_mel_tokens, shared_rows=shared, paged=False)
             return g.engine.decode_beam(max_mel_tokens, sp, nb)
         g.engine.prefill(emb, pad, max_mel_tokens, shared_rows=shared)
         return g.engine.decode(max_mel_tokens, sp, force_stop=extra.pop("force_stop", None))
@@ -667,9 +667,17 @@ class IndexTTS:
         while queue:
             first, queue = queue[:slots], queue[slots:]
             emb, pad = prefixes(first)
-            # the loop runs whole blocks of check_every steps: the cache has to hold that many positions past max_mel_tokens
-            eng.prefill(emb, pad, max(max_mel_tokens + int(check_every) + 1, int(cache_positions) - emb.shape[1] - 2),
-                        shared_rows=int(conds.shape[1]) if conds.shape[0] == 1 else 0)
+            ce = int(check_every)
+            if eng.paged:
+                # paged cache: one loop serves the whole queue -- a slot's blocks go back to the pool when its row stops.  The pool
+                # holds `slots` windows of (longest prompt + start token + max_mel_tokens + the steps up to the second next poll)
+                eng.prefill(emb, pad, max_mel_tokens + ce + 1, shared_rows=int(conds.shape[1]) if conds.shape[0] == 1 else 0,
+                            slots_window=emb.shape[1] + 1 + max_mel_tokens + 2 * ce + 2)
+            else:
+                # contiguous strips: the loop runs whole blocks of check_every steps, the cache has to hold that many positions
+                # past max_mel_tokens; cache positions only grow, so a loop ends when `cache_positions` are used up
+                eng.prefill(emb, pad, max(max_mel_tokens + ce + 1, int(cache_positions) - emb.shape[1] - 2),
+                            shared_rows=int(conds.shape[1]) if conds.shape[0] == 1 else 0, paged=False)
             entered = list(first)
 
             def feed(k):
@@ -683,7 +691,8 @@ class IndexTTS:
                 return [(e[j, p[j]:], stops[i]) for j, i in enumerate(take)]
 
             codes, leftover = eng.decode_refill(max_mel_tokens, sp, feed, force_stop=[stops[i] for i in first],
-                                                positions=max(int(cache_positions), eng._S + max_mel_tokens + int(check_every) + 1),
+                                                positions=None if eng.kv is not None else
+                                                max(int(cache_positions), eng._S + max_mel_tokens + int(check_every) + 1),
                                                 check_every=int(check_every), staged=bool(staged))
             if leftover:                                               # fed but not placed: back to the head of the queue
                 back = entered[len(entered) - len(leftover):]
@@ -755,7 +764,7 @@ class IndexTTS:
             if g.engine.beam_kv == "table":    # the prompt is computed and cached once per batch element (row table)
                 g.engine.prefill(emb, pad, max_mel_tokens, beams=nb, shared_rows=shared)
             else:                              # generate() expands every row to num_beams copies before the first forward
-                g.engine.prefill(emb.repeat_interleave(nb, dim=0), pad.repeat_interleave(nb), max_mel_tokens, shared_rows=shared)
+                g.engine.prefill(emb.repeat_interleave(nb, dim=0), pad.repeat_interleave(nb), max_mel_tokens, shared_rows=shared, paged=False)
             self._mark(phase_events, "prefilled")
             codes = g.engine.decode_beam(max_mel_tokens, sp, nb)
         else:

@@ -324,8 +324,8 @@ def test_beam_decode_matches_host_driven_oracle(gpt_small_fp32, do_sample):
     sp = dict(do_sample=do_sample, top_p=0.8 if do_sample else 1.0, top_k=30 if do_sample else 0, temperature=1.0,
               repetition_penalty=10.0, seed=5, length_penalty=0.0)
     emb_r, pad_r = emb.repeat_interleave(nb, 0), pad.repeat_interleave(nb)
-    # host-driven oracle loop
-    eng.prefill(emb_r, pad_r, max_new)
+    # host-driven oracle loop (beam search works on whole contiguous cache rows: paged=False)
+    eng.prefill(emb_r, pad_r, max_new, paged=False)
     ref = beam_ref.BeamSearch(B, nb, sp, [1] * int(emb.shape[1]) + [8192], eos=8193, length_penalty=0.0, seed=5)
     n = 0
     while True:
@@ -346,7 +346,7 @@ def test_beam_decode_matches_host_driven_oracle(gpt_small_fp32, do_sample):
     for kv in ("table", "copy"):
         for use_graph in (False, True):
             eng.beam_kv = kv
-            eng.prefill(emb_r, pad_r, max_new)
+            eng.prefill(emb_r, pad_r, max_new, paged=False)
             got = eng.decode_beam(max_new, sp, nb, use_graph=use_graph, check_every=4).cpu().numpy()
             w = min(got.shape[1], want.shape[1])
             assert np.array_equal(got[:, :w], want[:, :w]), (kv, use_graph, got, want)
@@ -361,6 +361,10 @@ def test_beam_decode_matches_host_driven_oracle(gpt_small_fp32, do_sample):
     with pytest.raises(ValueError):
         eng.prefill(emb, pad, max_new, beams=nb)
         eng.decode_beam(max_new, sp, nb + 1)
+    if eng.paged:
+        with pytest.raises(ValueError):          # a paged cache cannot be beam-searched: refused, not silently wrong
+            eng.prefill(emb_r, pad_r, max_new)
+            eng.decode_beam(max_new, sp, nb)
     eng.beam_kv = "copy"
     with pytest.raises(ValueError):
         eng.prefill(emb, pad, max_new, beams=nb)      # sharing the prompt needs the table
@@ -479,7 +483,10 @@ def test_prefill_computes_the_shared_conditioning_rows_once(dtype, lens):
     for shared in (0, 32):
         eng._cap_b = eng._cap_s = 0                       # fresh (zeroed) caches for both runs
         logits = eng.prefill(emb, pad, 12, shared_rows=shared).clone()
-        kc, vc = eng.kc[:, :B, :, :S].clone(), eng.vc[:, :B, :, :S].clone()
+        kc, vc = eng.dense_kv(B, S)                       # positions [0, S) of every row, through the block table if paged
+        for b_, p_ in enumerate(pad.tolist()):            # (positions in front of a row's window map to the scratch block)
+            kc[:, b_, :, :p_] = 0
+            vc[:, b_, :, :p_] = 0
         codes = eng.decode(12, sp)
         got[shared] = (logits, kc, vc, codes.clone())
     assert eng.share_prefix and eng.share_kv_reads
@@ -568,6 +575,111 @@ def test_decode_refill_gives_every_row_the_codes_it_gets_alone(gpt_small_fp32):
     assert len(codes) + len(leftover) + len(queue) == 9 and len(leftover) > 0
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_paged_kv_cache_gives_the_bits_of_the_contiguous_cache(dtype):
+    """The paged KV cache (block pool + per-row block table, the default for num_beams = 1) against contiguous cache rows on
+    the same engine: prefill logits, every decode step's logits and codes, the cache contents and the latent pass that reads
+    the prompt's keys / values back out of the cache are IDENTICAL BITS -- paging changes where a position lives, nothing
+    else.  Mixed text lengths (different left paddings), shared conditioning rows, graph replay."""
+    m = make_gpt(2, dtype)
+    eng = m.engine
+    rng = np.random.default_rng(77)
+    cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
+    conds = m.get_conditioning(cond_mel, None)
+    lens = [17, 3, 9, 12, 1]
+    text = torch.full((len(lens), max(lens)), m.stop_text_token, dtype=torch.int32)
+    for i, n in enumerate(lens):
+        text[i, :n] = torch.from_numpy(rng.integers(2, 12000, size=n)).to(torch.int32)
+    _, emb, mask = m.prepare_gpt_inputs(conds, text.to(DEV))
+    pad = (mask == 0).sum(1).to(torch.int32)
+    B, S = emb.shape[0], emb.shape[1] + 1
+    sp = dict(do_sample=True, top_p=0.8, top_k=30, temperature=1.0, repetition_penalty=10.0, seed=21)
+    runs = {}
+    for paged in (False, True):
+        eng.paged = paged
+        eng._cap_b = eng._cap_s = 0
+        eng._kv_pool = None
+        eng._graphs.clear()
+        lg0 = eng.prefill(emb, pad, 40, shared_rows=32).clone()
+        assert (eng.kv is not None) == paged
+        codes, logits = eng.decode(40, sp, return_logits=True)
+        eng.prefill(emb, pad, 40, shared_rows=32)
+        codes_g = eng.decode(40, sp, use_graph=True)
+        kc, vc = eng.dense_kv(B, S + 38)
+        for b_, p_ in enumerate(pad.tolist()):
+            kc[:, b_, :, :p_] = 0
+            vc[:, b_, :, :p_] = 0
+        mel = torch.cat([torch.cat([eng.mel_emb[eng.start_mel][None], eng.mel_emb[codes[b, :5]], eng.mel_emb[eng.stop_mel][None]]) +
+                         eng.mel_pos[:7] for b in range(B)])
+        lat = eng.latent_mel_rows(mel, [7] * B)
+        runs[paged] = (lg0, codes, logits, codes_g, kc, vc, lat)
+        if paged:
+            assert eng.kv.bs == 16 and eng.kv.used_blocks() == sum((S + 40) // 16 - int(p) // 16 + 1 for p in pad.tolist())
+    eng.paged = True
+    for a, b in zip(runs[False], runs[True]):
+        assert torch.equal(a, b)
+    assert torch.equal(runs[True][1], runs[True][3])          # graph replay == eager
+
+
+def test_paged_kv_long_queue_through_few_slots_in_one_loop():
+    """Continuous batching on the paged cache: 512 utterances through 32 decode slots in ONE loop (the contiguous cache had to
+    drain and restart whenever its position budget was used up) -- the blocks of a row that has stopped go back to the pool and
+    serve the utterance that takes its slot, the pool never holds more than the slots' windows, and the position counter runs
+    past the block table's ring (64 entries x 16 positions) without a row ever seeing another row's keys: every utterance of a
+    sample gets the greedy codes it gets decoded alone."""
+    m = make_gpt(2, torch.float32)
+    eng = m.engine
+    rng = np.random.default_rng(123)
+    cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
+    conds = m.get_conditioning(cond_mel, None)
+    for N, slots, max_new, hi in ((512, 32, 24, 22), (260, 4, 40, 38)):
+        lens = sorted((int(v) for v in rng.integers(2, 15, size=N)), reverse=True)
+        texts = [torch.from_numpy(rng.integers(2, 12000, size=n)).to(torch.int32) for n in lens]
+        stops = [int(v) for v in rng.integers(3, hi, size=N)]
+        sp = dict(do_sample=False, top_p=1.0, top_k=0, temperature=1.0, repetition_penalty=10.0, seed=0)
+
+        def prefix(ids):
+            L = max(lens[i] for i in ids)
+            bh = torch.full((len(ids), L), m.stop_text_token, dtype=torch.int32)
+            for j, i in enumerate(ids):
+                bh[j, : lens[i]] = texts[i]
+            _, emb, mask = m.prepare_gpt_inputs(conds, bh.to(DEV))
+            return emb, (mask == 0).sum(1).to(torch.int32)
+
+        queue = list(range(slots, N))
+        emb, pad = prefix(list(range(slots)))
+        ce = 4
+        eng.prefill(emb, pad, max_new + ce + 1, slots_window=emb.shape[1] + 1 + max_new + 2 * ce + 2)
+        assert eng.kv is not None
+        pool = eng.kv.blocks
+
+        def feed(k):
+            take = [queue.pop(0) for _ in range(min(k, len(queue)))]
+            if not take:
+                return []
+            e, p = prefix(take)
+            return [(e[j, int(p[j]):], stops[i]) for j, i in enumerate(take)]
+
+        codes, leftover = eng.decode_refill(max_new, sp, feed, force_stop=stops[:slots], check_every=ce, staged=True)
+        st = eng.refill_stats
+        assert not leftover and len(codes) == N and eng.kv.blocks == pool          # one loop, the pool never grew
+        assert st["rows_refilled"] == N - slots and st["peak_blocks"] <= st["blocks"]
+        assert all(int(c[-1]) == m.stop_mel_token and c.numel() == stops[i] + 1 for i, c in enumerate(codes))
+        if slots == 4:
+            assert eng._S + st["steps"] > 64 * eng.kv.bs, "the position counter must have wrapped the block table's ring"
+        # every row stopped and left: all blocks are back
+        assert eng.kv.used_blocks() == 0
+        for i in list(range(0, N, max(1, N // 10)))[:10]:
+            c, lg = m.inference_speech(cond_mel, texts[i][None].to(DEV), do_sample=False, num_beams=1, repetition_penalty=10.0,
+                                       max_generate_length=max_new, force_stop=[stops[i]], return_logits=True)
+            want, got = c[0].cpu(), codes[i].cpu()
+            for s_ in range(got.numel()):
+                if int(got[s_]) != int(want[s_]):
+                    top2 = torch.topk(lg[s_, 0].cpu(), 2).values
+                    assert (top2[0] - top2[1]).item() < 1e-3, (N, i, s_, got, want)
+                    break
+
+
 def test_infer_queue_equals_utterances_synthesised_one_by_one():
     """IndexTTS.infer_queue (continuous batching through 3 slots) returns, in input order, the waveforms infer_batch gives
     for each utterance alone; a tiny cache budget (several loops) changes nothing."""
@@ -618,7 +730,7 @@ def test_beam_decode_full_size_bf16_graph_equals_eager():
     sp = dict(do_sample=True, top_p=0.8, top_k=30, temperature=1.0, repetition_penalty=10.0, seed=11, length_penalty=0.0)
     outs = []
     for use_graph in (False, True):
-        eng.prefill(emb.repeat_interleave(3, 0), pad.repeat_interleave(3), 14)
+        eng.prefill(emb.repeat_interleave(3, 0), pad.repeat_interleave(3), 14, paged=False)
         outs.append(eng.decode_beam(14, sp, 3, use_graph=use_graph, check_every=4).cpu())
     assert outs[0].shape[0] == 2 and torch.equal(outs[0], outs[1])
 
@@ -636,12 +748,12 @@ def test_beam_graphs_follow_their_buffers(gpt_small_fp32):
     for B in (2, 1):
         _, emb, mask = m.prepare_gpt_inputs(conds, texts[B])
         pad = (mask == 0).sum(1).to(torch.int32)
-        eng.prefill(emb.repeat_interleave(3, 0), pad.repeat_interleave(3), 12)
+        eng.prefill(emb.repeat_interleave(3, 0), pad.repeat_interleave(3), 12, paged=False)
         want[B] = eng.decode_beam(12, sp, 3, use_graph=False).cpu()
     for B in (2, 1, 2, 1):
         _, emb, mask = m.prepare_gpt_inputs(conds, texts[B])
         pad = (mask == 0).sum(1).to(torch.int32)
-        eng.prefill(emb.repeat_interleave(3, 0), pad.repeat_interleave(3), 12)
+        eng.prefill(emb.repeat_interleave(3, 0), pad.repeat_interleave(3), 12, paged=False)
         got = eng.decode_beam(12, sp, 3, use_graph=True, check_every=4).cpu()
         assert torch.equal(got, want[B]), B
 

@@ -832,6 +832,95 @@ def test_embed_step_packed_copy_bump_and_position_clamp(nat):
     assert word.item() == 42 and step.item() == 5
 
 
+@pytest.mark.parametrize("dtype,bs", [(torch.bfloat16, 16), (torch.bfloat16, 64), (torch.float32, 32), (torch.float16, 16)])
+def test_paged_kv_kernels_equal_the_contiguous_cache(nat, dtype, bs):
+    """The paged cache through its three kernel families against contiguous cache rows holding the same keys / values:
+    QKV epilogue (append at *pos through the block table), decode attention (block ids out of a register, also for the shared
+    first keys read from row 0), packed prefill (prompt rows in) and the cached-prefix read of the latent pass -- identical
+    bits.  The position window sits ACROSS the table's ring boundary (positions around 64 * bs) and the blocks are dealt in a
+    shuffled order; every unmapped table entry points at the scratch block 0."""
+    torch.manual_seed(5)
+    B, H, D = 5, 4, 256
+    TAB = 64
+    base = TAB * bs - 37                                  # windows straddle the ring's wrap-around
+    pads = [base + v for v in (0, 9, 21, 3, 30)]
+    ctx_end = base + 75                                   # current write position
+    smax = ctx_end + 8
+    kc_r = torch.zeros(B, H, smax, 64, dtype=dtype, device=DEV)
+    vc_r = torch.zeros_like(kc_r)
+    nblk = 1 + B * ((ctx_end + 8 - base) // bs + 2)
+    pool_k = torch.zeros(nblk, H, bs, 64, dtype=dtype, device=DEV)
+    pool_v = torch.zeros_like(pool_k)
+    tab = np.zeros((B, TAB), dtype=np.int32)
+    free = list(np.random.default_rng(3).permutation(np.arange(1, nblk)))
+    for b in range(B):
+        for bi in range(pads[b] // bs, (ctx_end + 7) // bs + 1):
+            tab[b, bi % TAB] = free.pop()
+    tab_d = torch.from_numpy(tab).to(DEV)
+
+    def to_pool(rows_k, rows_v):
+        for b in range(B):
+            for j in range(pads[b], ctx_end + 1):
+                blk, off = int(tab[b, (j // bs) % TAB]), j % bs
+                pool_k[blk, :, off] = rows_k[b, :, j]
+                pool_v[blk, :, off] = rows_v[b, :, j]
+
+    # --- packed prefill writes the prompt rows (and the prefix read gets them back)
+    lens = [ctx_end - p for p in pads]                    # rows [pad_b, ctx_end)
+    M = sum(lens)
+    qkv = (torch.randn(M, 3 * D, device=DEV) * 0.5).to(dtype)
+    row_off = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device=DEV)
+    shift = torch.tensor(pads, dtype=torch.int32, device=DEV)
+    out_r, out_p = torch.empty(M, D, dtype=dtype, device=DEV), torch.empty(M, D, dtype=dtype, device=DEV)
+    nat.attn_prefill_packed(qkv, out_r, kc_r, vc_r, row_off, shift, B, max(lens), H, smax)
+    nat.attn_prefill_packed(qkv, out_p, pool_k, pool_v, row_off, shift, B, max(lens), H, 0, kv_tab=tab_d, kv_bs=bs)
+    assert torch.equal(out_r, out_p)
+    ref_k, ref_v = pool_k.clone(), pool_v.clone()
+    pool_k.zero_()
+    pool_v.zero_()
+    to_pool(kc_r, vc_r)
+    assert torch.equal(pool_k, ref_k) and torch.equal(pool_v, ref_v) and pool_k[0].abs().max().item() == 0
+    mq = [6, 3, 9, 1, 4]                                  # query rows behind the cached prefix
+    Mq = sum(mq)
+    qkv2 = (torch.randn(Mq, 3 * D, device=DEV) * 0.5).to(dtype)
+    ro2 = torch.tensor(np.concatenate([[0], np.cumsum(mq)]), dtype=torch.int32, device=DEV)
+    pre_len = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    pre_row = torch.arange(B, dtype=torch.int32, device=DEV)
+    o_r, o_p = torch.empty(Mq, D, dtype=dtype, device=DEV), torch.empty(Mq, D, dtype=dtype, device=DEV)
+    nat.attn_prefill_prefix(qkv2, o_r, kc_r, vc_r, ro2, pre_len, pre_row, shift, B, max(mq), H, smax)
+    nat.attn_prefill_prefix(qkv2, o_p, pool_k, pool_v, ro2, pre_len, pre_row, shift, B, max(mq), H, 0, kv_tab=tab_d, kv_bs=bs)
+    assert torch.equal(o_r, o_p)
+    # --- QKV epilogue appends at *pos
+    x = (torch.randn(B, D, device=DEV) * 0.5).to(dtype)
+    w = (torch.randn(D, 3 * D, device=DEV) * 0.05).to(dtype)
+    wp = nat.pack_weight(w)
+    bias = torch.randn(3 * D, device=DEV)
+    posd = torch.tensor([ctx_end], dtype=torch.int32, device=DEV)
+    q_r, q_p = torch.empty(B, D, dtype=dtype, device=DEV), torch.empty(B, D, dtype=dtype, device=DEV)
+    nat.gemm_skinny(dtype, B, 3 * D, D, wp, bias, x=x, epi=nat.EPI_QKV_CACHE, y=q_r, kcache=kc_r, vcache=vc_r, pos=posd, heads=H, smax=smax)
+    nat.gemm_skinny(dtype, B, 3 * D, D, wp, bias, x=x, epi=nat.EPI_QKV_CACHE, y=q_p, kcache=pool_k, vcache=pool_v, pos=posd, heads=H,
+                    smax=0, kv_tab=tab_d, kv_bs=bs)
+    assert torch.equal(q_r, q_p)
+    ref_k, ref_v = pool_k.clone(), pool_v.clone()
+    to_pool(kc_r, vc_r)
+    assert torch.equal(pool_k, ref_k) and torch.equal(pool_v, ref_v)
+    # --- decode attention over [pad_b, *pos], with and without the shared first keys, and with skipped rows
+    padd = torch.tensor(pads, dtype=torch.int32, device=DEV)
+    skip = torch.tensor([0, 0, 1, 0, 0], dtype=torch.int32, device=DEV)
+    C = 11
+    for b in range(1, B):                                 # make the promise true: the first C keys of every row are row 0's
+        kc_r[b, :, pads[b]:pads[b] + C] = kc_r[0, :, pads[0]:pads[0] + C]
+        vc_r[b, :, pads[b]:pads[b] + C] = vc_r[0, :, pads[0]:pads[0] + C]
+    to_pool(kc_r, vc_r)
+    for share in (None, torch.tensor([(pads[0] << 8) | C], dtype=torch.int32, device=DEV)):
+        a_r = torch.full((B, D), 7.0, dtype=dtype, device=DEV)
+        a_p = a_r.clone()
+        nat.attn_decode(q_r, kc_r, vc_r, a_r, padd, posd, B, H, smax, skip_rows=skip, kv_share=share)
+        nat.attn_decode(q_r, pool_k, pool_v, a_p, padd, posd, B, H, 0, skip_rows=skip, kv_share=share, kv_tab=tab_d, kv_bs=bs)
+        assert torch.equal(a_r, a_p)
+        assert (a_p[2] == 7.0).all() and not (a_p[1] == 7.0).any()
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_attn_decode_row_table_equals_permuted_cache(nat, dtype):
     """Beam search: attention through the KV row table (itts_beam_kv_rows + kv_rows argument) equals attention over a cache
