@@ -2,6 +2,11 @@
 #include "common.h"
 #include "ln_math.h"
 #include "aa_tile.h"
+#include <mutex>
+
+#ifndef ITTS_AA_F16_MFMA
+#define ITTS_AA_F16_MFMA 1   // build-time A/B: fp16 activation with both FIRs on the matrix cores (0: the VALU form for every type)
+#endif
 
 namespace itts {
 
@@ -59,6 +64,210 @@ __global__ __launch_bounds__(256) void aa_snake_btc_kernel(const T* __restrict__
       *reinterpret_cast<t4*>(yb + (int64_t)t * C + c4 * 4) = o;
     }
   });
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// The same activation with BOTH FIRs on the matrix cores (fp16 storage; round 4).  The VALU form above spends ~54
+// instructions per output element, two thirds of them on the two 12-tap filters; as banded-matrix products
+//   u[c][m]  = sum_k  x[c][k] Wup[k][m]          (16 channels x 16 u rows x 32 x rows per MFMA, 6 taps per u row)
+//   y[c][t]  = sum_k  s[c][k] Wdn[k][t]          (16 channels x 16 outputs x 64 s rows: two MFMAs, 12 taps per output)
+// the filters cost 2 + 4 v_mfma_f32_16x16x32_f16 per 16 x 16 block (each tap matrix is split into fp16 hi + lo parts, so the
+// TAPS stay exact to ~2^-22; the products of fp16 values accumulate in fp32) and the VALU keeps only the snake term.  One
+// rounding is added: s goes through LDS as fp16 (2^-11 relative) -- the storage type's own resolution.
+// Both LDS images are ROW-MAJOR [time][channel] (8-byte stores on the way in), and the MFMA contraction runs over TIME: the
+// signal fragments (A operand: 16 channels x 8 consecutive rows per lane group) come out of LDS through the hardware
+// transpose read ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group, delivered column-major); the banded tap matrices
+// are constant B fragments built once per workgroup.  The accumulator holds 4 consecutive CHANNELS of one row per lane: the
+// snake output goes back to LDS, and the result to the channels-last tensor, as 8-byte vectors.
+// Follows alias_free_torch/act.py:10-28 like aa_tile.h; replaces anti_alias_activation_cuda.cu:44-181 for 16-bit tensors.
+// -------------------------------------------------------------------------------------------------------------------
+template <int NCB>   // 16-channel blocks per workgroup (CS = 16 * NCB channels)
+struct AaMfma {
+  static constexpr int TT = 128;                 // output rows per tile
+  static constexpr int CS = 16 * NCB;
+  static constexpr int XR = TT + 32;             // X image rows: x rows t0-12 .. t0+TT+19 (8-aligned 32-row windows of the u blocks)
+  static constexpr int NUB = (2 * TT + 16) / 16; // u row blocks: u rows 2*t0-8 .. 2*t0+2*TT+7
+  static constexpr int SR = 2 * TT + 16 + 16;    // S image rows (+16: the last y block's 64-row window runs past the u rows; zero taps there)
+  static constexpr int RS = CS + 8;              // row stride of both images (elements)
+  static constexpr int NYB = TT / 16;            // y row blocks
+  static constexpr size_t LDS = (size_t)(XR + SR) * RS * 2;
+};
+
+typedef short aa_v4s __attribute__((__vector_size__(4 * sizeof(short))));
+// fragment of a [rows][RS] fp16 image for the MFMA A operand "16 channels x 32 rows": lane (g, r) gets rows row0 + 8g .. +7 of
+// channel col0 + r.  Two transposed reads; lane 4q+p of a 16-lane group addresses row q, columns 4p .. 4p+3 of the block.
+template <int RS>
+__device__ __forceinline__ f16x8 aa_tr_frag(const f16_t* img, int row0, int col0, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+  const f16_t* a = img + (row0 + 8 * g + q) * RS + col0 + 4 * pq;
+  typedef __attribute__((address_space(3))) aa_v4s* lptr;
+  const aa_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a));
+  const aa_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a + 4 * RS));
+  typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
+  const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(f16x8, both);
+}
+
+template <int NCB>
+__global__ __launch_bounds__(256) void aa_snake_mfma_kernel(const f16_t* __restrict__ x, f16_t* __restrict__ y,
+                                                             const float* __restrict__ alpha_log,
+                                                             const float* __restrict__ beta_log, Fir24 f, int T_full, int C,
+                                                             const int32_t* __restrict__ valid_rows, int tiles_per_wg) {
+  typedef AaMfma<NCB> G;
+  constexpr int TT = G::TT, CS = G::CS, XR = G::XR, NUB = G::NUB, RS = G::RS, NYB = G::NYB;
+  typedef f16_t h4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char aa_lds[];
+  f16_t* Xi = reinterpret_cast<f16_t*>(aa_lds);          // [XR][RS]
+  f16_t* Si = Xi + XR * RS;                              // [SR][RS]
+  __shared__ float taps[24];
+  const int c0 = blockIdx.y * CS;
+  const int b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  const int T_len = valid_rows != nullptr ? min(max(valid_rows[b], 0), T_full) : T_full;
+  if ((int)blockIdx.x * tiles_per_wg * TT >= T_len) return;
+  const f16_t* xb = x + (int64_t)b * T_full * C;
+  f16_t* yb = y + (int64_t)b * T_full * C;
+  if (tid < 12) taps[tid] = 2.0f * f.up[tid];      // (the upsampler's gain of 2 rides on its taps)
+  else if (tid < 24) taps[tid] = f.down[tid - 12];
+  __syncthreads();
+
+  // ---- constant B fragments (lane (g, r): column r, k = 8g + e).
+  // Wup, columns = u rows m0 + r, k = x rows k0 + kk with k0 = q0 - 8, q0 = m0 / 2:
+  //   u[2q] = 2 sum_{d=-3..2} x[q+d] up[5-2d],  u[2q+1] = 2 sum_{d=-2..3} x[q+d] up[6-2d]   (aa_tile.h)  ->  d = kk - 8 - (r >> 1)
+  // Wdn, columns = outputs t0' + r, k = s rows ks0 + kk with ks0 = 2 t0' - 8:
+  //   y[t] = sum_j down[j] s[2t + j - 5]  ->  j = kk - 2 r - 3
+  f16x8 wu_hi, wu_lo, wd_hi[2], wd_lo[2];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int kk = 8 * g + e;
+    const int d = kk - 8 - (r >> 1);
+    const int ju = (r & 1) ? 6 - 2 * d : 5 - 2 * d;        // tap index: valid for d in [-2, 3] (odd rows) / [-3, 2] (even rows)
+    const float w = (ju >= 0 && ju < 12) ? taps[min(max(ju, 0), 11)] : 0.f;
+    const f16_t hi = (f16_t)w;
+    wu_hi[e] = hi;
+    wu_lo[e] = (f16_t)(w - (float)hi);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const int j = 32 * st + kk - 2 * r - 3;
+      const float wd = (j >= 0 && j < 12) ? taps[12 + min(max(j, 0), 11)] : 0.f;
+      const f16_t dh = (f16_t)wd;
+      wd_hi[st][e] = dh;
+      wd_lo[st][e] = (f16_t)(wd - (float)dh);
+    }
+  }
+  // snake parameters of this lane's four channels in each channel block (channels c0 + 16 cb + 4g .. +3)
+  f32x4 ca[NCB], cbv[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ch = min(c0 + 16 * cb + 4 * g + e, C - 1);
+      ca[cb][e] = __expf(alpha_log[ch]) * 0.15915494309189535f;    // e^alpha / (2 pi): v_sin_f32 takes revolutions
+      cbv[cb][e] = __frcp_rn(__expf(beta_log[ch]) + 1e-9f);
+    }
+  // a workgroup walks tiles_per_wg consecutive tiles of its (batch element, channel slice): the fragments above are built once
+  for (int it = 0; it < tiles_per_wg; ++it) {
+  const int t0 = ((int)blockIdx.x * tiles_per_wg + it) * TT;
+  if (t0 >= T_len) break;
+  if (it > 0) __syncthreads();     // the previous tile's reads of both images are done
+
+  // ---- phase 1: x rows t0-12 .. t0+XR-13 -> X image.  Row indices are clamped to the sequence (the reference's replicate
+  // padding of x); channels past C (a 24-channel tensor in a 32-channel slice) read as zeros.  All loads first.  A thread keeps
+  // its channel quad and walks rows RPP apart (the kernel is bound by instruction issue: no division per load).
+  {
+    constexpr int C4 = CS / 4;
+    constexpr int RPP = 256 / C4;                 // rows per pass of the workgroup (RPP * C4 threads take part)
+    constexpr int NP = (XR + RPP - 1) / RPP;
+    const int pr = tid / C4, pc4 = tid - pr * C4;
+    const bool act = pr < RPP && c0 + pc4 * 4 < C;
+    const f16_t* xc = xb + c0 + pc4 * 4;
+    h4 v[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int row = min(max(t0 - 12 + pr + q * RPP, 0), T_len - 1);
+      v[q] = act ? *reinterpret_cast<const h4*>(xc + (int64_t)row * C) : h4{0, 0, 0, 0};
+    }
+    // the S rows past the u rows are read by the last y block's window (against zero taps): they must hold numbers
+    if (pr < 16) *reinterpret_cast<h4*>(&Si[(2 * TT + 16 + pr) * RS + pc4 * 4]) = h4{0, 0, 0, 0};
+    f16_t* xw = &Xi[pr * RS + pc4 * 4];
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+      if (pr < RPP && pr + q * RPP < XR) *reinterpret_cast<h4*>(xw + q * RPP * RS) = v[q];
+  }
+  __syncthreads();
+  // ---- phase 2: u blocks -> snake -> S image.  Row block ub: u rows 2*t0 - 8 + 16 ub .. +15; its x window starts at image row
+  // 8 ub (x row t0 - 12 + 8 ub = q0 - 8).  A wave takes every fourth row block, all channel blocks of it at once (independent
+  // chains: the transposed reads, the MFMAs and the transcendental ops of different blocks overlap).
+  for (int ub = wave; ub < NUB; ub += 4) {
+    f16x8 xf[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) xf[cb] = aa_tr_frag<RS>(Xi, 8 * ub, 16 * cb, lane);
+    f32x4 acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[cb], wu_hi, acc[cb], 0, 0, 0);
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[cb], wu_lo, acc[cb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      h4 sv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float u = acc[cb][e];
+        const float sn = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(u * ca[cb][e]));   // sin(2 pi frac(.)): the hardware's input range
+        sv[e] = (f16_t)(u + cbv[cb][e] * sn * sn);
+      }
+      // lane (g, r): channels 16 cb + 4g .. +3 of u row r of the block
+      *reinterpret_cast<h4*>(&Si[(16 * ub + r) * RS + 16 * cb + 4 * g]) = sv;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2b: replicate padding of the UPSAMPLED signal at the sequence ends (tile-uniform conditions); image row of m
+  // is m - (2 t0 - 8)
+  const int m_base = 2 * t0 - 8;
+  if (m_base < 0) {
+    for (int idx = tid; idx < (-m_base) * CS; idx += 256) {
+      const int mi = idx / CS, c = idx - mi * CS;
+      Si[mi * RS + c] = Si[(-m_base) * RS + c];
+    }
+    __syncthreads();
+  }
+  if (m_base + 2 * TT + 16 > 2 * T_len) {
+    const int last = 2 * T_len - 1 - m_base;  // image row of m = 2T-1 (>= 8: the tile starts inside the sequence)
+    const int n = 2 * TT + 16 - 1 - last;
+    for (int idx = tid; idx < n * CS; idx += 256) {
+      const int k = idx / CS, c = idx - k * CS;
+      Si[(last + 1 + k) * RS + c] = Si[last * RS + c];
+    }
+    __syncthreads();
+  }
+  // ---- phase 3: y blocks.  Row block yb: outputs t0 + 16 yb .. +15; its s window starts at image row 32 yb.
+  for (int yb_ = wave; yb_ < NYB; yb_ += 4) {
+    f16x8 s0[NCB], s1[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      s0[cb] = aa_tr_frag<RS>(Si, 32 * yb_, 16 * cb, lane);
+      s1[cb] = aa_tr_frag<RS>(Si, 32 * yb_ + 32, 16 * cb, lane);
+    }
+    const int t = t0 + 16 * yb_ + r;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(s0[cb], wd_hi[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(s0[cb], wd_lo[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(s1[cb], wd_hi[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(s1[cb], wd_lo[1], acc, 0, 0, 0);
+      // lane (g, r): channels 16 cb + 4g .. +3 of output row t0 + 16 yb + r
+      const int ch = c0 + 16 * cb + 4 * g;
+      if (t < T_len && ch < C) {
+        h4 o = {(f16_t)acc[0], (f16_t)acc[1], (f16_t)acc[2], (f16_t)acc[3]};
+        *reinterpret_cast<h4*>(yb + (int64_t)t * C + ch) = o;
+      }
+    }
+  }
+  }   // tiles of this workgroup
 }
 
 // Reference-op layout [B][C][T] (drop-in for anti_alias_activation_cuda.forward): one thread per output sample.
@@ -448,6 +657,13 @@ __global__ __launch_bounds__(256) void tanh_pcm_kernel(const T* __restrict__ x, 
 
 using namespace itts;
 
+// consecutive tiles one workgroup of the MFMA activation walks: enough workgroups to fill the chip several times over (768
+// resident at 3 per CU), as few fragment set-ups as that allows
+static int aa_tiles_per_wg(int64_t tiles) {
+  int64_t t = tiles / 3072;
+  return (int)(t < 1 ? 1 : t > 8 ? 8 : t);
+}
+
 extern "C" int itts_aa_snake_fwd(const void* x, void* y, const float* alpha_log, const float* beta_log,
                                  const float* up_filter12, const float* down_filter12, int B, int T, int C, int dtype,
                                  int layout, const int32_t* valid_rows, void* stream) {
@@ -485,6 +701,32 @@ extern "C" int itts_aa_snake_fwd(const void* x, void* y, const float* alpha_log,
         ITTS_AA_BY_CS(bf16_t);
         break;
       case ITTS_F16:
+        if (ITTS_AA_F16_MFMA && C <= 96 && (int64_t)B * T >= 32768) {
+          // Both FIRs on the matrix cores: 48-channel slices where the channel count allows, one 32-channel slice for C = 24.
+          // Measured (batch 32, MI355X, us per launch, MFMA form | VALU form): C = 96: 163 | 207, C = 48: 151 | 193, C = 24: 166 |
+          // 191; C = 192: 97 | 96, C = 384: 56 | 46, C = 768: 37 | 27 (few rows per batch element: the per-workgroup set-up of
+          // the tap fragments is not amortised) -- hence the last three stages only.
+          if (C % 48 == 0) {
+            static std::once_flag once3;
+            std::call_once(once3, [] {
+              (void)hipFuncSetAttribute((const void*)aa_snake_mfma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AaMfma<3>::LDS);
+            });
+            const int nt = (T + AaMfma<3>::TT - 1) / AaMfma<3>::TT;
+            const int tpw = aa_tiles_per_wg((int64_t)nt * (C / 48) * B);
+            dim3 g3((nt + tpw - 1) / tpw, C / 48, B);
+            hipLaunchKernelGGL(aa_snake_mfma_kernel<3>, g3, block, AaMfma<3>::LDS, s, (const f16_t*)x, (f16_t*)y, alpha_log, beta_log, f, T, C, valid_rows, tpw);
+          } else {
+            static std::once_flag once2;
+            std::call_once(once2, [] {
+              (void)hipFuncSetAttribute((const void*)aa_snake_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AaMfma<2>::LDS);
+            });
+            const int nt = (T + AaMfma<2>::TT - 1) / AaMfma<2>::TT;
+            const int tpw = aa_tiles_per_wg((int64_t)nt * ((C + 31) / 32) * B);
+            dim3 g2((nt + tpw - 1) / tpw, (C + 31) / 32, B);
+            hipLaunchKernelGGL(aa_snake_mfma_kernel<2>, g2, block, AaMfma<2>::LDS, s, (const f16_t*)x, (f16_t*)y, alpha_log, beta_log, f, T, C, valid_rows, tpw);
+          }
+          break;
+        }
         ITTS_AA_BY_CS(f16_t);
         break;
       default:

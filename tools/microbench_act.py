@@ -14,7 +14,10 @@ from indextts.BigVGAN.models import kaiser_sinc_filter  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 f = kaiser_sinc_filter()
-for T, C in ((560, 768), (2240, 384), (8960, 192), (35840, 96), (71680, 48), (143360, 24)):
+SHAPES = ((560, 768), (2240, 384), (8960, 192), (35840, 96), (71680, 48), (143360, 24))
+if os.environ.get("ACT_C"):      # one shape only (profiler runs)
+    SHAPES = tuple(sh for sh in SHAPES if sh[1] == int(os.environ["ACT_C"]))
+for T, C in SHAPES:
     x = torch.randn(32, T, C, device="cuda").half()
     y = torch.empty_like(x)
     al = torch.zeros(C, device="cuda")
