@@ -477,8 +477,9 @@ static SkinnyPlan plan_skinny(int N, int K, int ksplit, int MTall, int rows_per_
 #if ITTS_DIAG
   if (g_tune_ntb > 0) ntb = g_tune_ntb;
 #endif
-  if (ntb > 3) ntb = 3;
   const int SPWc = spw <= 5 ? 5 : 10;     // register-chunk variant
+  const int ntb_max = (fold && MT <= 2 && SPWc == 5) ? 4 : 3;   // 4 tiles: the folded GEMMs of a many-row step with the rows dealt to grid.z
+  if (ntb > ntb_max) ntb = ntb_max;
   if (SPWc == 10 && ntb > 2) ntb = 2;     // register budget of the 10-step variant
   if (MT > 2 && SPWc == 10) ntb = 1;      // 4-6 row tiles with 10-step chunks: accumulators + weight fragments
   if (NW == 16) ntb = 1;                  // 128 registers per lane
@@ -509,9 +510,12 @@ static void launch_skinny_mt(const SkinnyParams& p, const SkinnyPlan& q, hipStre
   if (q.SPWc == 5) {
     if (q.ntb == 1) ITTS_SK(5, 1, 8);
     else if (q.ntb == 2) ITTS_SK(5, 2, 8);
-    else {
+    else if (q.ntb == 3) {
       if constexpr (FOLD && MT > 2) ITTS_SK(5, 2, 8);   // (the plan never asks for 3 tiles there: register budget)
       else ITTS_SK(5, 3, 8);
+    } else {
+      if constexpr (FOLD && MT <= 2) ITTS_SK(5, 4, 8);
+      else ITTS_SK(5, 1, 8);                            // (never planned)
     }
   } else {
     if (q.ntb == 1) ITTS_SK(10, 1, 8);

@@ -126,6 +126,7 @@ class GPTEngine:
             self.decode_mode = "launch"
         # launch geometry of the two GEMMs that run without split-K in "fold" mode (rows per workgroup, 16-wave workgroups)
         self.fold_rows = [int(v) for v in os.environ.get("ITTS_FOLD_ROWS", "16,16").split(",")]   # out-projection, FC2
+        self.fold_rows_consumers = int(os.environ.get("ITTS_FOLD_ROWS_C", "32"))   # QKV' / FC' rows per workgroup when a step has > 32 rows
         self.fold_wide = os.environ.get("ITTS_FOLD_WIDE", "0") == "1"   # measured equal (836.7 / 840.6 us per token)
         # T-typed activations of the decode step (xn, attention output, MLP hidden) live in the packed fragment layout
         # (include/indextts_hip.h): the GEMMs read them as contiguous 1-KiB blocks.  ITTS_PACKED_ACT=0: row-major (same bits).
@@ -633,10 +634,16 @@ class GPTEngine:
             nat.embed_step(self.tokens, self.mel_emb, self.mel_pos, step, 2 if bump else 1, h, row_step0=rs0, h_packed=hb,
                            bump=pos if bump else None)
             r_o, r_p = self.fold_rows
+            # more than 32 rows (beam search: 32 x 3): a workgroup that covers ALL rows moves 246 KB of activations through its
+            # CU's load path per 1280-deep K; 32 rows per workgroup (the row tiles dealt to grid.z, 3-4 column tiles each so that
+            # the grid still fits the chip) moves a third of that
+            r_c = self.fold_rows_consumers if B > 32 else 0
+            if B > 32:
+                r_o, r_p = max(r_o, 32), max(r_p, 32)
             for i, l in enumerate(self.layers):
                 nat.gemm_skinny(T, B, 3 * D, D, l["wf_qkv"], l["d_qkv"], x=hb, epi=nat.EPI_QKV_CACHE, y=self.q, kcache=self.kc[i],
                                 vcache=self.vc[i], pos=pos, heads=H, smax=self._cap_s, x_packed=True, ln_c=l["c_qkv"],
-                                bump=step if (bump and i == 0) else None, **kva)
+                                bump=step if (bump and i == 0) else None, rows_per_wg=r_c, **kva)
                 nat.attn_decode(self.q, self.kc[i], self.vc[i], self.a, self.pad, pos, B, H, self._cap_s, out_packed=pa,
                                 kv_rows=self._kv_rows, kv_step=step if self._kv_rows is not None else None,
                                 skip_rows=self.finished if self._kv_rows is None and self.skip_finished else None,
@@ -644,7 +651,7 @@ class GPTEngine:
                 nat.gemm_skinny(T, B, D, D, l["w_o"], l["b_o"], x=self.a, epi=nat.EPI_RESID_F32, yf=h, y=hb, x_packed=pa,
                                 y_packed=True, rows_per_wg=r_o, wide_wg=self.fold_wide)
                 nat.gemm_skinny(T, B, 4 * D, D, l["wf_fc"], l["d_fc"], x=hb, epi=nat.EPI_GELU_STORE, y=self.f, x_packed=True,
-                                y_packed=pa, ln_c=l["c_fc"])
+                                y_packed=pa, ln_c=l["c_fc"], rows_per_wg=r_c)
                 nat.gemm_skinny(T, B, D, 4 * D, l["w_pr"], l["b_pr"], x=self.f, epi=nat.EPI_RESID_F32, yf=h, y=hb, x_packed=pa,
                                 y_packed=True, rows_per_wg=r_p, wide_wg=self.fold_wide)
             nat.ln_reduce(h, self.ln_f[0], self.ln_f[1], xn, w2=self.final_norm[0], b2=self.final_norm[1], y_packed=pa)
@@ -1084,7 +1091,8 @@ class GPTEngine:
         sp = self._seed_to_state(sp)
         self._beam_select(B, nb, sp)  # token 1 from the prefill logits
         n = 1
-        key = ("beam", B, nb, self.beam_kv, self.decode_mode, self.lora, tuple(self.fold_rows), self.fold_wide, self.pa, self.KSPLIT,
+        key = ("beam", B, nb, self.beam_kv, self.decode_mode, self.lora, tuple(self.fold_rows), self.fold_rows_consumers, self.fold_wide,
+               self.pa, self.KSPLIT,
                tuple(sorted(sp.items())))
         while n < max_new:
             if use_graph and not self.force_eager and n >= 2:

@@ -19,6 +19,7 @@ from indextts.gpt.engine import GPTEngine  # noqa: E402
 torch.set_grad_enabled(False)
 settings = sys.argv[1:] or ["default"]
 B, P, NEW = 32, 72, int(os.environ.get("ITTS_TOKENS", "140"))
+NB = int(os.environ.get("ITTS_BEAMS", "1"))      # > 1: beam-sample over B x NB rows (prompt cached once per element, row table)
 gsd = weights.gpt_state_dict(24)
 eng = GPTEngine(gsd, 24, 1280, 20, dtype=torch.bfloat16, device="cuda")
 g = torch.Generator().manual_seed(1)
@@ -37,16 +38,27 @@ for rep in range(2):
                     eng.decode_mode = v
                 elif k == "rows":
                     eng.fold_rows = [int(x) for x in v.split(":")]
+                elif k == "rc":
+                    eng.fold_rows_consumers = int(v)
                 elif k == "wide":
                     eng.fold_wide = v == "1"
         eng._graphs.clear()
-        eng.prefill(prefix, pad, NEW + 2)
-        codes = eng.decode(NEW, sp, force_stop=[NEW - 1] * B)   # warm-up + capture
-        eng.prefill(prefix, pad, NEW + 2)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        codes = eng.decode(NEW, sp, force_stop=[NEW - 1] * B)
-        torch.cuda.synchronize()
+
+        def run():
+            if NB > 1:
+                eng.prefill(prefix, pad, NEW + 2, beams=NB)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                c = eng.decode_beam(NEW, dict(sp, length_penalty=0.0), NB)
+            else:
+                eng.prefill(prefix, pad, NEW + 2)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                c = eng.decode(NEW, sp, force_stop=[NEW - 1] * B)
+            torch.cuda.synchronize()
+            return c, t
+        run()                                                   # warm-up + capture
+        codes, t0 = run()
         us = 1e6 * (time.perf_counter() - t0) / NEW
         if ref is None:
             ref = codes.clone()
