@@ -722,184 +722,6 @@ static int launch_plain(const ConvParams& p, hipStream_t s) {
 }
 
 // -------------------------------------------------------------------------------------------------------------------
-// Plain GEMM, large tile (round 3): 256 rows x 128 columns per workgroup, FOUR waves of 128 x 64 (8 x 4 accumulator tiles,
-// one wave per SIMD), BOTH operands through LDS in chunks of two k-steps.  Why: the 128 x 128 kernel above re-reads every
-// operand byte once per 128 rows / columns and fetches each weight fragment in two waves -- 43 FLOP per byte that crosses
-// L2 -> CU, 17 TB/s of L2 traffic at 745 TFLOP/s: it is L2-bandwidth bound.  This tile moves 85 FLOP per byte.  Per chunk a
-// wave issues 64 MFMAs (1 024 cycles) against 24 LDS fragment reads; the next chunk's rows / weight blocks are requested
-// from global memory one chunk ahead and written to the other LDS buffer under the current chunk's MFMAs.
-// MEASURED (diagnostic build only, itts_debug_set(3, 9 / 11); tools/probes/check_big_gemm.py, profiles/r03_big_gemm.txt):
-// bit-identical to the 128 x 128 kernel and SLOWER on every prefill / latent shape -- 300-475 against 580-670 TFLOP/s -- with
-// one or two chunks requested ahead and with or without the fragment reads of the second k-step issued under the first
-// one's MFMAs: a chunk takes ~5 000 cycles where its MFMAs need 1 024, whatever is prefetched.  Four waves per CU do not
-// keep this pipeline busy; the 16 waves of two 128 x 128 workgroups do.  Not used by the product.
-// -------------------------------------------------------------------------------------------------------------------
-// D = chunks requested ahead (register staging sets): the loads in flight per CU are D x 48 KB, and with one wave per SIMD
-// that product over the 2-3 us a loaded memory system takes IS the throughput (D = 1: 457 TFLOP/s measured = 48 KB / ~6 000 cycles)
-template <typename T, int D>
-__global__ __launch_bounds__(256, 1) void gemm_big_kernel(ConvParams p) {
-  typedef Elem<T> EL;
-  typedef typename EL::frag frag;
-  constexpr int TM = 8, TN = 4, BM = 256, BN = 128, KC = 2;
-  constexpr int ROWB = KC * 64 + 16;                  // LDS row stride of the activation tile (bytes)
-  constexpr int ABYTES = BM * ROWB, BBYTES = (BN / 16) * KC * 1024, BUFB = ABYTES + BBYTES;
-  constexpr int NA = BM * KC * 4 / 256, NB_ = BBYTES / 16 / 256;   // 16-byte staging slots per thread: 8 + 4
-  constexpr unsigned OOB = 0xFFFFFFFFu;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, r = lane & 15;
-  const int wm = wave >> 1, wn = wave & 1;
-  int mblk, nblk, b;
-  tile_of_workgroup(p, blockIdx.x, gridDim.x, mblk, nblk, b);
-  const int t0 = mblk * BM;
-  const int vrows = conv_valid_rows(p, b);
-  if (t0 + p.off0 >= vrows) return;
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T*>((const T*)p.x + (int64_t)b * p.x_bstride), 0, (int)((int64_t)vrows * p.Cin * (int)sizeof(T)), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(p.wp), 0, (int)((int64_t)p.NT * p.KT * 1024), 0x00020000);
-  const int NC = (p.KT + KC - 1) / KC;
-  const int kbytes = p.Cin * (int)sizeof(T);          // bytes of one activation row
-
-  // staging slots: chunk-independent parts of the addresses
-  unsigned a_g[NA], b_g[NB_];
-  int a_l[NA], b_l[NB_], a_cb[NA], b_ks[NB_];
-#pragma unroll
-  for (int q = 0; q < NA; ++q) {
-    const int idx = tid + q * 256, row = idx / (KC * 4), seg = idx - row * (KC * 4);
-    const int tin = t0 + p.off0 + row;
-    a_cb[q] = seg * 16;
-    a_g[q] = (tin >= 0 && tin < vrows) ? (unsigned)(tin * kbytes + seg * 16) : OOB;
-    a_l[q] = row * ROWB + seg * 16;
-  }
-#pragma unroll
-  for (int q = 0; q < NB_; ++q) {
-    const int idx = tid + q * 256, blk = idx >> 6, within = idx & 63;
-    const int nt = blk / KC, ks = blk - nt * KC;
-    const int gnt = nblk * (BN / 16) + nt;
-    b_ks[q] = ks;
-    b_g[q] = gnt < p.NT ? (unsigned)((gnt * p.KT + ks) * 1024 + within * 16) : OOB;
-    b_l[q] = ABYTES + blk * 1024 + within * 16;
-  }
-  frag sa[D][NA], sb[D][NB_];
-  auto request = [&](int c, frag (&xa)[NA], frag (&xb)[NB_]) {
-#pragma unroll
-    for (int q = 0; q < NA; ++q) {
-      const bool ok = a_g[q] != OOB && c * (KC * 64) + a_cb[q] < kbytes;
-      xa[q] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? a_g[q] + (unsigned)(c * KC * 64) : OOB, 0, 0));
-    }
-#pragma unroll
-    for (int q = 0; q < NB_; ++q) {
-      const bool ok = b_g[q] != OOB && c * KC + b_ks[q] < p.KT;
-      xb[q] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? b_g[q] + (unsigned)(c * KC * 1024) : OOB, 0, 0));
-    }
-  };
-  auto commit = [&](unsigned char* buf, frag (&xa)[NA], frag (&xb)[NB_]) {
-#pragma unroll
-    for (int q = 0; q < NA; ++q) st16(buf + a_l[q], xa[q]);
-#pragma unroll
-    for (int q = 0; q < NB_; ++q) st16(buf + b_l[q], xb[q]);
-  };
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int a_off = (wm * TM * 16 + r) * ROWB + g * 16;
-  const int b_off = ABYTES + (wn * TN * KC) * 1024 + lane * 16;
-
-  // prologue: chunk 0 into LDS buffer 0; chunks 1 .. D in flight (chunk j lives in register set j % D)
-  request(0, sa[0], sb[0]);
-  commit(lds, sa[0], sb[0]);
-#pragma unroll
-  for (int j = 1; j <= D; ++j) request(j, sa[j % D], sb[j % D]);
-  __syncthreads();
-  constexpr int U = (D % 2 == 0) ? D : 2 * D;       // unroll so that both the LDS buffer (c & 1) and the set (c % D) are static
-  // NO guard inside the unrolled body: the trip count is rounded up to U chunks (chunks past the end are zeros: their loads
-  // are out of range and cost nothing, their MFMAs add zero).  With a guard per body the compiler's wait-count pass merges the
-  // "body skipped" path into every wait and drains the whole queue (vmcnt(11..0) where vmcnt(12 (D - 1) + 11) is meant).
-  const int NCp = (NC + U - 1) / U * U;
-  for (int c0 = 0; c0 < NCp; c0 += U) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int c = c0 + u;
-      {
-        const unsigned char* cur = lds + (u & 1) * BUFB;
-        unsigned char* nxt = lds + ((u + 1) & 1) * BUFB;
-        // one wave per SIMD issues in order: the fragments of k-step 1 are requested BEFORE the MFMAs of k-step 0, so that
-        // their LDS latency runs under 32 MFMAs instead of stalling the wave (nothing else is there to fill the hole)
-        frag af0[TM], bf0[TN], af1[TM], bf1[TN];
-        const int ex = ITTS_CONV_EXP(p);   // diagnostic ablations: 256 no MFMAs, 512 no global requests, 1024 no LDS commit, 2048 no fragment reads
-        if (!(ex & 2048)) {
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) bf0[tn] = ld16<frag>(cur + b_off + (tn * KC + 0) * 1024);
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm) af0[tm] = ld16<frag>(cur + a_off + tm * 16 * ROWB + 0 * 64);
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) bf1[tn] = ld16<frag>(cur + b_off + (tn * KC + 1) * 1024);
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm) af1[tm] = ld16<frag>(cur + a_off + tm * 16 * ROWB + 1 * 64);
-        } else {
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) bf0[tn] = bf1[tn] = sb[0][0];
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm) af0[tm] = af1[tm] = sa[0][0];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(ex & 256)) {
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = EL::mma(bf0[tn], af0[tm], acc[tm][tn]);   // weights as A: transposed tile
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(ex & 1024)) commit(nxt, sa[(u + 1) % D], sb[(u + 1) % D]);                 // chunk c+1: requested D chunks ago
-        if (!(ex & 512)) request(c + 1 + D, sa[(u + 1) % D], sb[(u + 1) % D]);           // past the last chunk: out-of-range offsets, no traffic
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(ex & 256)) {
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = EL::mma(bf1[tn], af1[tm], acc[tm][tn]);
-        } else {
-          asm volatile("" ::"v"(af1[0]), "v"(bf1[0]), "v"(af0[0]), "v"(bf0[0]));
-        }
-        __syncthreads();
-      }
-    }
-  }
-  conv_epilogue<T, TM, TN>(p, acc, b, t0 + wm * TM * 16, nblk * (BN / 16) + wn * TN, g, r);
-}
-
-template <typename T, int D>
-static int launch_big(const ConvParams& p, hipStream_t s) {
-  constexpr int BM = 256, BN = 128;
-  constexpr size_t ldsb = (size_t)2 * (BM * (2 * 64 + 16) + (BN / 16) * 2 * 1024);
-  ConvParams q = p;
-  q.MB = (p.Tout + BM - 1) / BM;
-  q.NB = (p.N + BN - 1) / BN;
-  const int64_t wbytes = (int64_t)BN * p.KT * 64;
-  int gn = (int)((2 << 20) / (wbytes > 0 ? wbytes : 1));
-  gn = gn < 1 ? 1 : (gn > 8 ? 8 : gn);
-  int gm = 32 / gn;
-  gm = gm >= 32 ? 32 : (gm >= 16 ? 16 : (gm >= 8 ? 8 : 4));
-  q.GM = gm;
-  const int64_t total = (int64_t)q.MB * q.NB * p.B;
-  if (total > 0x7fffffff) {
-    set_error("itts_gemm_conv: too many tiles (%lld)", (long long)total);
-    return ITTS_ERR_INVALID;
-  }
-  static std::once_flag attr;
-  std::call_once(attr, [] {
-    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<T, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  });
-  hipLaunchKernelGGL((gemm_big_kernel<T, D>), dim3((unsigned)total), dim3(256), ldsb, s, q);
-  return check_launch("itts_gemm_conv");
-}
-
-// -------------------------------------------------------------------------------------------------------------------
 // Narrow convolution (Cin <= 64, N <= 64: the last two BigVGAN stages, conv_post and the last upsampler).  These layers
 // are HBM-bound (a k = 7 conv over 48 channels does 84 FLOP per byte moved), so the kernel is built around the row
 // stream, not the MFMA pipe:
@@ -1147,6 +969,194 @@ static int launch_narrow_taps(const ConvParams& p, hipStream_t s) {
   return check_launch("itts_gemm_conv");
 }
 
+// Third form (round 4): the activation rows of a tile are STAGED IN LDS.  The second form requests every tap's fragments from
+// global memory -- a k = 11 layer reads each input row eleven times through the CU's L1 path and a tile still pays one or two
+// dependent L2 round trips, 150-320 us per launch against an HBM time of ~100 us.  Here a workgroup's BM output rows plus the
+// dilation halo (BM + (taps - 1) dil rows x Cin channels) go through registers into LDS ONCE; every tap's fragments are
+// ds_read_b128 row reads (row stride = an odd number of 16-byte units: conflict-free), weights in LDS as before.  The NEXT tile's
+// rows are requested right after the current tile has been committed to LDS and arrive under its MFMAs (persistent grid,
+// register staging, two barriers per tile).  A fragment read may run up to (KT * KS - Cin) channels past a row's data -- into
+// the row's pad or the next row's first bytes -- against ZERO weights (the packed weights are zero-padded in K), so the buffer
+// only has to hold finite numbers there: it is cleared once.  Same arithmetic in the same order as the other two forms.
+template <int CIN, int ES>
+struct NarrowLds {
+  static constexpr int DB = CIN * ES;                                      // data bytes of a row
+  static constexpr int RSB = ((DB + 16) >> 4) & 1 ? DB + 16 : DB + 32;     // row stride: an odd number of 16-byte units
+  static constexpr int CPR = DB / 16;                                      // 16-byte chunks per row
+};
+
+template <typename T, int CIN, int TAPS, int TM, int NW>
+__global__ __launch_bounds__(NW * 64, 2)
+void conv_narrow_lds_kernel(ConvParams p) {
+  typedef Elem<T> EL;
+  typedef typename EL::frag frag;
+  constexpr int KS = EL::KS, ES = (int)sizeof(T), BM = NW * TM * 16, NTH = NW * 64;
+  constexpr int KT = (CIN + KS - 1) / KS, NT = (CIN + 15) / 16;
+  constexpr int WB = TAPS * NT * KT * 1024;
+  constexpr int MAXROWS = BM + CV_MAX_HALO + 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  constexpr int DB = NarrowLds<CIN, ES>::DB, rsb = NarrowLds<CIN, ES>::RSB, cpr = NarrowLds<CIN, ES>::CPR;
+  const int halo = (TAPS - 1) * p.dil;
+  const int rows_in = BM + halo;
+  unsigned char* tile = lds + WB;
+  for (int off = tid * 16; off < WB; off += NTH * 16) st16(lds + off, ld16<frag>((const unsigned char*)p.wp + off));
+  for (int off = tid * 16; off < MAXROWS * rsb; off += NTH * 16) st16(tile + off, zero_frag<frag>());
+  __syncthreads();
+  constexpr int NLD = (MAXROWS * cpr + NTH - 1) / NTH;   // staging requests per thread (upper bound: the largest halo)
+  const int ntiles = p.MB * p.B;
+  frag st[NLD];
+  auto request = [&](int tile_id) {
+    const int b = tile_id / p.MB, mblk = tile_id - b * p.MB;
+    const int vrows = conv_valid_rows(p, b);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>((const T*)p.x + (int64_t)b * p.x_bstride), 0, (int)((int64_t)vrows * p.Cin * ES), 0x00020000);
+    const int t_in0 = mblk * BM + p.off0;
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+      const int idx = tid + q * NTH;
+      const int row = idx / cpr, ch = idx - row * cpr;
+      const int tin = t_in0 + row;
+      const bool ok = row < rows_in && tin >= 0 && tin < vrows;
+      st[q] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)(tin * DB + ch * 16) : OOB, 0, 0));
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+      const int idx = tid + q * NTH;
+      const int row = idx / cpr, ch = idx - row * cpr;
+      if (row < rows_in) st16(tile + row * rsb + ch * 16, st[q]);
+    }
+  };
+  // Epilogue operands (residual rows, the running sum of an accumulating layer) are requested a WHOLE TILE AHEAD, with the next
+  // tile's activation rows: a lane's epilogue positions (row r of each row tile, channels 16 nt + 4g .. +3) are the same in every
+  // tile, so they wait in registers and the epilogue issues no load.  v = fma(acc + bias + resid, scale, sum) as conv_epilogue
+  // (y is T-typed, N / y_shift / y_limit multiples of 4, no per-batch bias, no activation: checked by the dispatcher).
+  typedef T t4 __attribute__((ext_vector_type(4)));
+  const bool has_r = p.resid != nullptr, has_a = p.accumulate != 0;
+  f32x4 bs[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const __amdgpu_buffer_rsrc_t rb1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.bias ? p.bias : (const float*)p.wp), 0, p.bias ? p.N * 4 : 0, 0x00020000);
+    bs[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb1, (unsigned)((nt * 16 + g * 4) * 4), 0, 0));
+  }
+  u32x2 rres[TM][NT], racc[TM][NT];
+  auto epi_request = [&](int tid_) {
+    const int b = tid_ / p.MB, mblk = tid_ - b * p.MB;
+    const int row0 = mblk * BM + wave * (TM * 16);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((T*)p.y + (int64_t)b * p.y_bstride, 0, (int)(p.y_limit * ES), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>((const T*)(p.resid ? p.resid : p.y)) + (int64_t)b * p.y_bstride, 0, (int)(p.y_limit * ES), 0x00020000);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int t = row0 + tm * 16 + r, col0 = nt * 16 + g * 4;
+        const int64_t flat = (int64_t)t * p.N + col0 + p.y_shift;
+        const bool ok = (t < p.Tout) && (col0 < p.N) && (flat >= 0) && (flat < p.y_limit);
+        const unsigned off = ok ? (unsigned)(flat * ES) : OOB;
+        rres[tm][nt] = has_r ? __builtin_amdgcn_raw_buffer_load_b64(rr, off, 0, 0) : u32x2{0u, 0u};
+        racc[tm][nt] = has_a ? __builtin_amdgcn_raw_buffer_load_b64(ry, off, 0, 0) : u32x2{0u, 0u};
+      }
+  };
+  int tile_id = blockIdx.x;
+  if (tile_id < ntiles) {
+    request(tile_id);
+    epi_request(tile_id);
+  }
+  for (; tile_id < ntiles; tile_id += gridDim.x) {
+    commit();
+    __syncthreads();
+    if (tile_id + (int)gridDim.x < ntiles) request(tile_id + gridDim.x);    // in flight under this tile's MFMAs
+    const int b = tile_id / p.MB, mblk = tile_id - b * p.MB;
+    const int row0 = mblk * BM + wave * (TM * 16);
+    const int vrows = conv_valid_rows(p, b);
+    if (row0 + p.off0 < vrows) {     // (ragged batch: a wave whose rows lie in the element's padding computes and stores nothing)
+      f32x4 acc[TM][NT];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const unsigned char* ar = tile + (wave * (TM * 16) + r) * rsb + g * 16;
+#pragma unroll
+      for (int j = 0; j < TAPS; ++j) {
+        frag af[TM][KT];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int ks = 0; ks < KT; ++ks) af[tm][ks] = ld16<frag>(ar + (tm * 16 + j * p.dil) * rsb + ks * (KS * ES));
+        const unsigned char* wb = lds + (size_t)j * NT * KT * 1024 + lane * 16;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int ks = 0; ks < KT; ++ks) {
+            const frag bf = ld16<frag>(wb + (nt * KT + ks) * 1024);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) acc[tm][nt] = EL::mma(bf, af[tm][ks], acc[tm][nt]);  // weights as A: transposed tile
+          }
+      }
+      const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((T*)p.y + (int64_t)b * p.y_bstride, 0, (int)(p.y_limit * ES), 0x00020000);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int t = row0 + tm * 16 + r, col0 = nt * 16 + g * 4;
+          const int64_t flat = (int64_t)t * p.N + col0 + p.y_shift;
+          const bool ok = (t < p.Tout) && (col0 < p.N) && (flat >= 0) && (flat < p.y_limit);
+          const t4 rv = __builtin_bit_cast(t4, rres[tm][nt]), av = __builtin_bit_cast(t4, racc[tm][nt]);
+          t4 o;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const float v = acc[tm][nt][jj] + bs[nt][jj];
+            o[jj] = (T)fmaf(v + (has_r ? (float)rv[jj] : 0.f), p.scale, has_a ? (float)av[jj] : 0.f);   // as conv_epilogue_impl
+          }
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ry, ok ? (unsigned)(flat * ES) : OOB, 0, 0);
+        }
+    }
+    // the NEXT tile's epilogue operands: requested now (their registers are free again), consumed at the end of the next tile
+    if (tile_id + (int)gridDim.x < ntiles) epi_request(tile_id + gridDim.x);
+    __syncthreads();     // every wave has read its rows: the next tile may be committed
+  }
+}
+
+template <typename T, int CIN, int TAPS, int TM, int NW>
+static int launch_narrow_lds(const ConvParams& p, hipStream_t s) {
+  constexpr int BM = NW * TM * 16, ES = (int)sizeof(T), KS = Elem<T>::KS;
+  constexpr int KT = (CIN + KS - 1) / KS, NT = (CIN + 15) / 16;
+  ConvParams q = p;
+  q.MB = (p.Tout + BM - 1) / BM;
+  q.NB = 1;
+  q.GM = 1;
+  const int64_t tiles = (int64_t)q.MB * p.B;
+  constexpr size_t ldsb = (size_t)TAPS * NT * KT * 1024 + (size_t)(BM + CV_MAX_HALO + 1) * NarrowLds<CIN, ES>::RSB;
+  static std::once_flag attr;
+  std::call_once(attr, [] {
+    (void)hipFuncSetAttribute((const void*)conv_narrow_lds_kernel<T, CIN, TAPS, TM, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024 - 256);
+    (void)hipGetLastError();
+  });
+  static thread_local size_t occ_lds = ~(size_t)0;
+  static thread_local int occ_wgs = 1;
+  if (occ_lds != ldsb) {
+    int q_wgs = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q_wgs, (const void*)conv_narrow_lds_kernel<T, CIN, TAPS, TM, NW>, NW * 64, ldsb) !=
+            hipSuccess || q_wgs < 1)
+      q_wgs = 1;
+    (void)hipGetLastError();
+    occ_lds = ldsb;
+    occ_wgs = q_wgs;
+  }
+  int64_t grid = (int64_t)conv_num_cus() * occ_wgs;
+  if (grid > tiles) grid = tiles;
+  hipLaunchKernelGGL((conv_narrow_lds_kernel<T, CIN, TAPS, TM, NW>), dim3((unsigned)grid), dim3(NW * 64), ldsb, s, q);
+  return check_launch("itts_gemm_conv");
+}
+
 #if ITTS_DIAG
 int g_conv_cfg = 0;  // diagnostic build: itts_debug_set(3, id) kernel override for A/B measurements (0 = default)
 #else
@@ -1158,6 +1168,17 @@ template <typename T>
 static int dispatch_narrow(const ConvParams& p, hipStream_t s, bool& handled) {
   handled = true;
   const int kt = p.KT, nt = p.NT;
+  if constexpr (sizeof(T) == 2) if (g_conv_cfg != 30 && g_conv_cfg != 31 && p.Cin == p.N && (p.Cin == 24 || p.Cin == 48) && !p.y_f32 &&
+                                    p.bias2 == nullptr && p.act == 0 && ((p.N | p.y_shift | p.y_limit) & 3) == 0) {
+    // third form (rows staged in LDS); diagnostic build: cfg 31 = the second form instead, for A/B runs
+#define ITTS_NL_CASE(CIN_, NW3_, NW7_, NW11_)                                                                       \
+    if (p.Cin == CIN_ && p.taps == 3) return launch_narrow_lds<T, CIN_, 3, 16 / NW3_, NW3_>(p, s);                  \
+    if (p.Cin == CIN_ && p.taps == 7) return launch_narrow_lds<T, CIN_, 7, 16 / NW7_, NW7_>(p, s);                  \
+    if (p.Cin == CIN_ && p.taps == 11) return launch_narrow_lds<T, CIN_, 11, 16 / NW11_, NW11_>(p, s);
+    ITTS_NL_CASE(24, 4, 4, 4)       // C = 24: 256-row tiles, 4 waves x 4 row tiles; weights + rows <= 48 KB -> 3 workgroups per CU
+    ITTS_NL_CASE(48, 4, 4, 8)       // C = 48: the same; 11 taps: 66 KB of weights -> one 8-wave workgroup per CU (2 row tiles per wave)
+#undef ITTS_NL_CASE
+  }
   if (g_conv_cfg != 30) {   // (diagnostic build: cfg 30 = the first form everywhere, for A/B runs)
 #define ITTS_NT_CASE(KT_, NT_, TM_, NW_)                                                               \
     if (kt == KT_ && nt == NT_ && p.taps == 3) return launch_narrow_taps<T, KT_, NT_, 3, TM_, NW_>(p, s);   \
@@ -1191,9 +1212,8 @@ static int dispatch_conv(const ConvParams& p, hipStream_t s) {
     // Measured on MI355X (bf16, M = 3008 / 7488, N = 1280..5120, K = 1280 / 5120): 128 x 128 pipelined 435-720 TFLOP/s,
     // 256 x 128 pipelined 300-625, the unpipelined 256 x 128 tile of the convolution kernel 260-540.
     if (g_conv_cfg == 5) return launch_plain<T, 2, 4, 8, 2>(p, s);   // 256 x 128
-    if (g_conv_cfg == 9) return launch_big<T, 1>(p, s);              // 256 x 128, both operands through LDS, 4 waves of 128 x 64
-    if (g_conv_cfg == 11) return launch_big<T, 2>(p, s);             // ... two / three chunks requested ahead
-
+    // (a 256 x 128 tile with both operands through LDS and four waves of 128 x 64 was built in round 3, measured slower on every
+    // shape -- 300-475 against 580-670 TFLOP/s, profiles/r03_big_gemm.txt -- and removed in round 4)
     return launch_plain<T, 2, 4, 4, 2>(p, s);                        // 128 x 128, two workgroups per CU
   }
   if (plain && p.N % 64 == 0) {
