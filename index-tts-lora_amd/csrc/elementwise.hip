@@ -166,36 +166,41 @@ __global__ __launch_bounds__(256) void aa_snake_mfma_kernel(const f16_t* __restr
       ca[cb][e] = __expf(alpha_log[ch]) * 0.15915494309189535f;    // e^alpha / (2 pi): v_sin_f32 takes revolutions
       cbv[cb][e] = __frcp_rn(__expf(beta_log[ch]) + 1e-9f);
     }
-  // a workgroup walks tiles_per_wg consecutive tiles of its (batch element, channel slice): the fragments above are built once
+  // A workgroup walks tiles_per_wg consecutive tiles of its (batch element, channel slice): the fragments above are built once,
+  // and the NEXT tile's x rows are requested as soon as the current tile's have been committed to LDS -- they arrive under the
+  // current tile's MFMAs and transcendental ops (a tile's global round trip is otherwise exposed: three workgroups per CU do not
+  // cover it).
+  // ---- phase 1: x rows t0-12 .. t0+XR-13 -> X image.  Row indices are clamped to the sequence (the reference's replicate
+  // padding of x); channels past C (a 24-channel tensor in a 32-channel slice) read as zeros.  A thread keeps its channel quad
+  // and walks rows RPP apart.
+  constexpr int C4 = CS / 4;
+  constexpr int RPP = 256 / C4;                 // rows per pass of the workgroup (RPP * C4 threads take part)
+  constexpr int NP = (XR + RPP - 1) / RPP;
+  const int pr = tid / C4, pc4 = tid - pr * C4;
+  const bool pact = pr < RPP && c0 + pc4 * 4 < C;
+  const f16_t* xc = xb + c0 + pc4 * 4;
+  h4 xv[NP];
+  auto request = [&](const int t0r) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int row = min(max(t0r - 12 + pr + q * RPP, 0), T_len - 1);
+      xv[q] = pact ? *reinterpret_cast<const h4*>(xc + (int64_t)row * C) : h4{0, 0, 0, 0};
+    }
+  };
+  // the S rows past the u rows are read by the last y block's window (against zero taps): they must hold numbers
+  if (pr < 16 && pc4 < C4) *reinterpret_cast<h4*>(&Si[(2 * TT + 16 + pr) * RS + pc4 * 4]) = h4{0, 0, 0, 0};
+  request((int)blockIdx.x * tiles_per_wg * TT);
   for (int it = 0; it < tiles_per_wg; ++it) {
   const int t0 = ((int)blockIdx.x * tiles_per_wg + it) * TT;
   if (t0 >= T_len) break;
-  if (it > 0) __syncthreads();     // the previous tile's reads of both images are done
-
-  // ---- phase 1: x rows t0-12 .. t0+XR-13 -> X image.  Row indices are clamped to the sequence (the reference's replicate
-  // padding of x); channels past C (a 24-channel tensor in a 32-channel slice) read as zeros.  All loads first.  A thread keeps
-  // its channel quad and walks rows RPP apart (the kernel is bound by instruction issue: no division per load).
   {
-    constexpr int C4 = CS / 4;
-    constexpr int RPP = 256 / C4;                 // rows per pass of the workgroup (RPP * C4 threads take part)
-    constexpr int NP = (XR + RPP - 1) / RPP;
-    const int pr = tid / C4, pc4 = tid - pr * C4;
-    const bool act = pr < RPP && c0 + pc4 * 4 < C;
-    const f16_t* xc = xb + c0 + pc4 * 4;
-    h4 v[NP];
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-      const int row = min(max(t0 - 12 + pr + q * RPP, 0), T_len - 1);
-      v[q] = act ? *reinterpret_cast<const h4*>(xc + (int64_t)row * C) : h4{0, 0, 0, 0};
-    }
-    // the S rows past the u rows are read by the last y block's window (against zero taps): they must hold numbers
-    if (pr < 16) *reinterpret_cast<h4*>(&Si[(2 * TT + 16 + pr) * RS + pc4 * 4]) = h4{0, 0, 0, 0};
     f16_t* xw = &Xi[pr * RS + pc4 * 4];
 #pragma unroll
     for (int q = 0; q < NP; ++q)
-      if (pr < RPP && pr + q * RPP < XR) *reinterpret_cast<h4*>(xw + q * RPP * RS) = v[q];
+      if (pr < RPP && pr + q * RPP < XR) *reinterpret_cast<h4*>(xw + q * RPP * RS) = xv[q];
   }
-  __syncthreads();
+  __syncthreads();     // X committed; every wave is also done with the previous tile's S reads
+  if (it + 1 < tiles_per_wg && t0 + TT < T_len) request(t0 + TT);
   // ---- phase 2: u blocks -> snake -> S image.  Row block ub: u rows 2*t0 - 8 + 16 ub .. +15; its x window starts at image row
   // 8 ub (x row t0 - 12 + 8 ub = q0 - 8).  A wave takes every fourth row block, all channel blocks of it at once (independent
   // chains: the transposed reads, the MFMAs and the transcendental ops of different blocks overlap).
