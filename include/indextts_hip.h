@@ -188,6 +188,12 @@ typedef struct itts_conv_args {
    * of batch element b read as zeros -- the convolution's own zero padding, so each element equals a run on its own --
    * and output tiles that only see that padding are not computed (their rows of y are left untouched). */
   const int32_t* valid_rows;
+  /* split-K of a plain GEMM (taps = 1, B = 1, N % 128 == 0; 0 / 1 = off, <= 8): the K range is cut into ksplit slices that run as
+   * separate tiles of ONE launch, and y (fp32, y_f32 = 1) receives the slabs [ksplit][Tout][N] -- slice ks holds the rows' partial
+   * products over its K range; no bias / bias2 / resid / accumulate / act (itts_ln_reduce sums the slabs in order, adds the bias
+   * and the residual and applies the LayerNorm that follows).  For GEMMs with few output tiles (the prefill's N = 1280 projections:
+   * 160 tiles of 128 x 128 for 512 workgroup slots). */
+  int ksplit;
 } itts_conv_args;
 int itts_gemm_conv(const itts_conv_args* a, void* stream);
 

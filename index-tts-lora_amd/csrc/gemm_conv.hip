@@ -34,6 +34,7 @@ struct ConvParams {
   int accumulate;
   float scale;
   int NT, KT;
+  int ksplit;      // plain GEMM only: > 1 = the batch index of a tile is a K SLICE (slabs, see itts_conv_args.ksplit)
   int MB, NB, GM;  // m-blocks per batch element, n-blocks, m-blocks per L2 group (XCD-aware tile order)
   const int32_t* valid_rows;   // [B] or null: input rows >= valid_rows[b] read as zeros, tiles wholly beyond are skipped
   int exp;         // diagnostic build only (itts_debug_set key 5): ablation switches of the tiled kernel, 0 in the product
@@ -595,11 +596,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_plain_kernel(ConvParams 
   tile_of_workgroup(p, blockIdx.x, gridDim.x, mblk, nblk, b);
   const int t0 = mblk * BM;
   const int nt0 = nblk * (BN / 16) + wn * TN;
-  const int NC = (p.KT + CK - 1) / CK;
-  const int vrows = conv_valid_rows(p, b);
+  // split-K (p.ksplit > 1): the "batch element" b is a K slice -- k-steps [kt0, kt0 + KTs) of the SAME rows, result into slab b
+  const bool split = p.ksplit > 1;
+  const int kt0 = split ? (int)(((int64_t)b * p.KT) / p.ksplit) : 0;
+  const int KTs = split ? (int)(((int64_t)(b + 1) * p.KT) / p.ksplit) - kt0 : p.KT;
+  const int cin_s = split ? min(KTs * KS, p.Cin - kt0 * KS) : p.Cin;     // columns of x this tile multiplies
+  const int NC = (KTs + CK - 1) / CK;
+  const int vrows = split ? p.Tin : conv_valid_rows(p, b);
   if (t0 + p.off0 >= vrows) return;   // ragged batch: the whole tile lies in this batch element's padding
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T*>((const T*)p.x + (int64_t)b * p.x_bstride), 0, (int)((int64_t)vrows * p.Cin * (int)sizeof(T)), 0x00020000);
+      const_cast<T*>((const T*)p.x + (split ? (int64_t)kt0 * KS : (int64_t)b * p.x_bstride)), 0,
+      (int)((int64_t)vrows * p.Cin * (int)sizeof(T) - (split ? kt0 * KS * (int)sizeof(T) : 0)), 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.wp), 0, (int)((int64_t)p.NT * p.KT * 1024), 0x00020000);
   constexpr unsigned OOB = 0xFFFFFFFFu;
@@ -628,7 +635,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_plain_kernel(ConvParams 
   auto prefetch_a = [&](int c) {
 #pragma unroll
     for (int q = 0; q < MAXST; ++q) {
-      bool ok = (st_goff[q] != OOB) && (c * (CK * KS) + st_col[q] < p.Cin);
+      bool ok = (st_goff[q] != OOB) && (c * (CK * KS) + st_col[q] < cin_s);
       unsigned off = ok ? st_goff[q] + (unsigned)(c * (CK * KS) * (int)sizeof(T)) : OOB;
       stg[q] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
     }
@@ -641,11 +648,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_plain_kernel(ConvParams 
   // weight block of (n-tile nt, flat k-step ks) = nt*KT + ks
   unsigned wbase[TN];
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) wbase[tn] = (nt0 + tn) < p.NT ? (unsigned)((((nt0 + tn) * p.KT) * 64 + lane) * 16) : OOB;
+  for (int tn = 0; tn < TN; ++tn) wbase[tn] = (nt0 + tn) < p.NT ? (unsigned)((((nt0 + tn) * p.KT + kt0) * 64 + lane) * 16) : OOB;
   auto fetch_b = [&](frag (&bf)[TN], int ks) {
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-      unsigned off = (wbase[tn] != OOB && ks < p.KT) ? wbase[tn] + (unsigned)ks * 1024u : OOB;
+      unsigned off = (wbase[tn] != OOB && ks < KTs) ? wbase[tn] + (unsigned)ks * 1024u : OOB;
       bf[tn] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0));
     }
   };
@@ -708,7 +715,13 @@ static int launch_plain(const ConvParams& p, hipStream_t s) {
   int gm = 32 / gn;
   gm = gm >= 32 ? 32 : (gm >= 16 ? 16 : (gm >= 8 ? 8 : 4));
   q.GM = gm;
-  const int64_t total = (int64_t)q.MB * q.NB * p.B;
+  if (p.ksplit > 1) {            // K slices in place of batch elements; slab ks of y = the rows' partial products over slice ks
+    q.B = p.ksplit;
+    q.y_bstride = (int64_t)p.Tout * p.N;
+    q.y_limit = (int64_t)p.Tout * p.N;
+    q.y_shift = 0;
+  }
+  const int64_t total = (int64_t)q.MB * q.NB * q.B;
   if (total > 0x7fffffff) {
     set_error("itts_gemm_conv: too many tiles (%lld)", (long long)total);
     return ITTS_ERR_INVALID;
@@ -1214,6 +1227,12 @@ static int dispatch_conv(const ConvParams& p, hipStream_t s) {
     if (g_conv_cfg == 5) return launch_plain<T, 2, 4, 8, 2>(p, s);   // 256 x 128
     // (a 256 x 128 tile with both operands through LDS and four waves of 128 x 64 was built in round 3, measured slower on every
     // shape -- 300-475 against 580-670 TFLOP/s, profiles/r03_big_gemm.txt -- and removed in round 4)
+    // Few rows (the prefill: M ~ 2 000): N = 5120 gives 16 x 40 = 640 tiles of 128 x 128 for 512 workgroup slots -- two rounds, the
+    // second a quarter full.  128 x 160 tiles (4 x 2 waves of 32 x 80) make it 16 x 32 = 512: one round.
+    if (p.ksplit <= 1 && p.N % 160 == 0 && p.B == 1) {
+      const int64_t mb = (p.Tout + 127) / 128, slots = 2 * (int64_t)conv_num_cus();
+      if (mb * (p.N / 160) <= slots && mb * (p.N / 128) > slots) return launch_plain<T, 4, 2, 2, 5>(p, s);
+    }
     return launch_plain<T, 2, 4, 4, 2>(p, s);                        // 128 x 128, two workgroups per CU
   }
   if (plain && p.N % 64 == 0) {
@@ -1295,6 +1314,13 @@ static int conv_params_from_args(const itts_conv_args* a, ConvParams& p, const c
   p.NT = (a->N + 15) / 16;
   p.KT = (a->Cin + ks - 1) / ks;
   p.MB = p.NB = p.GM = 1;
+  p.ksplit = a->ksplit > 1 ? a->ksplit : 1;
+  if (p.ksplit > 1 && !(a->taps == 1 && a->N % 128 == 0 && a->B == 1 && a->y_f32 && a->bias == nullptr && a->bias2 == nullptr &&
+                        a->resid == nullptr && !a->accumulate && a->act == 0 && a->valid_rows == nullptr && a->off0 == 0 &&
+                        a->Tin == a->Tout && a->Cin % ks == 0 && p.ksplit <= p.KT && p.ksplit <= 8)) {
+    set_error("%s: ksplit > 1 is for the plain GEMM (taps 1, N %% 128 == 0, B 1, fp32 y = slabs, no bias / residual / activation)", who);
+    return ITTS_ERR_INVALID;
+  }
   return ITTS_OK;
 }
 

@@ -46,7 +46,7 @@ class ConvArgs(C.Structure):
                 ("x_bstride", C.c_int64), ("wp", C.c_void_p), ("bias", C.c_void_p), ("bias2", C.c_void_p),
                 ("act", C.c_int), ("y", C.c_void_p), ("y_f32", C.c_int), ("y_bstride", C.c_int64),
                 ("y_shift", C.c_int64), ("y_limit", C.c_int64), ("resid", C.c_void_p), ("accumulate", C.c_int),
-                ("scale", C.c_float), ("valid_rows", C.c_void_p)]
+                ("scale", C.c_float), ("valid_rows", C.c_void_p), ("ksplit", C.c_int)]
 
 
 class SampleArgs(C.Structure):
@@ -260,7 +260,7 @@ def skinny_plan(dtype, M, N, K, ksplit=1, rows_per_wg=0, wide_wg=False, fold=Fal
 
 def gemm_conv(dtype, B, Tin, Tout, Cin, N, wp, x, y, taps=1, off0=0, dil=1, x_bstride=None, bias=None, bias2=None,
               act=0, y_f32=False, y_bstride=None, y_shift=0, y_limit=None, resid=None, accumulate=False, scale=1.0,
-              valid_rows=None):
+              valid_rows=None, ksplit=1):
     """valid_rows int32 [B]: ragged batch -- input rows >= valid_rows[b] read as zeros, tiles that only see them are skipped."""
     a = ConvArgs()
     a.dtype, a.B, a.Tin, a.Tout, a.Cin, a.N = dt(dtype), B, Tin, Tout, Cin, N
@@ -273,6 +273,7 @@ def gemm_conv(dtype, B, Tin, Tout, Cin, N, wp, x, y, taps=1, off0=0, dil=1, x_bs
     a.y_limit = Tout * N if y_limit is None else y_limit
     a.resid, a.accumulate, a.scale = _p(resid), int(accumulate), float(scale)
     a.valid_rows = _p(valid_rows)
+    a.ksplit = int(ksplit)
     _check(lib().itts_gemm_conv(C.byref(a), _stream()), "itts_gemm_conv")
 
 

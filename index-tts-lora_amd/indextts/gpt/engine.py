@@ -351,31 +351,67 @@ class GPTEngine:
         return k, v
 
     # ------------------------------------------------------------------------------------------------ big-M passes
-    def _blocks_full(self, h, B, S, pad, use_cache, row_off=None, cache_shift=None):
-        """All transformer blocks over h fp32 [M, D] (in place).  Padded form: M = B*S rows, pad int32 [B] (left padding)
-        or None.  Packed form (row_off int32 [B+1] on device): only real rows exist, batch element b owns rows
-        [row_off[b], row_off[b+1]), S is the longest element, cache row = cache_shift[b] + local row."""
-        T, D, H = self.dtype, self.D, self.H
+    def _proj_ksplit(self, M):
+        """Split-K factor for the two N = D projections of a big-M pass: their 128 x 128 output tiles number M/128 x 10 -- 160 at the
+        prefill's ~2 000 rows for 512 workgroup slots.  3 slices fill the chip; the slabs are summed by the LayerNorm launch that
+        follows (itts_ln_reduce: residual + bias + slabs, then LN), which replaces the GEMM's residual epilogue AND the LayerNorm
+        launch.  1 where the tiles alone already fill the slots (the latent pass)."""
+        if self.dtype == torch.float32 or self.D % 256 or os.environ.get("ITTS_PREFILL_KSPLIT", "1") == "0":
+            return 1
+        tiles = ((M + 127) // 128) * (self.D // 128)
+        return 3 if tiles * 3 <= 540 else 2 if tiles * 2 <= 540 else 1
+
+    def _big_m_layers(self, h, attn):
+        """The 24 blocks over packed rows h fp32 [M, D] (in place): LayerNorm -> QKV -> attn(i, qkv, att) -> out-projection ->
+        LayerNorm -> FC -> FC2.  With few rows the two N = D projections run split-K into slabs and the NEXT LayerNorm launch folds
+        them into h (see _proj_ksplit); returns h with every block applied."""
+        T, D, dev = self.dtype, self.D, self.device
         M = h.shape[0]
-        dev = self.device
         xn = torch.empty(M, D, dtype=T, device=dev)
         qkv = torch.empty(M, 3 * D, dtype=T, device=dev)
         att = torch.empty(M, D, dtype=T, device=dev)
         ff = torch.empty(M, 4 * D, dtype=T, device=dev)
+        ks = self._proj_ksplit(M)
+        slab = torch.empty(ks, M, D, dtype=torch.float32, device=dev) if ks > 1 else None
+        pending = None                       # bias of the projection whose slabs the next LayerNorm launch has to fold in
         for i, l in enumerate(self.layers):
-            nat.layernorm(h, l["ln1"][0], l["ln1"][1], xn)
+            if pending is None:
+                nat.layernorm(h, l["ln1"][0], l["ln1"][1], xn)
+            else:
+                nat.ln_reduce(h, l["ln1"][0], l["ln1"][1], xn, slab=slab, nslab=ks, bias=pending)
             nat.gemm_conv(T, 1, M, M, D, 3 * D, l["w_qkv"], xn, qkv, bias=l["b_qkv"])
+            attn(i, qkv, att)
+            w_o, w_pr = l.get("w_o_merged", l["w_o"]), l.get("w_pr_merged", l["w_pr"])
+            if ks > 1:
+                nat.gemm_conv(T, 1, M, M, D, D, w_o, att, slab, y_f32=True, ksplit=ks)
+                nat.ln_reduce(h, l["ln2"][0], l["ln2"][1], xn, slab=slab, nslab=ks, bias=l["b_o"])
+            else:
+                nat.gemm_conv(T, 1, M, M, D, D, w_o, att, h, bias=l["b_o"], y_f32=True, resid=h)
+                nat.layernorm(h, l["ln2"][0], l["ln2"][1], xn)
+            nat.gemm_conv(T, 1, M, M, D, 4 * D, l["w_fc"], xn, ff, bias=l["b_fc"], act=1)
+            if ks > 1:
+                nat.gemm_conv(T, 1, M, M, 4 * D, D, w_pr, ff, slab, y_f32=True, ksplit=ks)
+                pending = l["b_pr"]
+            else:
+                nat.gemm_conv(T, 1, M, M, 4 * D, D, w_pr, ff, h, bias=l["b_pr"], y_f32=True, resid=h)
+        if pending is not None:              # the last block's FC2 slabs: fold them in (the LayerNorm output is not used)
+            nat.ln_reduce(h, self.ln_f[0], self.ln_f[1], xn, slab=slab, nslab=ks, bias=pending)
+        return h
+
+    def _blocks_full(self, h, B, S, pad, use_cache, row_off=None, cache_shift=None):
+        """All transformer blocks over h fp32 [M, D] (in place).  Padded form: M = B*S rows, pad int32 [B] (left padding)
+        or None.  Packed form (row_off int32 [B+1] on device): only real rows exist, batch element b owns rows
+        [row_off[b], row_off[b+1]), S is the longest element, cache row = cache_shift[b] + local row."""
+        H = self.H
+        kva = self._kvargs() if use_cache else {}
+
+        def attn(i, qkv, att):
             kc, vc = (self.kc[i], self.vc[i]) if use_cache else (None, None)
             if row_off is None:
                 nat.attn_prefill(qkv, att, kc, vc, pad, B, S, H, self._cap_s)
             else:
-                nat.attn_prefill_packed(qkv, att, kc, vc, row_off, cache_shift, B, S, H, self._cap_s,
-                                        **(self._kvargs() if use_cache else {}))
-            nat.gemm_conv(T, 1, M, M, D, D, l.get("w_o_merged", l["w_o"]), att, h, bias=l["b_o"], y_f32=True, resid=h)
-            nat.layernorm(h, l["ln2"][0], l["ln2"][1], xn)
-            nat.gemm_conv(T, 1, M, M, D, 4 * D, l["w_fc"], xn, ff, bias=l["b_fc"], act=1)
-            nat.gemm_conv(T, 1, M, M, 4 * D, D, l.get("w_pr_merged", l["w_pr"]), ff, h, bias=l["b_pr"], y_f32=True, resid=h)
-        return h
+                nat.attn_prefill_packed(qkv, att, kc, vc, row_off, cache_shift, B, S, H, self._cap_s, **kva)
+        return self._big_m_layers(h, attn)
 
     def _head(self, h_rows, B):
         """ln_f -> final_norm -> mel_head on fp32 rows."""
@@ -417,20 +453,10 @@ class GPTEngine:
         pre_len, pre_row0, w_row, w_pos0 = take(E), take(E), take(E), take(E)
         last_rows, i_db, i_dp = take(B, False), take((B - 1) * C, False), take((B - 1) * C, False)
         h = emb.view(B * S, D)[i_rows]
-        xn = torch.empty(M, D, dtype=T, device=dev)
-        qkv = torch.empty(M, 3 * D, dtype=T, device=dev)
-        att = torch.empty(M, D, dtype=T, device=dev)
-        ff = torch.empty(M, 4 * D, dtype=T, device=dev)
         Smax = max(C, max(own))
-        for i, l in enumerate(self.layers):
-            nat.layernorm(h, l["ln1"][0], l["ln1"][1], xn)
-            nat.gemm_conv(T, 1, M, M, D, 3 * D, l["w_qkv"], xn, qkv, bias=l["b_qkv"])
-            nat.attn_prefill_shared(qkv, att, self.kc[i], self.vc[i], row_off, pre_len, pre_row0, w_row, w_pos0, E, Smax, H,
-                                    self._cap_s, **self._kvargs())
-            nat.gemm_conv(T, 1, M, M, D, D, l.get("w_o_merged", l["w_o"]), att, h, bias=l["b_o"], y_f32=True, resid=h)
-            nat.layernorm(h, l["ln2"][0], l["ln2"][1], xn)
-            nat.gemm_conv(T, 1, M, M, D, 4 * D, l["w_fc"], xn, ff, bias=l["b_fc"], act=1)
-            nat.gemm_conv(T, 1, M, M, 4 * D, D, l.get("w_pr_merged", l["w_pr"]), ff, h, bias=l["b_pr"], y_f32=True, resid=h)
+        kva = self._kvargs()
+        h = self._big_m_layers(h, lambda i, qkv, att: nat.attn_prefill_shared(
+            qkv, att, self.kc[i], self.vc[i], row_off, pre_len, pre_row0, w_row, w_pos0, E, Smax, H, self._cap_s, **kva))
         if B > 1:   # the shared block's keys / values: cache row 0 -> the same sequence positions of every other cache row
             p0 = pad_h[0]
             if self.kv is None:
@@ -581,20 +607,10 @@ class GPTEngine:
         meta = torch.from_numpy(np.concatenate([off, pl, cache_rows, pads]).astype(np.int32)).to(dev)   # one upload
         row_off, pre_len, pre_row, pre_pos0 = meta[: B + 1], meta[B + 1:2 * B + 1], meta[2 * B + 1:3 * B + 1], meta[3 * B + 1:]
         h = mel_emb.to(dev, torch.float32).contiguous()
-        xn = torch.empty(Mm, D, dtype=T, device=dev)
-        qkv = torch.empty(Mm, 3 * D, dtype=T, device=dev)
-        att = torch.empty(Mm, D, dtype=T, device=dev)
-        ff = torch.empty(Mm, 4 * D, dtype=T, device=dev)
-        for i, l in enumerate(self.layers):
-            nat.layernorm(h, l["ln1"][0], l["ln1"][1], xn)
-            nat.gemm_conv(T, 1, Mm, Mm, D, 3 * D, l["w_qkv"], xn, qkv, bias=l["b_qkv"])
-            # the prompt's keys / values straight from the decode cache (itts_attn_prefill_prefix), the mel rows' from qkv
-            nat.attn_prefill_prefix(qkv, att, self.kc[i], self.vc[i], row_off, pre_len, pre_row, pre_pos0, B, max(m), H, self._cap_s,
-                                    **self._kvargs())
-            nat.gemm_conv(T, 1, Mm, Mm, D, D, l.get("w_o_merged", l["w_o"]), att, h, bias=l["b_o"], y_f32=True, resid=h)
-            nat.layernorm(h, l["ln2"][0], l["ln2"][1], xn)
-            nat.gemm_conv(T, 1, Mm, Mm, D, 4 * D, l["w_fc"], xn, ff, bias=l["b_fc"], act=1)
-            nat.gemm_conv(T, 1, Mm, Mm, 4 * D, D, l.get("w_pr_merged", l["w_pr"]), ff, h, bias=l["b_pr"], y_f32=True, resid=h)
+        kva = self._kvargs()
+        # the prompt's keys / values straight from the decode cache (itts_attn_prefill_prefix), the mel rows' from qkv
+        h = self._big_m_layers(h, lambda i, qkv, att: nat.attn_prefill_prefix(
+            qkv, att, self.kc[i], self.vc[i], row_off, pre_len, pre_row, pre_pos0, B, max(m), H, self._cap_s, **kva))
         out = torch.empty_like(h)
         nat.layernorm(h, self.ln_f[0], self.ln_f[1], out, self.final_norm[0], self.final_norm[1])
         return out
@@ -807,23 +823,16 @@ class GPTEngine:
               "pads": meta[2 * M + 3 * k + 1:2 * M + 4 * k + 1].to(torch.int32), "stops": meta[2 * M + 4 * k + 1:].to(torch.int32)}
         row_off = meta[2 * M:2 * M + k + 1].to(torch.int32)
         last = meta[2 * M + k + 1:2 * M + 2 * k + 1]
-        xn = torch.empty(M, D, dtype=T, device=dev)
-        qkv = torch.empty(M, 3, H, 64, dtype=T, device=dev)
-        att = torch.empty(M, D, dtype=T, device=dev)
-        ff = torch.empty(M, 4 * D, dtype=T, device=dev)
         kst = torch.empty(M, self.L, H, 64, dtype=T, device=dev)
         vst = torch.empty(M, self.L, H, 64, dtype=T, device=dev)
         Smax = max(lens)
-        for i, l in enumerate(self.layers):
-            nat.layernorm(h, l["ln1"][0], l["ln1"][1], xn)
-            nat.gemm_conv(T, 1, M, M, D, 3 * D, l["w_qkv"], xn, qkv.view(M, 3 * D), bias=l["b_qkv"])
-            kst[:, i] = qkv[:, 1]
-            vst[:, i] = qkv[:, 2]
-            nat.attn_prefill_packed(qkv.view(M, 3 * D), att, None, None, row_off, None, k, Smax, H, self._cap_s)
-            nat.gemm_conv(T, 1, M, M, D, D, l.get("w_o_merged", l["w_o"]), att, h, bias=l["b_o"], y_f32=True, resid=h)
-            nat.layernorm(h, l["ln2"][0], l["ln2"][1], xn)
-            nat.gemm_conv(T, 1, M, M, D, 4 * D, l["w_fc"], xn, ff, bias=l["b_fc"], act=1)
-            nat.gemm_conv(T, 1, M, M, 4 * D, D, l.get("w_pr_merged", l["w_pr"]), ff, h, bias=l["b_pr"], y_f32=True, resid=h)
+
+        def attn(i, qkv, att):     # keys / values are kept aside (they enter the cache when the rows join), plain causal attention
+            q4 = qkv.view(M, 3, H, 64)
+            kst[:, i] = q4[:, 1]
+            vst[:, i] = q4[:, 2]
+            nat.attn_prefill_packed(qkv, att, None, None, row_off, None, k, Smax, H, self._cap_s)
+        h = self._big_m_layers(h, attn)
         xn_t = torch.zeros(nat.packed_rows(k), D, dtype=T, device=dev)
         lg_t = torch.empty(k, self.V, dtype=torch.float32, device=dev)
         nat.ln_reduce(h[last].contiguous(), self.ln_f[0], self.ln_f[1], xn_t, w2=self.final_norm[0], b2=self.final_norm[1],

@@ -809,6 +809,59 @@ def test_gemm_skinny_residual_epilogue_with_packed_copy(nat, dtype, M, K, rows_p
     assert plan["grid"][2] * plan["row_tiles_per_wg"] * 16 >= min(M, 16 if dtype == torch.float32 else 96) and plan["waves"] in (8, 16)
 
 
+@pytest.mark.parametrize("M,K", [(2016, 1280), (2016, 5120), (300, 5120), (1000, 1280)])
+@pytest.mark.parametrize("ks", [2, 3])
+def test_gemm_conv_split_k_slabs_and_ln_reduce(nat, M, K, ks):
+    """Plain GEMM with split-K inside one launch (itts_conv_args.ksplit: the K slices run as separate tiles, partial products into
+    fp32 slabs) followed by itts_ln_reduce (residual + bias + slabs in order, then LayerNorm): the prefill's out-projection / FC2
+    when their 128 x 128 output tiles alone do not fill the chip.  Held against the one-launch GEMM with the residual epilogue +
+    itts_layernorm (same products, another summation order: fp32 rounding apart) and the fp64 formula."""
+    dtype, N = torch.bfloat16, 1280
+    x = rnd(M, K, seed=440).to(dtype)
+    w = (rnd(K, N, seed=441) * 0.03).to(dtype)
+    wp = nat.pack_weight(w)
+    b = rnd(N, seed=442)
+    lw, lb = 1.0 + 0.1 * rnd(N, seed=443), 0.1 * rnd(N, seed=444)
+    h0 = rnd(M, N, seed=445, scale=2.0)
+    slab = torch.zeros(ks, M, N, device=DEV)
+    nat.gemm_conv(dtype, 1, M, M, K, N, wp, x, slab, y_f32=True, ksplit=ks)
+    KT = K // 32
+    for s_ in range(ks):                                       # every slab holds its slice's partial products
+        k0, k1 = (s_ * KT) // ks * 32, ((s_ + 1) * KT) // ks * 32
+        ref_s = x[:, k0:k1].double() @ w[k0:k1].double()
+        assert (slab[s_].double() - ref_s).abs().max().item() < 2e-3 * max(1.0, ref_s.abs().max().item()), s_
+    h, xn = h0.clone(), torch.empty(M, N, dtype=dtype, device=DEV)
+    nat.ln_reduce(h, lw, lb, xn, slab=slab, nslab=ks, bias=b)
+    h1 = h0.clone()
+    nat.gemm_conv(dtype, 1, M, M, K, N, wp, x, h1, bias=b, y_f32=True, resid=h1)
+    xn1 = torch.empty(M, N, dtype=dtype, device=DEV)
+    nat.layernorm(h1, lw, lb, xn1)
+    assert (h - h1).abs().max().item() < 1e-3
+    assert (xn.float() - xn1.float()).abs().max().item() < 4e-2
+    ref = h0.double() + b.double() + x.double() @ w.double()
+    assert (h.double() - ref).abs().max().item() < 2e-3
+    with pytest.raises(nat.NativeError):                       # slabs carry no bias / residual: refused
+        nat.gemm_conv(dtype, 1, M, M, K, N, wp, x, slab, y_f32=True, ksplit=ks, bias=b)
+
+
+def test_gemm_conv_plain_wide_tiles_for_few_rows(nat):
+    """N = 5120 at the prefill's ~2 000 rows: 128 x 160 output tiles (512 of them: one round of the chip) instead of 128 x 128 (640:
+    two rounds) -- same products per output element as at a row count that takes the 128 x 128 kernel."""
+    dtype, K, N = torch.bfloat16, 1280, 5120
+    w = (rnd(K, N, seed=451) * 0.03).to(dtype)
+    wp = nat.pack_weight(w)
+    b = rnd(N, seed=452)
+    x = rnd(4000, K, seed=450).to(dtype)
+    big = torch.empty(4000, N, dtype=dtype, device=DEV)
+    nat.gemm_conv(dtype, 1, 4000, 4000, K, N, wp, x, big, bias=b, act=1)          # 32 x 40 tiles: the 128 x 128 kernel
+    for M in (2016, 1999, 2048):
+        y = torch.empty(M, N, dtype=dtype, device=DEV)
+        nat.gemm_conv(dtype, 1, M, M, K, N, wp, x[:M].contiguous(), y, bias=b, act=1)    # 16 x 32 tiles of 128 x 160
+        assert torch.equal(y, big[:M]), M
+    ref = gelu_new(x[:64].float() @ w.float() + b)
+    assert (big[:64].float() - ref).abs().max().item() < 3e-2 * max(1.0, ref.abs().max().item())
+
+
 def test_embed_step_packed_copy_bump_and_position_clamp(nat):
     """itts_embed_step: fp32 rows + the T-typed packed copy, the word it advances, per-row clocks, and the clamp of the
     position index (a finished slot that keeps stepping must not read past the table)."""
