@@ -1227,11 +1227,14 @@ static int dispatch_conv(const ConvParams& p, hipStream_t s) {
     if (g_conv_cfg == 5) return launch_plain<T, 2, 4, 8, 2>(p, s);   // 256 x 128
     // (a 256 x 128 tile with both operands through LDS and four waves of 128 x 64 was built in round 3, measured slower on every
     // shape -- 300-475 against 580-670 TFLOP/s, profiles/r03_big_gemm.txt -- and removed in round 4)
-    // Few rows (the prefill: M ~ 2 000): N = 5120 gives 16 x 40 = 640 tiles of 128 x 128 for 512 workgroup slots -- two rounds, the
-    // second a quarter full.  128 x 160 tiles (4 x 2 waves of 32 x 80) make it 16 x 32 = 512: one round.
+    // Tile shape by rounds of the chip (all tiles of a launch take the same time, so a launch costs its number of ROUNDS over the
+    // 512 workgroup slots times the tile's work): 128 x 160 tiles (4 x 2 waves of 32 x 80, 1.25x the work) where they save a round --
+    // the prefill's FC at M ~ 2 000 (640 tiles of 128 x 128 = two rounds, 512 of 128 x 160 = one), the latent pass's QKV at M ~ 4 500
+    // (1 080 = three rounds against 864 = two).
     if (p.ksplit <= 1 && p.N % 160 == 0 && p.B == 1) {
       const int64_t mb = (p.Tout + 127) / 128, slots = 2 * (int64_t)conv_num_cus();
-      if (mb * (p.N / 160) <= slots && mb * (p.N / 128) > slots) return launch_plain<T, 4, 2, 2, 5>(p, s);
+      const int64_t r128 = (mb * (p.N / 128) + slots - 1) / slots, r160 = (mb * (p.N / 160) + slots - 1) / slots;
+      if (5 * r160 < 4 * r128) return launch_plain<T, 4, 2, 2, 5>(p, s);
     }
     return launch_plain<T, 2, 4, 4, 2>(p, s);                        // 128 x 128, two workgroups per CU
   }

@@ -680,6 +680,37 @@ def test_paged_kv_long_queue_through_few_slots_in_one_loop():
                     break
 
 
+@pytest.mark.parametrize("paged", [True, False])
+def test_decode_refill_idle_slot_outlives_the_position_table_and_budget_is_checked(paged):
+    """Two findings of the round-3 review.  (1) A slot whose row has stopped and is not refilled keeps stepping formally until the
+    last row is done: its clock runs past the mel position table (803 rows) -- the embedding launch clamps the index instead of
+    reading past the table.  (2) The loop runs whole blocks of check_every steps, so the cache must hold max_new + check_every
+    positions behind the prompt: with contiguous cache rows a smaller reservation is refused (it used to spill K / V into the next
+    head's rows); the paged cache deals blocks as the loop advances."""
+    m = make_gpt(2, torch.float32)
+    eng = m.engine
+    eng.paged = paged
+    cond_mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
+    conds = m.get_conditioning(cond_mel, None)
+    text = torch.tensor([[11, 22, 33, 44, 55, 66], [77, 88, 99, 1, 1, 1]], dtype=torch.int32, device=DEV)
+    _, emb, mask = m.prepare_gpt_inputs(conds, text)
+    pad = (mask == 0).sum(1).to(torch.int32)
+    sp = dict(do_sample=False, top_p=1.0, top_k=0, temperature=1.0, repetition_penalty=10.0, seed=0)
+    max_new, ce = 806, 16
+    assert eng.mel_pos.shape[0] == 803
+    if not paged:
+        eng.prefill(emb, pad, max_new, paged=False)
+        with pytest.raises(ValueError):      # a budget of exactly prompt + max_new + 1 positions (what round 3 accepted)
+            eng.decode_refill(max_new, sp, lambda k: [], force_stop=[3, 805], check_every=ce, positions=eng._S + max_new + 1)
+    eng.prefill(emb, pad, max_new + ce, paged=paged)
+    codes, leftover = eng.decode_refill(max_new, sp, lambda k: [], force_stop=[3, 805], check_every=ce)
+    assert not leftover and len(codes) == 2
+    assert codes[0].numel() == 4 and codes[1].numel() == 806 and int(codes[1][-1]) == m.stop_mel_token
+    assert eng.refill_stats["steps"] >= 806          # slot 0 idled for ~800 steps, its position index far past the table
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.h[:2]).all()
+
+
 def test_infer_queue_equals_utterances_synthesised_one_by_one():
     """IndexTTS.infer_queue (continuous batching through 3 slots) returns, in input order, the waveforms infer_batch gives
     for each utterance alone; a tiny cache budget (several loops) changes nothing."""
