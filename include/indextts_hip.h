@@ -48,7 +48,7 @@ extern "C" {
 #define ITTS_BF16 1
 #define ITTS_F16 2
 
-#define ITTS_ABI_VERSION 7 /* 7: LayerNorm folded into the consuming skinny GEMM (ln_c), residual epilogue with a packed T copy, rows_per_wg / wide_wg, bump words in itts_gemm_skinny / itts_embed_step (+ clamp, packed copy); the reducer tail is gone; paged KV cache (kv_tab / kv_bs); 6: per-row clocks (row_step0) in itts_embed_step / itts_sample_args (slot refill), itts_attn_prefill_prefix / _shared, kv_share in itts_attn_decode; 5: itts_ln_reduce takes up to 6 slabs */
+#define ITTS_ABI_VERSION 8 /* 8: prompt front-end (itts_subsample_conv, itts_mha_small, itts_glu_dwconv_ln_silu, itts_rows, itts_geglu), ITTS_EPI_SILU_STORE, y_row0 / y_mtp and any M with rows_per_wg in itts_gemm_skinny, itts_gemm_conv ksplit <= 64; 7: LayerNorm folded into the consuming skinny GEMM (ln_c), residual epilogue with a packed T copy, rows_per_wg / wide_wg, bump words in itts_gemm_skinny / itts_embed_step (+ clamp, packed copy); the reducer tail is gone; paged KV cache (kv_tab / kv_bs); 6: per-row clocks (row_step0) in itts_embed_step / itts_sample_args (slot refill), itts_attn_prefill_prefix / _shared, kv_share in itts_attn_decode; 5: itts_ln_reduce takes up to 6 slabs */
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -106,7 +106,8 @@ int itts_aa_snake_fwd(const void* x, void* y, const float* alpha_log, const floa
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Skinny GEMM for the decode step: Y[M][N] = epi( X[M][K] @ W[K][N] + bias ), up to 96 rows (bf16/f16; 16 in fp32) per
- * pass over the weights (larger M is processed in row chunks by the entry point).  1-3 16-column tiles (x one K slice)
+ * pass over the weights (larger M is processed in row chunks by the entry point, or -- rows_per_wg > 0 -- as ONE launch
+ * whose row tiles are dealt to grid.z: the prompt front-end's ~150-row GEMMs).  1-3 16-column tiles (x one K slice)
  * per workgroup, the K range split over the workgroup's waves and reduced deterministically through LDS; every global
  * load is issued before its first use (one memory round trip per launch); 8/16-byte epilogue accesses.
  * ------------------------------------------------------------------------------------------------------------------ */
@@ -118,6 +119,7 @@ int itts_aa_snake_fwd(const void* x, void* y, const float* alpha_log, const floa
 #define ITTS_EPI_STORE_F32 4  /* yf (fp32 [M][N]) = v               (logits) */
 #define ITTS_EPI_SLAB_F32 5   /* yf (fp32 [ksplit][M][N]): slice ks stores its partial product (bias added by slice 0);
                                  the slabs are summed in order by itts_ln_reduce */
+#define ITTS_EPI_SILU_STORE 6 /* y (T [M][N]) = v * sigmoid(v)   (the Conformer's feed-forward activation) */
 
 typedef struct itts_skinny_args {
   int dtype;
@@ -151,8 +153,12 @@ typedef struct itts_skinny_args {
   const int32_t* kv_tab;
   int kv_bs;
   /* Packed-activation layout (see "Packed activation layout" above): x_packed -- x is packed [K/KS][ceil(M/16)][64][E];
-   * y_packed -- y (ITTS_EPI_STORE / ITTS_EPI_GELU_STORE / ITTS_EPI_RESID_F32, N % KS == 0) is written packed. */
+   * y_packed -- y (ITTS_EPI_STORE / ITTS_EPI_GELU_STORE / ITTS_EPI_SILU_STORE / ITTS_EPI_RESID_F32, N % KS == 0) is written packed.
+   * y_row0 / y_mtp (packed y only; 0 / 0 = the rows are the whole operand): the M rows land at rows [y_row0, y_row0 + M) of a
+   * packed operand of y_mtp row tiles (y_row0 % 16 == 0) -- the Perceiver's [latents ; context] operand is written by two GEMMs.
+   * x_mtp (packed x only; 0 = ceil(M / 16)): x is the first M rows of a packed operand of x_mtp row tiles. */
   int x_packed, y_packed;
+  int y_row0, y_mtp, x_mtp;
 } itts_skinny_args;
 int itts_gemm_skinny(const itts_skinny_args* a, void* stream);
 /* launch geometry itts_gemm_skinny would use: out8 = {grid.x, grid.y, waves per workgroup, column tiles per workgroup,
@@ -188,10 +194,10 @@ typedef struct itts_conv_args {
    * of batch element b read as zeros -- the convolution's own zero padding, so each element equals a run on its own --
    * and output tiles that only see that padding are not computed (their rows of y are left untouched). */
   const int32_t* valid_rows;
-  /* split-K of a plain GEMM (taps = 1, B = 1, N % 128 == 0; 0 / 1 = off, <= 8): the K range is cut into ksplit slices that run as
+  /* split-K of a plain GEMM (taps = 1, B = 1, N % 128 == 0; 0 / 1 = off, <= 64): the K range is cut into ksplit slices that run as
    * separate tiles of ONE launch, and y (fp32, y_f32 = 1) receives the slabs [ksplit][Tout][N] -- slice ks holds the rows' partial
    * products over its K range; no bias / bias2 / resid / accumulate / act (itts_ln_reduce sums the slabs in order, adds the bias
-   * and the residual and applies the LayerNorm that follows).  For GEMMs with few output tiles (the prefill's N = 1280 projections:
+   * and the residual and applies the LayerNorm that follows; itts_rows sums any number of them).  For GEMMs with few output tiles (the prefill's N = 1280 projections:
    * 160 tiles of 128 x 128 for 512 workgroup slots). */
   int ksplit;
 } itts_conv_args;
@@ -388,6 +394,67 @@ int itts_beam_reorder_kv(void* kcache, void* vcache, const int32_t* src, const i
 /* pcm[b][i] = trunc( clamp(32767 * tanh(x[b][i]), -32767, 32767) ) as int16; also writes fp32 wav if wav != NULL.
  * apply_tanh = 0 skips the tanh (input already in (-1,1)). */
 int itts_tanh_pcm(const void* x, float* wav, int16_t* pcm, int64_t n, int dtype, int apply_tanh, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Prompt front-end: the Conformer + Perceiver conditioner of UnifiedVoice.get_conditioning (indextts/gpt/model.py:487-546;
+ * conformer_encoder.py:167-290,360-386, conformer/subsampling.py:111-143, conformer/attention.py, perceiver.py:181-312) as a
+ * chain of these launches and LayerNorm-folded itts_gemm_skinny calls over one prompt (~150 rows): bf16 / f16 only, fp32
+ * residual stream, every GEMM operand in the packed activation layout.  The host side is indextts/gpt/conditioner.py.
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* y (T [T2][C * F2], T2 = (T-3)/2+1, F2 = (F-3)/2+1) = relu(Conv2d(1, C, 3, stride 2)(mel [T][F])) laid out as the operand of
+ * the Linear(C * F2 -> d) that follows: element (t, c * F2 + f).  w [C][9], b [C] fp32.  (C * F2) % 8 == 0. */
+int itts_subsample_conv(const float* mel, const float* w, const float* b, void* y, int T, int F, int C, int dtype, void* stream);
+
+/* Multi-head attention over a short sequence, head dim 64:  out[i] = softmax_j( scale * ((q_i + u) . k_j + (q_i + v) . p_j) ) v_j
+ * for i < Tq, j < Tk.  q / k / v: T rows with the given strides (elements, multiples of 8), head h at columns [64 h, 64 h + 64).
+ * pos (T [H][Tk][64], the layer's projected position table) with bias_u / bias_v (fp32 [H * 64]) = the Conformer's relative-
+ * position attention WITHOUT rel_shift; pos = NULL: plain attention (the term and the biases are absent).  out: T in the packed
+ * activation layout of a [Tq][H * 64] operand with out_mtp row tiles. */
+typedef struct itts_mha_args {
+  int dtype;
+  int Tq, Tk, H;
+  const void* q;
+  const void* k;
+  const void* v;
+  int64_t q_stride, k_stride, v_stride;
+  const void* pos;
+  const float* bias_u;
+  const float* bias_v;
+  float scale;
+  void* out;
+  int out_mtp;
+} itts_mha_args;
+int itts_mha_small(const itts_mha_args* a, void* stream);
+
+/* The Conformer convolution module between its pointwise convolutions: x (T [T][2 C], value | gate) -> GLU -> depthwise
+ * Conv1d(taps, zero "same" padding; w fp32 [C][taps], b [C]) -> LayerNorm(ln_w, ln_b, eps) -> SiLU -> y (T, packed layout of
+ * [T][C] with y_mtp row tiles).  C % 128 == 0, C <= 2048; taps 7 / 15 / 31. */
+int itts_glu_dwconv_ln_silu(const void* x, const float* w, const float* b, const float* ln_w, const float* ln_b, void* y, int T,
+                            int C, int taps, int y_mtp, float eps, int dtype, void* stream);
+
+/* Row operations on an fp32 residual stream [M][D] (D % 4 == 0, D <= 2048):
+ *   v = (x ? x[m] : 0) + (bias ? bias : 0) + slab[0][m] + ... + slab[nslab-1][m]       (fixed order; slab fp32 [nslab][M][D])
+ *   norm 1: v = LayerNorm(v; w, b, eps)     norm 2: v = v / max(|v|_2, 1e-12) * sqrt(D) * w     norm 0: as is
+ *   y (fp32 [M][D], may alias x, or NULL) = v;   y_packed (T, or NULL): rows [y_row0, y_row0 + M) of a packed operand of y_mtp
+ *   row tiles (0 = ceil(M / 16)).  */
+typedef struct itts_rows_args {
+  int dtype, M, D;
+  const float* x;
+  const float* slab;
+  int nslab;
+  const float* bias;
+  int norm;
+  const float* w;
+  const float* b;
+  float eps;
+  float* y;
+  void* y_packed;
+  int y_row0, y_mtp;
+} itts_rows_args;
+int itts_rows(const itts_rows_args* a, void* stream);
+
+/* y (T, packed layout of [M][Kp], y_mtp row tiles, 0 = ceil(M / 16)) = gelu(h[:, Kp:]) * h[:, :Kp]  (erf gelu; h T [M][2 Kp]). */
+int itts_geglu(const void* h, void* y, int M, int Kp, int y_mtp, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

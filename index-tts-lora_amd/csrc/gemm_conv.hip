@@ -1320,7 +1320,7 @@ static int conv_params_from_args(const itts_conv_args* a, ConvParams& p, const c
   p.ksplit = a->ksplit > 1 ? a->ksplit : 1;
   if (p.ksplit > 1 && !(a->taps == 1 && a->N % 128 == 0 && a->B == 1 && a->y_f32 && a->bias == nullptr && a->bias2 == nullptr &&
                         a->resid == nullptr && !a->accumulate && a->act == 0 && a->valid_rows == nullptr && a->off0 == 0 &&
-                        a->Tin == a->Tout && a->Cin % ks == 0 && p.ksplit <= p.KT && p.ksplit <= 8)) {
+                        a->Tin == a->Tout && a->Cin % ks == 0 && p.ksplit <= p.KT && p.ksplit <= 64)) {
     set_error("%s: ksplit > 1 is for the plain GEMM (taps 1, N %% 128 == 0, B 1, fp32 y = slabs, no bias / residual / activation)", who);
     return ITTS_ERR_INVALID;
   }

@@ -65,6 +65,7 @@ struct SkinnyParams {
   int32_t* bump;           // one device word this launch increments (it must not read it)
   int x_pa, y_pa;          // packed-activation layout for x / y
   int mtp, row0;           // row tiles of the WHOLE operand, first row of this launch (a multiple of 16)
+  int y_mtp, y_row0;       // the same for a packed y (the rows may land inside a taller packed operand)
 #if ITTS_STAMPS
   unsigned long long* stamps;
 #endif
@@ -361,11 +362,17 @@ __global__ __launch_bounds__(MAXW * 64) void gemm_skinny_kernel(SkinnyParams p) 
     const int nval = min(4, p.N - col0);
     switch (p.epi) {
       case ITTS_EPI_STORE:
-        store4<T>((T*)p.y + (p.y_pa ? pa_off<T>(p.row0 + row, col0, p.mtp) : (int64_t)row * p.N + col0), v, nval);
+        store4<T>((T*)p.y + (p.y_pa ? pa_off<T>(p.y_row0 + row, col0, p.y_mtp) : (int64_t)row * p.N + col0), v, nval);
         break;
       case ITTS_EPI_GELU_STORE: {
         f32x4 gv = {gelu_new(v[0]), gelu_new(v[1]), gelu_new(v[2]), gelu_new(v[3])};
-        store4<T>((T*)p.y + (p.y_pa ? pa_off<T>(p.row0 + row, col0, p.mtp) : (int64_t)row * p.N + col0), gv, nval);
+        store4<T>((T*)p.y + (p.y_pa ? pa_off<T>(p.y_row0 + row, col0, p.y_mtp) : (int64_t)row * p.N + col0), gv, nval);
+      } break;
+      case ITTS_EPI_SILU_STORE: {
+        f32x4 sv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sv[e] = v[e] / (1.f + __expf(-v[e]));
+        store4<T>((T*)p.y + (p.y_pa ? pa_off<T>(p.y_row0 + row, col0, p.y_mtp) : (int64_t)row * p.N + col0), sv, nval);
       } break;
       case ITTS_EPI_RESID_F32: {
         // residual stream update, one owner per element (no split-K): the old values were requested with the bias.  The
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(MAXW * 64) void gemm_skinny_kernel(SkinnyParams p) 
           const f32x4 nv = p2 + v;
           store4<float>(p.yf + (int64_t)row * p.N + col0, nv, nval);
           if (p.y != nullptr)
-            store4<T>((T*)p.y + (p.y_pa ? pa_off<T>(p.row0 + row, col0, p.mtp) : (int64_t)row * p.N + col0), nv, nval);
+            store4<T>((T*)p.y + (p.y_pa ? pa_off<T>(p.y_row0 + row, col0, p.y_mtp) : (int64_t)row * p.N + col0), nv, nval);
         }
       } break;
       case ITTS_EPI_STORE_F32:
@@ -530,7 +537,7 @@ static void launch_skinny_mt(const SkinnyParams& p, const SkinnyPlan& q, hipStre
 template <typename T>
 static int launch_skinny(const SkinnyParams& p, int rows_per_wg, bool wide, hipStream_t s) {
   const bool fold = p.cvec != nullptr;
-  const int MTall = p.M <= 16 ? 1 : p.M <= 32 ? 2 : p.M <= 64 ? 4 : 6;
+  const int MTall = p.M <= 16 ? 1 : p.M <= 32 ? 2 : p.M <= 64 ? 4 : p.M <= 96 ? 6 : (p.M + 15) / 16;   // > 96: rows dealt to grid.z
   const SkinnyPlan q = plan_skinny<T>(p.N, p.K, p.ksplit, MTall, rows_per_wg, wide && !fold, fold);
   if constexpr (sizeof(T) == 4) {
     if (fold) {
@@ -573,7 +580,8 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
   else if (a->epi == ITTS_EPI_RESID_F32 || a->epi == ITTS_EPI_STORE_F32 || a->epi == ITTS_EPI_SLAB_F32)
     ITTS_REQUIRE(a->yf, "itts_gemm_skinny: yf is null");
   else
-    ITTS_REQUIRE((a->epi == ITTS_EPI_STORE || a->epi == ITTS_EPI_GELU_STORE) && a->y, "itts_gemm_skinny: bad epilogue %d", a->epi);
+    ITTS_REQUIRE((a->epi == ITTS_EPI_STORE || a->epi == ITTS_EPI_GELU_STORE || a->epi == ITTS_EPI_SILU_STORE) && a->y,
+                 "itts_gemm_skinny: bad epilogue %d", a->epi);
   if (a->epi == ITTS_EPI_RESID_F32)
     ITTS_REQUIRE(a->N % 4 == 0 && (int64_t)a->M * a->N < (1ll << 29), "itts_gemm_skinny: the residual epilogue needs N %% 4 == 0");
   if (a->ln_c != nullptr)
@@ -582,10 +590,18 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
                  "itts_gemm_skinny: the LayerNorm-folded form needs ksplit 1, bias (= d), N %% 4 == 0, a storing epilogue, bf16 / f16");
   ITTS_REQUIRE(a->rows_per_wg == 0 || a->rows_per_wg == 16 || a->rows_per_wg == 32, "itts_gemm_skinny: rows_per_wg must be 0, 16 or 32");
   if (a->y_packed)
-    ITTS_REQUIRE((a->epi == ITTS_EPI_STORE || a->epi == ITTS_EPI_GELU_STORE || a->epi == ITTS_EPI_RESID_F32) && a->N % ks == 0 && a->y,
-                 "itts_gemm_skinny: a packed y needs the STORE / GELU_STORE / RESID_F32 epilogue and N %% %d == 0", ks);
+    ITTS_REQUIRE((a->epi == ITTS_EPI_STORE || a->epi == ITTS_EPI_GELU_STORE || a->epi == ITTS_EPI_SILU_STORE ||
+                  a->epi == ITTS_EPI_RESID_F32) && a->N % ks == 0 && a->y,
+                 "itts_gemm_skinny: a packed y needs the STORE / GELU_STORE / SILU_STORE / RESID_F32 epilogue and N %% %d == 0", ks);
+  const int y_mtp = a->y_mtp > 0 ? a->y_mtp : (a->M + 15) / 16;
+  ITTS_REQUIRE(a->y_row0 >= 0 && a->y_row0 % 16 == 0 && (!a->y_packed || a->y_row0 + a->M <= y_mtp * 16) &&
+                   (a->y_packed || (a->y_row0 == 0 && a->y_mtp == 0)),
+               "itts_gemm_skinny: y_row0 / y_mtp place the rows of a PACKED y inside a taller operand (y_row0 %% 16 == 0)");
+  ITTS_REQUIRE(a->x_mtp == 0 || (a->x_packed && a->x_mtp * 16 >= a->M), "itts_gemm_skinny: x_mtp is for a packed x of at least M rows");
   if (a->M == 0) return ITTS_OK;
-  const int rows_per = (a->dtype == ITTS_F32) ? 16 : 96;
+  // one launch covers 96 rows per workgroup; with rows_per_wg > 0 the row tiles are dealt to grid.z and any M runs as one launch
+  const int rows_per = (a->dtype == ITTS_F32) ? 16 : (a->rows_per_wg > 0 ? (a->M > 96 ? a->M : 96) : 96);
+  ITTS_REQUIRE(a->M <= 96 || a->rows_per_wg == 0 || (a->M + 15) / 16 / (a->rows_per_wg / 16) < 65535, "itts_gemm_skinny: too many rows");
   hipStream_t s = (hipStream_t)stream;
   for (int r0 = 0; r0 < a->M; r0 += rows_per) {
     SkinnyParams p;
@@ -597,8 +613,10 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
     p.x = a->x_packed ? (const char*)a->x : (const char*)a->x + (size_t)r0 * a->K * esz;
     p.x_pa = a->x_packed ? 1 : 0;
     p.y_pa = a->y_packed ? 1 : 0;
-    p.mtp = (a->M + 15) / 16;
+    p.mtp = a->x_mtp > 0 ? a->x_mtp : (a->M + 15) / 16;
     p.row0 = r0;
+    p.y_mtp = y_mtp;
+    p.y_row0 = r0 + a->y_row0;
     p.epi = a->epi;
     const size_t ycols = a->epi == ITTS_EPI_QKV_CACHE ? (size_t)a->N / 3 : (size_t)a->N;
     p.y = a->y ? (a->y_packed ? (char*)a->y : (char*)a->y + (size_t)r0 * ycols * esz) : nullptr;
@@ -635,7 +653,7 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
 
 extern "C" int itts_skinny_plan(int dtype, int M, int N, int K, int ksplit, int rows_per_wg, int wide_wg, int fold, int* out8) {
   ITTS_REQUIRE(out8 && N > 0 && K > 0 && ksplit > 0 && M > 0, "itts_skinny_plan: bad arguments");
-  const int MT = dtype == ITTS_F32 ? 1 : M <= 16 ? 1 : M <= 32 ? 2 : M <= 64 ? 4 : 6;
+  const int MT = dtype == ITTS_F32 ? 1 : M <= 16 ? 1 : M <= 32 ? 2 : M <= 64 ? 4 : (M <= 96 || rows_per_wg == 0) ? 6 : (M + 15) / 16;
   const SkinnyPlan q = dtype == ITTS_F32 ? plan_skinny<float>(N, K, ksplit, 1, 0, false, false)
                                          : plan_skinny<bf16_t>(N, K, ksplit, MT, rows_per_wg, wide_wg != 0 && !fold, fold != 0);
   out8[0] = q.gx; out8[1] = q.gy; out8[2] = q.NW; out8[3] = q.ntb; out8[4] = q.spw; out8[5] = (int)q.lds; out8[6] = q.gz; out8[7] = q.MT;

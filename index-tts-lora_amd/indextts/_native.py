@@ -12,7 +12,7 @@ import threading
 import torch
 
 F32, BF16, F16 = 0, 1, 2
-EPI_STORE, EPI_GELU_STORE, EPI_RESID_F32, EPI_QKV_CACHE, EPI_STORE_F32, EPI_SLAB_F32 = 0, 1, 2, 3, 4, 5
+EPI_STORE, EPI_GELU_STORE, EPI_RESID_F32, EPI_QKV_CACHE, EPI_STORE_F32, EPI_SLAB_F32, EPI_SILU_STORE = 0, 1, 2, 3, 4, 5, 6
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libindextts_hip.so")
@@ -30,7 +30,19 @@ class SkinnyArgs(C.Structure):
                 ("kcache", C.c_void_p), ("vcache", C.c_void_p), ("pos", C.c_void_p), ("heads", C.c_int),
                 ("smax", C.c_int), ("ksplit", C.c_int), ("ln_c", C.c_void_p), ("ln_eps", C.c_float), ("bump", C.c_void_p),
                 ("rows_per_wg", C.c_int), ("wide_wg", C.c_int), ("kv_tab", C.c_void_p), ("kv_bs", C.c_int),
-                ("x_packed", C.c_int), ("y_packed", C.c_int)]
+                ("x_packed", C.c_int), ("y_packed", C.c_int), ("y_row0", C.c_int), ("y_mtp", C.c_int), ("x_mtp", C.c_int)]
+
+
+class MhaArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("Tq", C.c_int), ("Tk", C.c_int), ("H", C.c_int), ("q", C.c_void_p), ("k", C.c_void_p),
+                ("v", C.c_void_p), ("q_stride", C.c_int64), ("k_stride", C.c_int64), ("v_stride", C.c_int64), ("pos", C.c_void_p),
+                ("bias_u", C.c_void_p), ("bias_v", C.c_void_p), ("scale", C.c_float), ("out", C.c_void_p), ("out_mtp", C.c_int)]
+
+
+class RowsArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("M", C.c_int), ("D", C.c_int), ("x", C.c_void_p), ("slab", C.c_void_p), ("nslab", C.c_int),
+                ("bias", C.c_void_p), ("norm", C.c_int), ("w", C.c_void_p), ("b", C.c_void_p), ("eps", C.c_float),
+                ("y", C.c_void_p), ("y_packed", C.c_void_p), ("y_row0", C.c_int), ("y_mtp", C.c_int)]
 
 
 class LnReduceArgs(C.Structure):
@@ -105,6 +117,12 @@ _SIGNATURES = {
     "itts_beam_reorder_kv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int64, C.c_int, C.c_void_p]),
     "itts_tanh_pcm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "itts_subsample_conv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "itts_mha_small": (C.c_int, [C.POINTER(MhaArgs), C.c_void_p]),
+    "itts_glu_dwconv_ln_silu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "itts_rows": (C.c_int, [C.POINTER(RowsArgs), C.c_void_p]),
+    "itts_geglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -124,7 +142,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.itts_abi_version() != 7:
+        if L.itts_abi_version() != 8:
             raise NativeError("libindextts_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -207,10 +225,12 @@ def aa_snake(x, alpha_log, beta_log, up_f, down_f, layout=0, out=None, valid_row
 
 def gemm_skinny(dtype, M, N, K, wp, bias=None, x=None, epi=EPI_STORE, y=None, yf=None, kcache=None, vcache=None, pos=None,
                 heads=0, smax=0, ksplit=1, x_packed=False, y_packed=False, ln_c=None, ln_eps=1e-5, bump=None, rows_per_wg=0,
-                wide_wg=False, kv_tab=None, kv_bs=0):
+                wide_wg=False, kv_tab=None, kv_bs=0, y_row0=0, y_mtp=0, x_mtp=0):
     """ln_c fp32 [N]: LayerNorm folded into the GEMM -- x holds the RAW rows, wp = pack(gamma . W), bias = beta W + b
     (see itts_skinny_args).  EPI_RESID_F32: yf += x W + bias, and y (optional, T) receives a copy of the new rows.
-    bump: int32 device word the launch increments.  rows_per_wg / wide_wg: launch-geometry hints."""
+    bump: int32 device word the launch increments.  rows_per_wg / wide_wg: launch-geometry hints.
+    y_row0 / y_mtp: a packed y's rows land at [y_row0, y_row0 + M) of an operand of y_mtp row tiles; x_mtp: a packed x is the
+    first M rows of an operand of x_mtp row tiles."""
     a = SkinnyArgs()
     a.dtype, a.M, a.N, a.K = dt(dtype), M, N, K
     a.wp, a.bias, a.x = _p(wp), _p(bias), _p(x)
@@ -220,7 +240,56 @@ def gemm_skinny(dtype, M, N, K, wp, bias=None, x=None, epi=EPI_STORE, y=None, yf
     a.ln_c, a.ln_eps, a.bump = _p(ln_c), float(ln_eps), _p(bump)
     a.rows_per_wg, a.wide_wg = int(rows_per_wg), int(bool(wide_wg))
     a.kv_tab, a.kv_bs = _p(kv_tab), int(kv_bs)
+    a.y_row0, a.y_mtp, a.x_mtp = int(y_row0), int(y_mtp), int(x_mtp)
     _check(lib().itts_gemm_skinny(C.byref(a), _stream()), "itts_gemm_skinny")
+
+
+def subsample_conv(mel, w, b, y):
+    """mel fp32 [T, F], w fp32 [C, 9], b [C] -> y T [T2, C * F2] = relu(conv2d 3x3 stride 2), laid out for the Linear behind it."""
+    _dev(mel, w, b, y)
+    T, Fq = mel.shape
+    _check(lib().itts_subsample_conv(_p(mel), _p(w), _p(b), _p(y), T, Fq, w.shape[0], dt(y.dtype), _stream()), "itts_subsample_conv")
+    return y
+
+
+def mha_small(q, k, v, out, Tq, Tk, H, q_stride, k_stride, v_stride, out_mtp, scale, pos=None, bias_u=None, bias_v=None):
+    """Short-sequence attention (head dim 64) into the packed layout; pos / bias_u / bias_v: the Conformer's relative-position term.
+    q / k / v may be views into one buffer (pointer + row stride in elements)."""
+    a = MhaArgs()
+    a.dtype, a.Tq, a.Tk, a.H = dt(out.dtype), Tq, Tk, H
+    a.q, a.k, a.v = _p(q), _p(k), _p(v)
+    a.q_stride, a.k_stride, a.v_stride = q_stride, k_stride, v_stride
+    a.pos, a.bias_u, a.bias_v = _p(pos), _p(bias_u), _p(bias_v)
+    a.scale, a.out, a.out_mtp = float(scale), _p(out), int(out_mtp)
+    _check(lib().itts_mha_small(C.byref(a), _stream()), "itts_mha_small")
+    return out
+
+
+def glu_dwconv_ln_silu(x, w, b, ln_w, ln_b, y, T, Cn, y_mtp, eps=1e-5):
+    """x T [T, 2C] -> GLU -> depthwise conv (w fp32 [C, taps]) -> LayerNorm -> SiLU -> y T packed [T, C]."""
+    _dev(x, w, b, ln_w, ln_b, y)
+    _check(lib().itts_glu_dwconv_ln_silu(_p(x), _p(w), _p(b), _p(ln_w), _p(ln_b), _p(y), T, Cn, w.shape[1], int(y_mtp), float(eps),
+                                         dt(y.dtype), _stream()), "itts_glu_dwconv_ln_silu")
+    return y
+
+
+def rows(M, D, dtype, x=None, slab=None, nslab=0, bias=None, norm=0, w=None, b=None, eps=1e-5, y=None, y_packed=None, y_row0=0,
+         y_mtp=0):
+    """Row operations on an fp32 stream: (x) + bias + sum(slabs) -> [LayerNorm | l2-normalise * sqrt(D) * w] -> y fp32 and / or a
+    packed T copy (itts_rows)."""
+    a = RowsArgs()
+    a.dtype, a.M, a.D = dt(dtype), M, D
+    a.x, a.slab, a.nslab, a.bias = _p(x), _p(slab), int(nslab), _p(bias)
+    a.norm, a.w, a.b, a.eps = int(norm), _p(w), _p(b), float(eps)
+    a.y, a.y_packed, a.y_row0, a.y_mtp = _p(y), _p(y_packed), int(y_row0), int(y_mtp)
+    _check(lib().itts_rows(C.byref(a), _stream()), "itts_rows")
+
+
+def geglu(h, y, M, Kp, y_mtp=0):
+    """h T [M, 2 Kp] (x | gate) -> y T packed [M, Kp] = gelu(gate) * x."""
+    _dev(h, y)
+    _check(lib().itts_geglu(_p(h), _p(y), M, Kp, int(y_mtp), dt(y.dtype), _stream()), "itts_geglu")
+    return y
 
 
 def packed_rows(M: int) -> int:

@@ -8,11 +8,13 @@ conditioner is host-side PyTorch-ROCm.  Training paths (losses, LoRA) are out of
 """
 from __future__ import annotations
 
+import os
 import warnings
 
 import torch
 import torch.nn.functional as F
 
+from .conditioner import ConditionerEngine
 from .conformer_encoder import conformer_encode
 from .engine import GPTEngine
 from .perceiver import perceiver_resample
@@ -42,13 +44,14 @@ class UnifiedVoice:
         self.dtype = torch.float32
         self._sd = {}
         self._cond_w = None
+        self._cond_engine = None
         self.engine: GPTEngine | None = None
         self.inference_model = None
 
     # ---- nn.Module-like surface -------------------------------------------------------------------------------
     def load_state_dict(self, sd, strict=False):
         self._sd = {k: v.detach() for k, v in sd.items() if not k.startswith("inference_model.")}
-        self._cond_w, self.engine = None, None
+        self._cond_w, self._cond_engine, self.engine = None, None, None
         return self
 
     def state_dict(self):
@@ -63,7 +66,7 @@ class UnifiedVoice:
                 self.dtype = a
             elif isinstance(a, (str, torch.device)):
                 self.device = torch.device(a)
-        self._cond_w, self.engine = None, None
+        self._cond_w, self._cond_engine, self.engine = None, None, None
         return self
 
     def half(self):
@@ -99,6 +102,17 @@ class UnifiedVoice:
                             if k.startswith(("conditioning_encoder.", "perceiver_encoder.")) and not k.endswith("pos_enc.pe")}
         return self._cond_w
 
+    def conditioner(self):
+        """The Conformer + Perceiver conditioner on the HIP kernels (gpt/conditioner.py), or None in fp32 mode: a 16-bit model
+        (the benched and the reference's GPU default precision) runs it in fp16 -- normalised activations, fp32 residual stream --
+        whatever the transformer's 16-bit type is; fp32 keeps the functional PyTorch form, the parity mode."""
+        if self.dtype == torch.float32 or self.device.type != "cuda" or os.environ.get("ITTS_NATIVE_CONDITIONER", "1") == "0":
+            return None
+        if self._cond_engine is None:
+            self._cond_engine = ConditionerEngine(self._cond_weights(), heads=int(self.condition_module.get("attention_heads", 8)),
+                                                  dtype=torch.float16, device=self.device)
+        return self._cond_engine
+
     # ---- conditioning / prefix --------------------------------------------------------------------------------
     def get_conditioning(self, speech_conditioning_input, cond_mel_lengths=None, speaker_ids=None):
         """model.py:487-546 (conformer_perceiver branch, plus the stored mean_condition_{id} shortcut)."""
@@ -116,6 +130,10 @@ class UnifiedVoice:
         mel = speech_conditioning_input.to(self.device, torch.float32)
         if mel.ndim == 2:
             mel = mel[None]
+        eng = self.conditioner() if cond_mel_lengths is None else None
+        if eng is not None:                  # unpadded prompts: the HIP conditioner, one prompt per pass
+            rows = mel.transpose(1, 2).contiguous()
+            return torch.stack([eng(rows[i]).clone() for i in range(rows.shape[0])], 0)
         W = self._cond_weights()
         # cond_mel_lengths = None: every row is as long as the tensor (model.py:491 builds exactly that) -- no padding, the
         # mask operations of the two networks are identities and are skipped

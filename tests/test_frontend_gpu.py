@@ -1,0 +1,223 @@
+"""The prompt front-end on the HIP kernels (csrc/frontend.hip + gpt/conditioner.py): each kernel against a plain PyTorch fp32
+statement of the same operation, and the whole Conformer + Perceiver conditioner against (a) the functional fp32 form of this
+package, which the reference-run fixture pins to 1e-3, and (b) that fixture itself.
+
+Tolerances: the kernels store fp16 / bf16 and accumulate in fp32 -- a kernel is held to a few units of its storage type's
+resolution on O(1) values (fp16 2^-11, bf16 2^-8); the whole fp16 conditioner to 1e-2 max-abs on latents of RMS ~1."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import synth
+import weights
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda"
+RES = {torch.float16: 2.0 ** -11, torch.bfloat16: 2.0 ** -8}
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("T,Fq,C", [(300, 100, 512), (41, 20, 64), (3, 5, 8)])
+def test_subsample_conv_matches_conv2d(dtype, T, Fq, C):
+    from indextts import _native as nat
+    mel = rnd(T, Fq, seed=1, scale=2.0)
+    w, b = rnd(C, 9, seed=2, scale=0.3), rnd(C, seed=3, scale=0.1)
+    t, f2 = (T - 3) // 2 + 1, (Fq - 3) // 2 + 1
+    y = torch.empty(t, C * f2, dtype=dtype, device=DEV)
+    nat.subsample_conv(mel, w, b, y)
+    ref = F.relu(F.conv2d(mel[None, None], w.view(C, 1, 3, 3), b, stride=2))[0]          # [C, t, f2]
+    ref = ref.permute(1, 0, 2).reshape(t, C * f2)
+    assert (y.float() - ref).abs().max().item() <= 2 * RES[dtype] * max(1.0, ref.abs().max().item())
+
+
+def mha_ref(q, k, v, H, scale, pos=None, u=None, vb=None):
+    Tq, Tk = q.shape[0], k.shape[0]
+    qh = q.float().view(Tq, H, 64).transpose(0, 1)
+    kh = k.float().view(Tk, H, 64).transpose(0, 1)
+    vh = v.float().view(Tk, H, 64).transpose(0, 1)
+    if pos is None:
+        sc = qh @ kh.transpose(-1, -2)
+    else:
+        sc = (qh + u.view(H, 1, 64)) @ kh.transpose(-1, -2) + (qh + vb.view(H, 1, 64)) @ pos.float().transpose(-1, -2)
+    return (torch.softmax(sc * scale, -1) @ vh).transpose(0, 1).reshape(Tq, H * 64)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Tq,Tk,H,rel", [(149, 149, 8, True), (32, 181, 8, False), (5, 5, 2, True), (70, 450, 3, True),
+                                         (16, 193, 1, False), (1, 1, 1, False)])
+def test_mha_small_matches_torch(dtype, Tq, Tk, H, rel):
+    """Keys past one 192-row LDS chunk, ragged last 32-key step, one-row edge; with and without the relative-position term."""
+    from indextts import _native as nat
+    d = H * 64
+    buf = (rnd(max(Tq, Tk), 3 * d, seed=5) * 0.7).to(dtype)
+    q, k, v = buf[:Tq, :d], buf[:Tk, d:2 * d], buf[:Tk, 2 * d:]
+    pos = (rnd(H, Tk, 64, seed=6) * 0.5).to(dtype) if rel else None
+    u, vb = (rnd(d, seed=7) * 0.2, rnd(d, seed=8) * 0.2) if rel else (None, None)
+    mtp = (Tq + 15) // 16
+    out = torch.zeros(mtp * 16 * d, dtype=dtype, device=DEV)
+    nat.mha_small(buf, buf[:, d:], buf[:, 2 * d:], out, Tq, Tk, H, 3 * d, 3 * d, 3 * d, mtp, 0.125, pos=pos, bias_u=u, bias_v=vb)
+    got = nat.unpack_activation(out, Tq, d).float()
+    ref = mha_ref(q, k, v, H, 0.125, pos, u, vb)
+    assert torch.isfinite(got).all()
+    # probabilities and q + u are rounded to the storage type before their products
+    assert (got - ref).abs().max().item() <= 12 * RES[dtype] * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("T,C,taps", [(149, 512, 15), (9, 128, 15), (40, 256, 7), (33, 128, 31)])
+def test_glu_dwconv_ln_silu_matches_torch(dtype, T, C, taps):
+    from indextts import _native as nat
+    x = rnd(T, 2 * C, seed=9).to(dtype)
+    w, b = rnd(C, taps, seed=10, scale=0.3), rnd(C, seed=11, scale=0.1)
+    lw, lb = 1.0 + rnd(C, seed=12, scale=0.1), rnd(C, seed=13, scale=0.1)
+    mtp = (T + 15) // 16
+    y = torch.zeros(mtp * 16 * C, dtype=dtype, device=DEV)
+    nat.glu_dwconv_ln_silu(x, w, b, lw, lb, y, T, C, mtp)
+    g = F.glu(x.float().t()[None], dim=1)                                               # [1, C, T]
+    c = F.conv1d(g, w[:, None, :], b, padding=(taps - 1) // 2, groups=C)[0].t()           # [T, C]
+    ref = F.silu(F.layer_norm(c, (C,), lw, lb, 1e-5))
+    got = nat.unpack_activation(y, T, C).float()
+    assert (got - ref).abs().max().item() <= 4 * RES[dtype] * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_rows_modes(dtype):
+    from indextts import _native as nat
+    M, D = 37, 1280
+    x = rnd(M, D, seed=14)
+    slab = rnd(5, M, D, seed=15)
+    bias, w, b = rnd(D, seed=16), 1.0 + rnd(D, seed=17, scale=0.1), rnd(D, seed=18, scale=0.1)
+    # slabs + bias (no x), packed copy inside a taller operand
+    y = torch.empty(M, D, device=DEV)
+    yp = torch.zeros(5 * 16 * D, dtype=dtype, device=DEV)
+    nat.rows(M, D, dtype, slab=slab, nslab=5, bias=bias, y=y, y_packed=yp, y_row0=32, y_mtp=5)
+    ref = bias + slab.sum(0)
+    assert (y - ref).abs().max().item() < 1e-5
+    up = nat.unpack_activation(yp, 80, D)
+    assert torch.equal(up[32:32 + M], ref.to(dtype)) or (up[32:32 + M].float() - ref).abs().max().item() <= RES[dtype] * 8
+    assert (up[:32] == 0).all() and (up[32 + M:] == 0).all()
+    # LayerNorm in place
+    xi = x.clone()
+    nat.rows(M, D, dtype, x=xi, norm=1, w=w, b=b, y=xi)
+    assert (xi - F.layer_norm(x, (D,), w, b, 1e-5)).abs().max().item() < 1e-4
+    # l2-normalise * sqrt(D) * gamma
+    out = torch.empty(M, D, device=DEV)
+    nat.rows(M, D, dtype, x=x, norm=2, w=w, y=out)
+    assert (out - F.normalize(x, dim=-1) * math.sqrt(D) * w).abs().max().item() < 1e-4
+    with pytest.raises(nat.NativeError):
+        nat.rows(M, 2052, dtype, x=x, y=out)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_geglu(dtype):
+    from indextts import _native as nat
+    M, Kp = 32, 3424
+    h = rnd(M, 2 * Kp, seed=19).to(dtype)
+    y = torch.zeros(M * Kp, dtype=dtype, device=DEV)
+    nat.geglu(h, y, M, Kp)
+    ref = F.gelu(h[:, Kp:].float()) * h[:, :Kp].float()
+    assert (nat.unpack_activation(y, M, Kp).float() - ref).abs().max().item() <= 2 * RES[dtype] * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_skinny_many_rows_one_launch(dtype):
+    """M = 149 rows with the row tiles dealt to grid.z (one launch): LayerNorm-folded + SiLU into a packed y at a row offset,
+    the residual epilogue, and a packed x that is the head of a taller operand (x_mtp)."""
+    from indextts import _native as nat
+    from indextts.gpt.conditioner import _fold
+    M, K, N = 149, 512, 2048
+    x = rnd(M, K, seed=20) * 3.0 + 1.5
+    W, bias = rnd(K, N, seed=21, scale=K ** -0.5), rnd(N, seed=22, scale=0.1)
+    gamma, beta = 1.0 + rnd(K, seed=23, scale=0.1), rnd(K, seed=24, scale=0.1)
+    wp, c, d = _fold(W, bias, gamma, beta, dtype)
+    xp = nat.pack_activation(x.to(dtype))
+    mt_all = 14
+    y = torch.zeros(mt_all * 16 * N, dtype=dtype, device=DEV)
+    nat.gemm_skinny(dtype, M, N, K, wp, d, x=xp, epi=nat.EPI_SILU_STORE, y=y, x_packed=True, y_packed=True, ln_c=c, rows_per_wg=32,
+                    y_row0=32, y_mtp=mt_all)
+    ref = F.silu(F.layer_norm(x.to(dtype).float(), (K,), gamma, beta, 1e-5) @ W + bias)
+    got = nat.unpack_activation(y, mt_all * 16, N)
+    assert (got[32:32 + M].float() - ref).abs().max().item() <= 16 * RES[dtype] * max(1.0, ref.abs().max().item())
+    assert (got[:32] == 0).all() and (got[32 + M + 16:] == 0).all()
+    pl = nat.skinny_plan(dtype, M, N, K, 1, 32, False, True)
+    assert pl["grid"][2] == 5 and pl["row_tiles_per_wg"] == 2
+    # residual epilogue over the same rows, unfolded weight; x = the first 149 rows of a 12-tile operand
+    wp2 = nat.pack_weight(W[:, :512].to(dtype).contiguous())
+    big = torch.zeros(12 * 16, K, dtype=dtype, device=DEV)
+    big[:M] = x.to(dtype)
+    big[M:] = 7.0
+    h = rnd(M, 512, seed=25)
+    h0 = h.clone()
+    hb = torch.zeros(10 * 16 * 512, dtype=dtype, device=DEV)
+    nat.gemm_skinny(dtype, M, 512, K, wp2, bias[:512].contiguous(), x=nat.pack_activation(big), epi=nat.EPI_RESID_F32, yf=h, y=hb,
+                    x_packed=True, y_packed=True, rows_per_wg=32, x_mtp=12)
+    ref2 = h0 + x.to(dtype).float() @ W[:, :512].to(dtype).float() + bias[:512]
+    assert (h - ref2).abs().max().item() <= 1e-3 * max(1.0, ref2.abs().max().item())
+    assert torch.equal(nat.unpack_activation(hb, M, 512), h.to(dtype))
+    with pytest.raises(nat.NativeError):
+        nat.gemm_skinny(dtype, M, 512, K, wp2, None, x=xp, epi=nat.EPI_STORE, y=hb, x_packed=True, y_row0=16)   # y_row0 needs a packed y
+
+
+def _cond_model(dtype):
+    from indextts.gpt.model import UnifiedVoice
+    m = UnifiedVoice(**dict(weights.reference_config()["gpt"], layers=2))
+    m.load_state_dict(weights.gpt_state_dict(2))
+    return m.to(DEV).to(dtype)
+
+
+@pytest.mark.parametrize("frames", [120, 300, 437])
+def test_conditioner_engine_matches_functional_fp32(frames):
+    """The whole Conformer + Perceiver conditioner (fp16 kernels) against the functional fp32 form over the same weights;
+    437 frames = 218 context rows: more than one 192-key chunk in the Perceiver's attention."""
+    m = _cond_model(torch.bfloat16)
+    mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, frames), -6.0, 2.0)).to(DEV)
+    got = m.get_conditioning(mel, None)
+    assert m.conditioner() is not None and m.conditioner().launches == 3 + 9 * 6 + 2 + 6 * 2 + 1
+    os.environ["ITTS_NATIVE_CONDITIONER"] = "0"
+    try:
+        ref = m.get_conditioning(mel, None)
+    finally:
+        del os.environ["ITTS_NATIVE_CONDITIONER"]
+    assert got.shape == ref.shape == (1, 32, 1280) and torch.isfinite(got).all()
+    err = (got - ref).abs()
+    assert err.max().item() < 1e-2 and err.pow(2).mean().sqrt().item() < 2e-3, (err.max().item(), ref.pow(2).mean().sqrt().item())
+
+
+def test_conditioner_engine_against_reference_fixture():
+    """conds of the reference run (tests/golden/gpt_small.npz, made by make_golden.py from the reference's own modules)."""
+    g = np.load(os.path.join(G, "gpt_small.npz"))
+    m = _cond_model(torch.bfloat16)
+    mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
+    got = m.get_conditioning(mel, None)
+    ref = torch.from_numpy(g["conds"]).to(DEV)
+    assert (got - ref).abs().max().item() < 1e-2
+    # a batch of equal-length prompts is a loop over prompts; the graph-captured form replays to the same bits
+    two = m.get_conditioning(torch.cat([mel, mel * 0.5]), None)
+    assert torch.equal(two[0], got[0]) and not torch.equal(two[1], got[0])
+    gr = torch.cuda.CUDAGraph()
+    eng = m.conditioner()
+    row = mel[0].t().contiguous()
+    with torch.cuda.graph(gr):
+        out = eng(row)
+    out.zero_()
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, got[0])
+
+
+def test_conditioner_fp32_mode_keeps_the_functional_form():
+    m = _cond_model(torch.float32)
+    assert m.conditioner() is None
+    with pytest.raises(ValueError):
+        from indextts.gpt.conditioner import ConditionerEngine
+        ConditionerEngine(m._cond_weights(), dtype=torch.float32)

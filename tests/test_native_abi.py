@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for s in dsyms:
         assert not hasattr(lib, s), f"{s} (diagnostic build only) is exported by the product library"
     lib.itts_abi_version.restype = ctypes.c_int
-    assert lib.itts_abi_version() == 7
+    assert lib.itts_abi_version() == 8
     lib.itts_packed_bytes.restype = ctypes.c_int64
     assert lib.itts_packed_bytes(1, 1280, 3840, 1) == 1280 * 3840 * 2
     assert lib.itts_packed_bytes(7, 24, 1, 0) == 7 * 1 * 2 * 1024
