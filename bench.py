@@ -531,8 +531,8 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         conds = tts._prompt_conds(cond_mel)              # the product path: Conformer + Perceiver as one graph replay
-        _, emb, mask = tts.gpt.prepare_gpt_inputs(conds, batch_tokens)
-        tts.gpt.engine.prefill(emb, (mask == 0).sum(1).to(torch.int32), 4, shared_rows=int(conds.shape[1]))   # as infer_batch does
+        emb, pad = tts.gpt.prefix_rows(conds, batch_tokens)
+        tts.gpt.engine.prefill(emb, pad, 4, shared_rows=int(conds.shape[1]))   # as infer_batch does
         tts.gpt.engine._sample(BATCH, sp)
         torch.cuda.synchronize()
         lat_ms.append((time.perf_counter() - t1) * 1e3)

@@ -48,7 +48,7 @@ extern "C" {
 #define ITTS_BF16 1
 #define ITTS_F16 2
 
-#define ITTS_ABI_VERSION 8 /* 8: prompt front-end (itts_subsample_conv, itts_mha_small, itts_glu_dwconv_ln_silu, itts_rows, itts_geglu), ITTS_EPI_SILU_STORE, y_row0 / y_mtp and any M with rows_per_wg in itts_gemm_skinny, itts_gemm_conv ksplit <= 64; 7: LayerNorm folded into the consuming skinny GEMM (ln_c), residual epilogue with a packed T copy, rows_per_wg / wide_wg, bump words in itts_gemm_skinny / itts_embed_step (+ clamp, packed copy); the reducer tail is gone; paged KV cache (kv_tab / kv_bs); 6: per-row clocks (row_step0) in itts_embed_step / itts_sample_args (slot refill), itts_attn_prefill_prefix / _shared, kv_share in itts_attn_decode; 5: itts_ln_reduce takes up to 6 slabs */
+#define ITTS_ABI_VERSION 8 /* 8: prompt front-end (itts_subsample_conv, itts_mha_small, itts_glu_dwconv_ln_silu, itts_rows, itts_geglu, itts_prefix_rows), ITTS_EPI_SILU_STORE, y_row0 / y_mtp and any M with rows_per_wg in itts_gemm_skinny, itts_gemm_conv ksplit <= 64; 7: LayerNorm folded into the consuming skinny GEMM (ln_c), residual epilogue with a packed T copy, rows_per_wg / wide_wg, bump words in itts_gemm_skinny / itts_embed_step (+ clamp, packed copy); the reducer tail is gone; paged KV cache (kv_tab / kv_bs); 6: per-row clocks (row_step0) in itts_embed_step / itts_sample_args (slot refill), itts_attn_prefill_prefix / _shared, kv_share in itts_attn_decode; 5: itts_ln_reduce takes up to 6 slabs */
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -402,7 +402,7 @@ int itts_tanh_pcm(const void* x, float* wav, int16_t* pcm, int64_t n, int dtype,
  * residual stream, every GEMM operand in the packed activation layout.  The host side is indextts/gpt/conditioner.py.
  * ------------------------------------------------------------------------------------------------------------------ */
 /* y (T [T2][C * F2], T2 = (T-3)/2+1, F2 = (F-3)/2+1) = relu(Conv2d(1, C, 3, stride 2)(mel [T][F])) laid out as the operand of
- * the Linear(C * F2 -> d) that follows: element (t, c * F2 + f).  w [C][9], b [C] fp32.  (C * F2) % 8 == 0. */
+ * the Linear(C * F2 -> d) that follows: element (t, c * F2 + f).  w [C][9], b [C] fp32. */
 int itts_subsample_conv(const float* mel, const float* w, const float* b, void* y, int T, int F, int C, int dtype, void* stream);
 
 /* Multi-head attention over a short sequence, head dim 64:  out[i] = softmax_j( scale * ((q_i + u) . k_j + (q_i + v) . p_j) ) v_j
@@ -455,6 +455,16 @@ int itts_rows(const itts_rows_args* a, void* stream);
 
 /* y (T, packed layout of [M][Kp], y_mtp row tiles, 0 = ceil(M / 16)) = gelu(h[:, Kp:]) * h[:, :Kp]  (erf gelu; h T [M][2 Kp]). */
 int itts_geglu(const void* h, void* y, int M, int Kp, int y_mtp, int dtype, void* stream);
+
+/* The GPT prompt rows of UnifiedVoice.prepare_gpt_inputs (indextts/gpt/model.py:606-667): per batch row b the ids of text [B][L]
+ * (int64) that are neither start_tok nor stop_tok (n of them, order kept) become start | ids | stop, embedded as
+ * text_emb[id] + text_pos[j] (fp32 tables of n_tok / n_pos rows, j = index in that sequence), placed behind the C conditioning latents
+ * (conds fp32 [conds_rows][C][D], conds_rows 1 = shared by all rows) and right-aligned in P = C + L + 2 positions:
+ *   emb (fp32 [B][P][D]): L - n zero rows, the latents, the n + 2 text rows;  mask (int64 [B][P + 1]): 0 on the zero rows, else 1
+ *   (the last slot is the start-mel token's);  pad (int32 [B]) = L - n.   L <= 2046, D % 4 == 0. */
+int itts_prefix_rows(const int64_t* text, const float* conds, int conds_rows, const float* text_emb, const float* text_pos, float* emb,
+                     int64_t* mask, int32_t* pad, int B, int L, int C, int D, int start_tok, int stop_tok, int n_tok, int n_pos,
+                     void* stream);
 
 #ifdef __cplusplus
 }

@@ -12,54 +12,74 @@
 //   rows_kernel             row-wise residual-stream operations: slab sum + bias, LayerNorm / l2-normalise, packed T copy
 //   geglu_kernel            gelu(gate) * x of the Perceiver's feed-forward (perceiver.py:181-193)
 #include "common.h"
-#include <mutex>
 
 namespace itts {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Conv2d(1 -> C, 3 x 3, stride 2) + ReLU over mel [T][F] (time-major), written as the row-major T-typed operand
-// y[t'][c * F2 + f'] of the following Linear(C * F2 -> d).  One workgroup per output row t'.
+// y[t'][c * F2 + f'] of the following Linear(C * F2 -> d).  One workgroup per output row t'; a LANE is one output frequency f'
+// and keeps its 3 x 3 input window in registers, a wave walks its share of the channels with the nine weights and the bias as
+// wave-uniform operands: nine FMAs per output; the wave's run of the row leaves through LDS as 16-byte vectors.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void subsample_conv_kernel(const float* __restrict__ mel, const float* __restrict__ w,
+template <typename T, bool STAGED>
+__global__ __launch_bounds__(512) void subsample_conv_kernel(const float* __restrict__ mel, const float* __restrict__ w,
                                                              const float* __restrict__ b, T* __restrict__ y, int F, int C, int F2) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // [3][F] mel rows | [C][9] weights | [C] bias
-  float* mrow = sm;
-  float* wl = sm + 3 * F;
-  float* bl = wl + C * 9;
-  const int t = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < 3 * F; i += 256) mrow[i] = mel[(int64_t)(2 * t) * F + i];
-  for (int i = tid; i < C * 9; i += 256) wl[i] = w[i];
-  for (int i = tid; i < C; i += 256) bl[i] = b[i];
-  __syncthreads();
-  const int n8 = C * F2 / 8;
+  extern __shared__ __attribute__((aligned(16))) char sub_lds[];   // STAGED: the wave's run of the output row, written out as 16-byte vectors
+  const int t = blockIdx.x, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;
+  const int cpw = (C + NW - 1) / NW;                 // channels per wave, a contiguous run
+  const int c_begin = wave * cpw, c_end = min(C, c_begin + cpw);
   T* yr = y + (int64_t)t * C * F2;
-  for (int it = tid; it < n8; it += 256) {
-    typedef T t8 __attribute__((ext_vector_type(8)));
-    t8 o;
+  T* stage = reinterpret_cast<T*>(sub_lds) + (size_t)wave * cpw * F2;
+  for (int f0 = 0; f0 < F2; f0 += 64) {
+    const int f = f0 + lane;
+    const bool ok = f < F2;
+    float m[9];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int idx = it * 8 + e;
-      const int c = idx / F2, f = idx - c * F2;
-      const float* wc = wl + c * 9;
-      float acc = bl[c];
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) m[i * 3 + j] = ok ? mel[(int64_t)(2 * t + i) * F + 2 * f + j] : 0.f;
+    // the nine weights and the bias of channel cg + lane sit in this lane's registers; channel by channel they are broadcast
+    // with v_readlane (scalar loads per channel would serialise on their round trips)
+    for (int cg = c_begin; cg < c_end; cg += 64) {
+      const int mc = min(cg + lane, c_end - 1);
+      float wr[9];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc = fmaf(wc[i * 3 + j], mrow[i * F + 2 * f + j], acc);
-      o[e] = Elem<T>::from_f(fmaxf(acc, 0.f));
+      for (int k = 0; k < 9; ++k) wr[k] = w[mc * 9 + k];
+      const float br = b[mc];
+      const int nc = min(64, c_end - cg);
+      for (int ci = 0; ci < nc; ++ci) {
+        float acc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, br), ci));
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+          acc = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wr[k]), ci)), m[k], acc);
+        const T o = Elem<T>::from_f(fmaxf(acc, 0.f));
+        if (ok) {
+          if constexpr (STAGED) stage[(cg + ci - c_begin) * F2 + f] = o;
+          else yr[(cg + ci) * F2 + f] = o;
+        }
+      }
     }
-    *reinterpret_cast<t8*>(yr + it * 8) = o;
+  }
+  if constexpr (STAGED) {
+    // one wave wrote this run and reads it back: the LDS pipe keeps a wave's accesses in order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int n16 = (c_end - c_begin) * F2 / 8;
+    T* dst = yr + (int64_t)c_begin * F2;
+    for (int i = lane; i < n16; i += 64) st16(dst + i * 8, ld16<B16>(stage + i * 8));
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Small multi-head attention, head dim 64.  grid (ceil(Tq / 64), H), 4 waves, one 16-row query tile per wave; the keys are
-// walked in chunks of KC rows staged in LDS (K, V and -- RELPOS -- the projected position table P of the head), 32 keys per
-// step with an online softmax.  Everything runs transposed (keys / feature dims as MFMA rows, queries as columns): a lane owns
-// ONE query row, so the running max / sum are lane scalars and the probabilities leave the score accumulators already in
-// B-operand order for the second product (key slot (g, j) of a 32-key step = key 16 (j / 4) + 4 g + j % 4; the V^T fragments
-// are fetched with the same slot order through the transposed LDS read).
+// Small multi-head attention, head dim 64.  grid (ceil(Tq / 16), H): one 16-row query tile per workgroup, whose 4 waves SPLIT
+// THE KEYS (32-key steps dealt round-robin) and merge their partial softmax states through LDS at the end -- a prompt is ~150
+// keys, so the key walk is the only loop long enough to cut, and 10 x 8 tiles x 4 waves fill the chip where 24 workgroups did not.
+// Everything runs transposed (keys / feature dims as MFMA rows, queries as columns): a lane owns ONE query row, so the running
+// max / sum are lane scalars and the probabilities leave the score accumulators already in B-operand order for the second
+// product (key slot (g, j) of a 32-key step = key 16 (j / 4) + 4 g + j % 4).  K and the projected position table P are read
+// straight from global memory in A-operand order; V goes through a wave-private LDS image and comes back transposed
+// (ds_read_b64_tr_b16) with the same slot order.
 // ---------------------------------------------------------------------------------------------------------------
 struct MhaParams {
   int Tq, Tk, H;
@@ -75,8 +95,7 @@ struct MhaParams {
   int out_mtp;
 };
 
-constexpr int MHA_KC = 192;   // keys per LDS chunk
-constexpr int MHA_RS = 72;    // LDS row stride (elements): 144 bytes, an odd multiple of 16
+constexpr int MHA_RS = 72;    // LDS row stride of the V image (elements): 144 bytes, an odd multiple of 16
 
 typedef short mha_v4s __attribute__((__vector_size__(4 * sizeof(short))));
 
@@ -84,15 +103,14 @@ template <typename T, bool RELPOS>
 __global__ __launch_bounds__(256) void mha_small_kernel(MhaParams p) {
   typedef Elem<T> EL;
   typedef typename EL::frag frag;
-  extern __shared__ __attribute__((aligned(16))) char mha_lds[];
-  T* Ki = reinterpret_cast<T*>(mha_lds);
-  T* Vi = Ki + MHA_KC * MHA_RS;
-  T* Pi = Vi + MHA_KC * MHA_RS;
+  __shared__ __attribute__((aligned(16))) T Vimg[4][32 * MHA_RS];
+  __shared__ __attribute__((aligned(16))) float comb[4][4][64][4];
+  __shared__ float ml[4][16][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r = lane & 15;
   const int h = blockIdx.y;
-  const int q0 = ((int)blockIdx.x * 4 + wave) * 16;
-  const bool active = q0 < p.Tq;
+  const int q0 = (int)blockIdx.x * 16;
+  T* Vi = Vimg[wave];
 
   // query fragments (B operand: column = query row r, k = feature dims 32 kk + 8 g .. + 7), with the two position biases added
   frag qu[2], qv[2];
@@ -103,11 +121,13 @@ __global__ __launch_bounds__(256) void mha_small_kernel(MhaParams p) {
     for (int kk = 0; kk < 2; ++kk) {
       const frag qf = ld16<frag>(qp + 32 * kk);
       if constexpr (RELPOS) {
+        const f32x4 u0 = ld16<f32x4>(p.bu + h * 64 + 32 * kk + 8 * g), u1 = ld16<f32x4>(p.bu + h * 64 + 32 * kk + 8 * g + 4);
+        const f32x4 v0 = ld16<f32x4>(p.bv + h * 64 + 32 * kk + 8 * g), v1 = ld16<f32x4>(p.bv + h * 64 + 32 * kk + 8 * g + 4);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float qe = EL::to_f(qf[e]);
-          qu[kk][e] = EL::from_f(qe + p.bu[h * 64 + 32 * kk + 8 * g + e]);
-          qv[kk][e] = EL::from_f(qe + p.bv[h * 64 + 32 * kk + 8 * g + e]);
+          qu[kk][e] = EL::from_f(qe + (e < 4 ? u0[e & 3] : u1[e & 3]));
+          qv[kk][e] = EL::from_f(qe + (e < 4 ? v0[e & 3] : v1[e & 3]));
         }
       } else {
         qu[kk] = qf;
@@ -120,90 +140,116 @@ __global__ __launch_bounds__(256) void mha_small_kernel(MhaParams p) {
   for (int nt = 0; nt < 4; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
 
-  for (int c0 = 0; c0 < p.Tk; c0 += MHA_KC) {
-    const int rows = min(MHA_KC, p.Tk - c0);
-    const int rows32 = (rows + 31) & ~31;
-    if (c0 > 0) __syncthreads();   // every wave is done with the previous chunk
-    for (int idx = tid; idx < rows32 * 8; idx += 256) {
-      const int row = idx >> 3, seg = idx & 7;
-      const bool ok = row < rows;
-      const int64_t kr = c0 + row;
-      const frag z = zero_frag<frag>();
-      st16(Ki + row * MHA_RS + seg * 8, ok ? ld16<frag>((const T*)p.k + kr * p.ks + h * 64 + seg * 8) : z);
-      st16(Vi + row * MHA_RS + seg * 8, ok ? ld16<frag>((const T*)p.v + kr * p.vs + h * 64 + seg * 8) : z);
-      if constexpr (RELPOS)
-        st16(Pi + row * MHA_RS + seg * 8, ok ? ld16<frag>((const T*)p.pos + ((int64_t)h * p.Tk + kr) * 64 + seg * 8) : z);
-    }
-    __syncthreads();
-    if (!active) continue;
-    for (int kb = 0; kb < rows32; kb += 32) {
-      f32x4 s[2];
+  for (int kb = wave * 32; kb < p.Tk; kb += 128) {
+    // ---- operand requests of this 32-key step
+    frag kf[2][2], pf_[2][2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const T* kr = Ki + (kb + 16 * j + r) * MHA_RS + 8 * g;
-        s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        s[j] = EL::mma(ld16<frag>(kr), qu[0], s[j]);
-        s[j] = EL::mma(ld16<frag>(kr + 32), qu[1], s[j]);
-        if constexpr (RELPOS) {
-          const T* pr = Pi + (kb + 16 * j + r) * MHA_RS + 8 * g;
-          s[j] = EL::mma(ld16<frag>(pr), qv[0], s[j]);
-          s[j] = EL::mma(ld16<frag>(pr + 32), qv[1], s[j]);
-        }
-      }
-      // lane (g, r): s[j][e] = score of query r against key c0 + kb + 16 j + 4 g + e
-      float mloc = -INFINITY;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int key = c0 + kb + 16 * j + 4 * g + e;
-          s[j][e] = key < p.Tk ? s[j][e] * p.scale : -INFINITY;
-          mloc = fmaxf(mloc, s[j][e]);
-        }
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-      const float m_new = fmaxf(m_run, mloc);       // finite: the first key of a step always exists
-      const float alpha = __expf(m_run - m_new);
-      float lsum = 0.f;
-      frag pf;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float pe = __expf(s[j][e] - m_new);
-          const T pt = EL::from_f(pe);
-          pf[4 * j + e] = pt;
-          lsum += EL::to_f(pt);                      // the normaliser sums what the product multiplies
-        }
-      lsum += __shfl_xor(lsum, 16, 64);
-      lsum += __shfl_xor(lsum, 32, 64);
-      l_run = l_run * alpha + lsum;
-      m_run = m_new;
-      // V^T fragments: lane (g, r) needs feature dim 16 nt + r of keys kb + 4 g + {0..3} and kb + 16 + 4 g + {0..3}
-      const int qq = r >> 2, pq = r & 3;
-      typedef __attribute__((address_space(3))) mha_v4s* lptr;
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const T* a = Vi + (kb + 4 * g + qq) * MHA_RS + 16 * nt + 4 * pq;
-        const mha_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a));
-        const mha_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a + 16 * MHA_RS));
-        typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
-        const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        o[nt] = o[nt] * alpha;
-        o[nt] = EL::mma(__builtin_bit_cast(frag, both), pf, o[nt]);
+    for (int j = 0; j < 2; ++j) {
+      const int64_t key = min(kb + 16 * j + r, p.Tk - 1);        // rows past the end are masked below
+      const T* kr = (const T*)p.k + key * p.ks + h * 64 + 8 * g;
+      kf[j][0] = ld16<frag>(kr);
+      kf[j][1] = ld16<frag>(kr + 32);
+      if constexpr (RELPOS) {
+        const T* pr = (const T*)p.pos + ((int64_t)h * p.Tk + key) * 64 + 8 * g;
+        pf_[j][0] = ld16<frag>(pr);
+        pf_[j][1] = ld16<frag>(pr + 32);
       }
     }
-  }
-  if (!active || q0 + r >= p.Tq) return;
-  const float inv = 1.0f / l_run;
+    frag vrow[4];
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    typedef T t4 __attribute__((ext_vector_type(4)));
-    t4 ov;
+    for (int i = 0; i < 4; ++i) {
+      const int idx = lane + 64 * i, row = idx >> 3, seg = idx & 7;
+      vrow[i] = kb + row < p.Tk ? ld16<frag>((const T*)p.v + (int64_t)(kb + row) * p.vs + h * 64 + seg * 8) : zero_frag<frag>();
+    }
+    // ---- scores (transposed): lane (g, r): s[j][e] = query r against key kb + 16 j + 4 g + e
+    f32x4 s[2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) ov[e] = EL::from_f(o[nt][e] * inv);
-    *reinterpret_cast<t4*>((T*)p.out + pa_off<T>(q0 + r, h * 64 + 16 * nt + 4 * g, p.out_mtp)) = ov;
+    for (int j = 0; j < 2; ++j) {
+      s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      s[j] = EL::mma(kf[j][0], qu[0], s[j]);
+      s[j] = EL::mma(kf[j][1], qu[1], s[j]);
+      if constexpr (RELPOS) {
+        s[j] = EL::mma(pf_[j][0], qv[0], s[j]);
+        s[j] = EL::mma(pf_[j][1], qv[1], s[j]);
+      }
+    }
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int key = kb + 16 * j + 4 * g + e;
+        s[j][e] = key < p.Tk ? s[j][e] * p.scale : -INFINITY;
+        mloc = fmaxf(mloc, s[j][e]);
+      }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(m_run, mloc);       // finite: the first key of a step always exists
+    const float alpha = __expf(m_run - m_new);
+    float lsum = 0.f;
+    frag pf;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const T pt = EL::from_f(__expf(s[j][e] - m_new));
+        pf[4 * j + e] = pt;
+        lsum += EL::to_f(pt);                      // the normaliser sums what the product multiplies
+      }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+    // ---- V rows into the wave's image, back out transposed: lane (g, r) gets feature dim 16 nt + r of keys kb + 4 g + {0..3}
+    // and kb + 16 + 4 g + {0..3}.  One wave writes and reads the image: the LDS pipe keeps a wave's accesses in order.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = lane + 64 * i;
+      st16(Vi + (idx >> 3) * MHA_RS + (idx & 7) * 8, vrow[i]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int qq = r >> 2, pq = r & 3;
+    typedef __attribute__((address_space(3))) mha_v4s* lptr;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const T* a = Vi + (4 * g + qq) * MHA_RS + 16 * nt + 4 * pq;
+      const mha_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a));
+      const mha_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a + 16 * MHA_RS));
+      typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
+      const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      o[nt] = o[nt] * alpha;
+      o[nt] = EL::mma(__builtin_bit_cast(frag, both), pf, o[nt]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
+  // ---- merge the four partial states: wave w finishes feature tile nt = w
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) st16(&comb[wave][nt][lane][0], o[nt]);
+  if (g == 0) {
+    ml[wave][r][0] = m_run;
+    ml[wave][r][1] = l_run;
+  }
+  __syncthreads();
+  float M = -INFINITY;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) M = fmaxf(M, ml[w][r][0]);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float L = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float sc = __expf(ml[w][r][0] - M);     // a wave without keys: exp(-inf) = 0
+    L = fmaf(sc, ml[w][r][1], L);
+    acc += ld16<f32x4>(&comb[w][wave][lane][0]) * sc;
+  }
+  if (q0 + r >= p.Tq) return;
+  const float inv = 1.0f / L;
+  typedef T t4 __attribute__((ext_vector_type(4)));
+  t4 ov;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) ov[e] = EL::from_f(acc[e] * inv);
+  *reinterpret_cast<t4*>((T*)p.out + pa_off<T>(q0 + r, h * 64 + 16 * wave + 4 * g, p.out_mtp)) = ov;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -296,7 +342,14 @@ __global__ __launch_bounds__(256) void rows_kernel(RowsParams p) {
     if (c4 < D4) {
       if (p.x != nullptr) v[i] = ld16<f32x4>(p.x + (int64_t)m * p.D + c4 * 4);
       if (p.bias != nullptr) v[i] += ld16<f32x4>(p.bias + c4 * 4);
-      for (int s = 0; s < p.nslab; ++s) v[i] += ld16<f32x4>(p.slab + ((int64_t)s * p.M + m) * p.D + c4 * 4);
+      for (int s0 = 0; s0 < p.nslab; s0 += 8) {     // eight requests in flight, summed in slab order
+        f32x4 tv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          tv[j] = s0 + j < p.nslab ? ld16<f32x4>(p.slab + ((int64_t)(s0 + j) * p.M + m) * p.D + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i] += tv[j];
+      }
     }
   }
   if (p.norm != 0) {
@@ -362,6 +415,73 @@ __global__ __launch_bounds__(256) void geglu_kernel(const T* __restrict__ h, T* 
   *reinterpret_cast<t4*>(y + pa_off<T>(m, c, mtp)) = o;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The GPT prompt rows of UnifiedVoice.prepare_gpt_inputs (indextts/gpt/model.py:606-667) in one launch: per batch row, the
+// text ids without start / stop ids become  start | ids | stop, are embedded (token + position tables), follow the C
+// conditioning latents and are pushed to the RIGHT end of the P = C + L + 2 positions (left padding = L - n zero rows);
+// emb fp32 [B][P][D], mask int64 [B][P + 1] (0 on the padding, 1 elsewhere and on the start-mel slot), pad int32 [B].
+// grid (ceil(P / 8), B): every workgroup compacts its row's ids again (a block scan over <= L ids) and writes 8 positions.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int PREFIX_MAXL = 2046;
+__global__ __launch_bounds__(256) void prefix_rows_kernel(const int64_t* __restrict__ text, const float* __restrict__ conds, int Bc,
+                                                          const float* __restrict__ temb, const float* __restrict__ tpos,
+                                                          float* __restrict__ emb, int64_t* __restrict__ mask,
+                                                          int32_t* __restrict__ pad_out, int L, int C, int D, int start_tok,
+                                                          int stop_tok, int n_tok, int n_pos) {
+  __shared__ int ctok[PREFIX_MAXL + 2];
+  __shared__ int wsum[4];
+  __shared__ int base_s;
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t* tr = text + (int64_t)b * L;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int l0 = 0; l0 < L; l0 += 256) {           // stable compaction of the ids that are neither start nor stop
+    const int l = l0 + tid;
+    const int64_t tk = l < L ? tr[l] : (int64_t)stop_tok;
+    const bool ok = l < L && tk != stop_tok && tk != start_tok;
+    const unsigned long long bal = __ballot(ok);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (ok) ctok[1 + off + before] = (int)tk;
+    __syncthreads();
+    if (tid == 0) base_s += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+  const int n = base_s;
+  if (tid == 0) {
+    ctok[0] = start_tok;
+    ctok[n + 1] = stop_tok;
+  }
+  __syncthreads();
+  const int P = C + L + 2, pad = L - n;
+  if (blockIdx.x == 0) {
+    for (int i = tid; i <= P; i += 256) mask[(int64_t)b * (P + 1) + i] = (i >= pad) ? 1 : 0;
+    if (tid == 0) pad_out[b] = pad;
+  }
+  const int D4 = D / 4;
+  for (int pi = 0; pi < 8; ++pi) {
+    const int pos = (int)blockIdx.x * 8 + pi;
+    if (pos >= P) break;
+    const int src = pos - pad;
+    float* dst = emb + ((int64_t)b * P + pos) * D;
+    if (src < 0) {
+      for (int i = tid; i < D4; i += 256) st16(dst + i * 4, f32x4{0.f, 0.f, 0.f, 0.f});
+    } else if (src < C) {
+      const float* cr = conds + ((int64_t)(Bc == 1 ? 0 : b) * C + src) * D;
+      for (int i = tid; i < D4; i += 256) st16(dst + i * 4, ld16<f32x4>(cr + i * 4));
+    } else {
+      const int j = src - C;                        // 0 .. n + 1
+      const int tk = min(max(ctok[j], 0), n_tok - 1);
+      const float* er = temb + (int64_t)tk * D;
+      const float* pr = tpos + (int64_t)min(j, n_pos - 1) * D;
+      for (int i = tid; i < D4; i += 256) st16(dst + i * 4, ld16<f32x4>(er + i * 4) + ld16<f32x4>(pr + i * 4));
+    }
+  }
+}
+
 }  // namespace itts
 
 using namespace itts;
@@ -371,14 +491,18 @@ extern "C" int itts_subsample_conv(const float* mel, const float* w, const float
   ITTS_REQUIRE(mel && w && b && y && T >= 3 && F >= 3 && C > 0, "itts_subsample_conv: bad arguments");
   ITTS_REQUIRE(dtype == ITTS_BF16 || dtype == ITTS_F16, "itts_subsample_conv: the front-end kernels are built for bf16 / f16");
   const int T2 = (T - 3) / 2 + 1, F2 = (F - 3) / 2 + 1;
-  ITTS_REQUIRE((C * F2) % 8 == 0, "itts_subsample_conv: C * F' = %d must be a multiple of 8", C * F2);
-  const size_t lds = (size_t)(3 * F + C * 10) * 4;
-  ITTS_REQUIRE(lds <= 64 * 1024, "itts_subsample_conv: C = %d, F = %d do not fit the staging buffer", C, F);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == ITTS_BF16)
-    hipLaunchKernelGGL(subsample_conv_kernel<bf16_t>, dim3(T2), dim3(256), lds, s, mel, w, b, (bf16_t*)y, F, C, F2);
-  else
-    hipLaunchKernelGGL(subsample_conv_kernel<f16_t>, dim3(T2), dim3(256), lds, s, mel, w, b, (f16_t*)y, F, C, F2);
+  // staged form: every wave's run of cpw channels x F2 outputs is a whole number of 16-byte vectors and the row fits 64 KiB of LDS
+  const int cpw = (C + 7) / 8;
+  const bool staged = C % 8 == 0 && (cpw * F2) % 8 == 0 && (size_t)C * F2 * 2 <= 64 * 1024;
+  const size_t lds = staged ? (size_t)C * F2 * 2 : 0;
+  if (dtype == ITTS_BF16) {
+    if (staged) hipLaunchKernelGGL((subsample_conv_kernel<bf16_t, true>), dim3(T2), dim3(512), lds, s, mel, w, b, (bf16_t*)y, F, C, F2);
+    else hipLaunchKernelGGL((subsample_conv_kernel<bf16_t, false>), dim3(T2), dim3(512), 0, s, mel, w, b, (bf16_t*)y, F, C, F2);
+  } else {
+    if (staged) hipLaunchKernelGGL((subsample_conv_kernel<f16_t, true>), dim3(T2), dim3(512), lds, s, mel, w, b, (f16_t*)y, F, C, F2);
+    else hipLaunchKernelGGL((subsample_conv_kernel<f16_t, false>), dim3(T2), dim3(512), 0, s, mel, w, b, (f16_t*)y, F, C, F2);
+  }
   return check_launch("itts_subsample_conv");
 }
 
@@ -399,18 +523,9 @@ extern "C" int itts_mha_small(const itts_mha_args* a, void* stream) {
   p.pos = a->pos; p.bu = a->bias_u; p.bv = a->bias_v;
   p.scale = a->scale;
   p.out = a->out; p.out_mtp = a->out_mtp;
-  const dim3 grid((a->Tq + 63) / 64, a->H), block(256);
-  const size_t lds = (size_t)(rel ? 3 : 2) * MHA_KC * MHA_RS * 2;
+  const dim3 grid((a->Tq + 15) / 16, a->H), block(256);
   hipStream_t s = (hipStream_t)stream;
-#define ITTS_MHA(T_, R_)                                                                                                 \
-  do {                                                                                                                   \
-    static std::once_flag attr_;   /* one-shot per instantiation, safe under concurrent first calls */                   \
-    std::call_once(attr_, [] {                                                                                           \
-      (void)hipFuncSetAttribute((const void*)mha_small_kernel<T_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
-                                3 * MHA_KC * MHA_RS * 2);                                                                \
-    });                                                                                                                  \
-    hipLaunchKernelGGL((mha_small_kernel<T_, R_>), grid, block, lds, s, p);                                              \
-  } while (0)
+#define ITTS_MHA(T_, R_) hipLaunchKernelGGL((mha_small_kernel<T_, R_>), grid, block, 0, s, p)
   if (a->dtype == ITTS_BF16) {
     if (rel) ITTS_MHA(bf16_t, true);
     else ITTS_MHA(bf16_t, false);
@@ -481,4 +596,17 @@ extern "C" int itts_geglu(const void* h, void* y, int M, int Kp, int y_mtp, int 
   if (dtype == ITTS_BF16) hipLaunchKernelGGL(geglu_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)h, (bf16_t*)y, M, Kp, mtp);
   else hipLaunchKernelGGL(geglu_kernel<f16_t>, grid, block, 0, s, (const f16_t*)h, (f16_t*)y, M, Kp, mtp);
   return check_launch("itts_geglu");
+}
+
+extern "C" int itts_prefix_rows(const int64_t* text, const float* conds, int conds_rows, const float* text_emb, const float* text_pos,
+                                float* emb, int64_t* mask, int32_t* pad, int B, int L, int C, int D, int start_tok, int stop_tok,
+                                int n_tok, int n_pos, void* stream) {
+  ITTS_REQUIRE((text || L == 0) && (conds || C == 0) && text_emb && text_pos && emb && mask && pad, "itts_prefix_rows: null args");
+  ITTS_REQUIRE(B > 0 && B <= 65535 && L >= 0 && L <= PREFIX_MAXL && C >= 0 && D > 0 && D % 4 == 0 && n_tok > 0 && n_pos > 0,
+               "itts_prefix_rows: bad shape (L <= %d, D %% 4 == 0)", PREFIX_MAXL);
+  ITTS_REQUIRE(conds_rows == 1 || conds_rows == B, "itts_prefix_rows: conds has 1 or B rows");
+  const int P = C + L + 2;
+  hipLaunchKernelGGL(prefix_rows_kernel, dim3((P + 7) / 8, B), dim3(256), 0, (hipStream_t)stream, text, conds, conds_rows, text_emb,
+                     text_pos, emb, mask, pad, L, C, D, start_tok, stop_tok, n_tok, n_pos);
+  return check_launch("itts_prefix_rows");
 }

@@ -123,6 +123,8 @@ _SIGNATURES = {
                                           C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "itts_rows": (C.c_int, [C.POINTER(RowsArgs), C.c_void_p]),
     "itts_geglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "itts_prefix_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -290,6 +292,21 @@ def geglu(h, y, M, Kp, y_mtp=0):
     _dev(h, y)
     _check(lib().itts_geglu(_p(h), _p(y), M, Kp, int(y_mtp), dt(y.dtype), _stream()), "itts_geglu")
     return y
+
+
+def prefix_rows(text, conds, text_emb, text_pos, start_tok, stop_tok):
+    """text int64 [B, L], conds fp32 [1 | B, C, D] -> (emb fp32 [B, P, D], mask int64 [B, P + 1], pad int32 [B]), P = C + L + 2:
+    the GPT prompt rows of prepare_gpt_inputs in one launch (itts_prefix_rows)."""
+    _dev(text, conds, text_emb, text_pos)
+    B, L = text.shape
+    Bc, Cn, D = conds.shape
+    P = Cn + L + 2
+    emb = torch.empty(B, P, D, dtype=torch.float32, device=text.device)
+    mask = torch.empty(B, P + 1, dtype=torch.int64, device=text.device)
+    pad = torch.empty(B, dtype=torch.int32, device=text.device)
+    _check(lib().itts_prefix_rows(_p(text), _p(conds), Bc, _p(text_emb), _p(text_pos), _p(emb), _p(mask), _p(pad), B, L, Cn, D,
+                                  int(start_tok), int(stop_tok), text_emb.shape[0], text_pos.shape[0], _stream()), "itts_prefix_rows")
+    return emb, mask, pad
 
 
 def packed_rows(M: int) -> int:

@@ -14,6 +14,7 @@ import warnings
 import torch
 import torch.nn.functional as F
 
+from .. import _native as nat
 from .conditioner import ConditionerEngine
 from .conformer_encoder import conformer_encode
 from .engine import GPTEngine
@@ -146,32 +147,25 @@ class UnifiedVoice:
         """model.py:606-667 -> (fake_inputs [B,P+1], prefix_emb [B,P,D] fp32, attention_mask [B,P+1])."""
         eng = self.engine
         dev = self.device
-        t = text_inputs.to(dev).long()
+        t = text_inputs.to(dev).long().contiguous()
         B, L = t.shape
-        D = conditional_latents.shape[-1]
         C = conditional_latents.shape[1]
         P = C + L + 2
-        # strip start/stop ids, then start | tokens | stop, vectorised over the batch (model.py:630-636)
-        valid = (t != self.stop_text_token) & (t != self.start_text_token)
-        n = valid.sum(dim=1)                                               # tokens kept per row
-        rank = torch.cumsum(valid, dim=1) - 1
-        tok = torch.full((B, L + 2), self.stop_text_token, dtype=torch.long, device=dev)
-        tok[:, 0] = self.start_text_token
-        rows = torch.arange(B, device=dev)[:, None].expand(B, L)
-        tok[rows[valid], (rank + 1)[valid]] = t[valid]
-        te = eng.text_emb[tok] + eng.text_pos[: L + 2][None]               # positions > n+1 are dropped by the shift below
-        c = conditional_latents.to(dev, torch.float32)
-        if c.shape[0] == 1 and B > 1:
-            c = c.expand(B, -1, -1)
-        row = torch.cat([c, te], dim=1)                                    # [B, P, D], valid length C + n + 2
-        pad = (L - n)                                                      # left padding per row (model.py:643-649)
-        idx = torch.arange(P, device=dev)[None, :] - pad[:, None]
-        keep = idx >= 0
-        emb = row.gather(1, idx.clamp(min=0)[:, :, None].expand(-1, -1, D)) * keep[:, :, None]
-        mask = torch.cat([keep.long(), torch.ones(B, 1, dtype=torch.long, device=dev)], dim=1)
+        c = conditional_latents.to(dev, torch.float32).contiguous()
+        # strip start / stop ids, then start | tokens | stop, embedded behind the latents and left-padded to P positions
+        # (model.py:630-649): one launch, no host round trip (itts_prefix_rows)
+        emb, mask, _ = nat.prefix_rows(t, c, eng.text_emb, eng.text_pos, self.start_text_token, self.stop_text_token)
         fake = torch.ones(B, P + 1, dtype=torch.long, device=dev)
         fake[:, -1] = self.start_mel_token
-        return fake, emb.contiguous(), mask
+        return fake, emb, mask
+
+    def prefix_rows(self, conditional_latents, text_inputs):
+        """What the engine needs of prepare_gpt_inputs: (prefix_emb [B,P,D] fp32, left padding per row int32 [B]) -- the same
+        launch, without the fake ids and without re-deriving the padding from the mask."""
+        t = text_inputs.to(self.device).long().contiguous()
+        c = conditional_latents.to(self.device, torch.float32).contiguous()
+        emb, _, pad = nat.prefix_rows(t, c, self.engine.text_emb, self.engine.text_pos, self.start_text_token, self.stop_text_token)
+        return emb, pad
 
     # ---- generation -------------------------------------------------------------------------------------------
     def inference_speech(self, speech_conditioning_mel, text_inputs, cond_mel_lengths=None, input_tokens=None,
@@ -207,8 +201,7 @@ class UnifiedVoice:
         if hf:
             raise TypeError(f"unsupported generate() arguments: {sorted(hf)}")
         conds = self.get_conditioning(speech_conditioning_mel, cond_mel_lengths, speaker_ids=speaker_ids)
-        _, emb, mask = self.prepare_gpt_inputs(conds, text_inputs)
-        pad = (mask == 0).sum(dim=1).to(torch.int32)
+        emb, pad = self.prefix_rows(conds, text_inputs)
         shared = int(conds.shape[1]) if conds.shape[0] == 1 else 0   # one prompt: every row starts with the same latents
         max_new = (self.max_mel_tokens - 1) if max_generate_length is None else int(max_generate_length)
         if num_beams > 1:

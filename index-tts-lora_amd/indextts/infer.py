@@ -373,8 +373,7 @@ class IndexTTS:
     def _generate(self, conds, text_tokens, gen, max_mel_tokens, **extra):
         """gpt.inference_speech with precomputed conditioning latents (same values as recomputing them per call)."""
         g = self.gpt
-        _, emb, mask = g.prepare_gpt_inputs(conds, text_tokens)
-        pad = (mask == 0).sum(dim=1).to(torch.int32)
+        emb, pad = g.prefix_rows(conds, text_tokens)
         shared = int(conds.shape[1]) if conds.shape[0] == 1 else 0   # one prompt: every row starts with the same latents
         sp = dict(do_sample=bool(gen["do_sample"]), top_p=float(gen["top_p"]), top_k=int(gen["top_k"]),
                   temperature=float(gen["temperature"]), repetition_penalty=float(gen["repetition_penalty"]),
@@ -653,13 +652,12 @@ class IndexTTS:
         stop_text = self.cfg.gpt.stop_text_token
 
         def prefixes(ids):
-            """(left-padded prefix batch, pad) of the utterances `ids` -- one prepare_gpt_inputs call"""
+            """(left-padded prefix batch, pad) of the utterances `ids` -- one itts_prefix_rows launch"""
             L = max(int(texts[i].numel()) for i in ids)
             bh = torch.full((len(ids), L), stop_text, dtype=torch.int32)
             for j, i in enumerate(ids):
                 bh[j, : texts[i].numel()] = texts[i]
-            _, emb, mask = g.prepare_gpt_inputs(conds, bh.to(self.device))
-            return emb, (mask == 0).sum(dim=1).to(torch.int32)
+            return g.prefix_rows(conds, bh.to(self.device))
 
         queue = sorted(range(N), key=lambda i: -int(texts[i].numel()))     # longest first: every later prompt fits
         rows: List[torch.Tensor | None] = [None] * N
@@ -748,8 +746,7 @@ class IndexTTS:
             batch_h[i, : t.numel()] = t.reshape(-1).to(torch.int32)
         batch = batch_h.to(self.device)   # one upload for the whole batch
         g = self.gpt
-        _, emb, mask = g.prepare_gpt_inputs(conds, batch)
-        pad = (mask == 0).sum(dim=1).to(torch.int32)
+        emb, pad = g.prefix_rows(conds, batch)
         sp = dict(do_sample=bool(gen["do_sample"]), top_p=float(gen["top_p"]), top_k=int(gen["top_k"]),
                   temperature=float(gen["temperature"]), repetition_penalty=float(gen["repetition_penalty"]), seed=int(seed))
         if not sp["do_sample"]:

@@ -221,3 +221,48 @@ def test_conditioner_fp32_mode_keeps_the_functional_form():
     with pytest.raises(ValueError):
         from indextts.gpt.conditioner import ConditionerEngine
         ConditionerEngine(m._cond_weights(), dtype=torch.float32)
+
+
+def _prefix_ref(t, c, text_emb, text_pos, start, stop):
+    """prepare_gpt_inputs (reference model.py:606-667) in plain torch ops."""
+    B, L = t.shape
+    D, C = c.shape[-1], c.shape[1]
+    P = C + L + 2
+    valid = (t != stop) & (t != start)
+    n = valid.sum(dim=1)
+    rank = torch.cumsum(valid, dim=1) - 1
+    tok = torch.full((B, L + 2), stop, dtype=torch.long, device=t.device)
+    tok[:, 0] = start
+    rows = torch.arange(B, device=t.device)[:, None].expand(B, L)
+    tok[rows[valid], (rank + 1)[valid]] = t[valid]
+    te = text_emb[tok] + text_pos[: L + 2][None]
+    if c.shape[0] == 1 and B > 1:
+        c = c.expand(B, -1, -1)
+    row = torch.cat([c, te], dim=1)
+    pad = L - n
+    idx = torch.arange(P, device=t.device)[None, :] - pad[:, None]
+    keep = idx >= 0
+    emb = row.gather(1, idx.clamp(min=0)[:, :, None].expand(-1, -1, D)) * keep[:, :, None]
+    mask = torch.cat([keep.long(), torch.ones(B, 1, dtype=torch.long, device=t.device)], dim=1)
+    return emb, mask, pad.to(torch.int32)
+
+
+@pytest.mark.parametrize("B,L,C,D,shared", [(32, 60, 32, 1280, True), (3, 7, 32, 64, False), (2, 300, 4, 128, True), (1, 1, 0, 8, True)])
+def test_prefix_rows_matches_torch(B, L, C, D, shared):
+    """Ids with start / stop ids anywhere (stripped, order kept), rows of different length, more ids than one scan pass."""
+    from indextts import _native as nat
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    start, stop, V = 0, 1, 500
+    t = torch.randint(2, V, (B, L), generator=g)
+    for b in range(B):
+        n = int(torch.randint(0, L + 1, (1,), generator=g))
+        t[b, n:] = stop
+        if L > 4:
+            t[b, int(torch.randint(0, L, (1,), generator=g))] = start     # a stray start id inside the text
+    t = t.to(DEV)
+    conds = rnd(1 if shared else B, C, D, seed=31)
+    te, tp = rnd(V, D, seed=32), rnd(L + 2, D, seed=33)
+    emb, mask, pad = nat.prefix_rows(t, conds, te, tp, start, stop)
+    remb, rmask, rpad = _prefix_ref(t, conds, te, tp, start, stop)
+    assert torch.equal(mask, rmask) and torch.equal(pad, rpad)
+    assert torch.equal(emb, remb)

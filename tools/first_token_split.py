@@ -41,8 +41,8 @@ def timed(name, fn):
 
 for it in range(24):
     conds = timed("conditioner", lambda: tts._prompt_conds(cond_mel))
-    _, emb, mask = timed("prefix", lambda: tts.gpt.prepare_gpt_inputs(conds, tok))
-    timed("prefill", lambda: tts.gpt.engine.prefill(emb, (mask == 0).sum(1).to(torch.int32), 4, shared_rows=int(conds.shape[1])))
+    emb, pad = timed("prefix", lambda: tts.gpt.prefix_rows(conds, tok))
+    timed("prefill", lambda: tts.gpt.engine.prefill(emb, pad, 4, shared_rows=int(conds.shape[1])))
     timed("sample", lambda: tts.gpt.engine._sample(32, sp))
     timed("speaker embedding (not on the first token's path)", lambda: tts._prompt_spk(cond_mel))
 for k, v in parts.items():

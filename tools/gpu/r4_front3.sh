@@ -1,0 +1,15 @@
+#!/bin/bash
+set -o pipefail
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout -k 10 900 python -m pytest tests/test_frontend_gpu.py -x -q > gpurun_out/r04_front_tests.log 2>&1 || { tail -30 gpurun_out/r04_front_tests.log; exit 1; }
+tail -3 gpurun_out/r04_front_tests.log
+python tools/conditioner_time.py 300 300 > gpurun_out/r04_conditioner_time.txt 2>&1 || { tail -20 gpurun_out/r04_conditioner_time.txt; exit 1; }
+cat gpurun_out/r04_conditioner_time.txt
+rm -rf gpurun_out/prof_cond
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_cond -- python3 tools/conditioner_time.py 300 50 > gpurun_out/r04_conditioner_prof.log 2>&1 || { tail -20 gpurun_out/r04_conditioner_prof.log; exit 1; }
+f=$(find gpurun_out/prof_cond -name '*kernel_stats.csv' | head -1)
+cp "$f" gpurun_out/r04_conditioner_kernel_stats.csv
+grep "itts" gpurun_out/r04_conditioner_kernel_stats.csv | cut -c1-150
+python tools/first_token_split.py > gpurun_out/r04_first_token_split.txt 2>&1 || { tail -20 gpurun_out/r04_first_token_split.txt; exit 1; }
+tail -6 gpurun_out/r04_first_token_split.txt
