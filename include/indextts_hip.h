@@ -48,7 +48,7 @@ extern "C" {
 #define ITTS_BF16 1
 #define ITTS_F16 2
 
-#define ITTS_ABI_VERSION 8 /* 8: prompt front-end (itts_subsample_conv, itts_mha_small, itts_glu_dwconv_ln_silu, itts_rows, itts_geglu, itts_prefix_rows), ITTS_EPI_SILU_STORE, y_row0 / y_mtp and any M with rows_per_wg in itts_gemm_skinny, itts_gemm_conv ksplit <= 64; 7: LayerNorm folded into the consuming skinny GEMM (ln_c), residual epilogue with a packed T copy, rows_per_wg / wide_wg, bump words in itts_gemm_skinny / itts_embed_step (+ clamp, packed copy); the reducer tail is gone; paged KV cache (kv_tab / kv_bs); 6: per-row clocks (row_step0) in itts_embed_step / itts_sample_args (slot refill), itts_attn_prefill_prefix / _shared, kv_share in itts_attn_decode; 5: itts_ln_reduce takes up to 6 slabs */
+#define ITTS_ABI_VERSION 8 /* 8: prompt front-end (itts_subsample_conv, itts_mha_small, itts_glu_dwconv_ln_silu, itts_rows, itts_geglu, itts_prefix_rows) and speaker encoder (itts_im2col_reflect, itts_res2_step, itts_se_gate, itts_scale_resid, itts_col_stats, ITTS_EPI_RELU_AFFINE_*), ITTS_EPI_SILU_STORE, y_row0 / y_mtp and any M with rows_per_wg in itts_gemm_skinny, itts_gemm_conv ksplit <= 64; 7: LayerNorm folded into the consuming skinny GEMM (ln_c), residual epilogue with a packed T copy, rows_per_wg / wide_wg, bump words in itts_gemm_skinny / itts_embed_step (+ clamp, packed copy); the reducer tail is gone; paged KV cache (kv_tab / kv_bs); 6: per-row clocks (row_step0) in itts_embed_step / itts_sample_args (slot refill), itts_attn_prefill_prefix / _shared, kv_share in itts_attn_decode; 5: itts_ln_reduce takes up to 6 slabs */
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -120,6 +120,9 @@ int itts_aa_snake_fwd(const void* x, void* y, const float* alpha_log, const floa
 #define ITTS_EPI_SLAB_F32 5   /* yf (fp32 [ksplit][M][N]): slice ks stores its partial product (bias added by slice 0);
                                  the slabs are summed in order by itts_ln_reduce */
 #define ITTS_EPI_SILU_STORE 6 /* y (T [M][N]) = v * sigmoid(v)   (the Conformer's feed-forward activation) */
+#define ITTS_EPI_RELU_AFFINE_STORE 7      /* y (T) = relu(v) * post_scale[n] + post_shift[n]: a TDNN block of the speaker encoder,
+                                             eval-mode BatchNorm behind the ReLU (indextts/BigVGAN/ECAPA_TDNN.py:79-130) */
+#define ITTS_EPI_RELU_AFFINE_TANH_STORE 8 /* y (T) = tanh(relu(v) * post_scale[n] + post_shift[n])  (the attention branch of its pooling) */
 
 typedef struct itts_skinny_args {
   int dtype;
@@ -159,6 +162,8 @@ typedef struct itts_skinny_args {
    * x_mtp (packed x only; 0 = ceil(M / 16)): x is the first M rows of a packed operand of x_mtp row tiles. */
   int x_packed, y_packed;
   int y_row0, y_mtp, x_mtp;
+  const float* post_scale; /* [N], ITTS_EPI_RELU_AFFINE_* only */
+  const float* post_shift;
 } itts_skinny_args;
 int itts_gemm_skinny(const itts_skinny_args* a, void* stream);
 /* launch geometry itts_gemm_skinny would use: out8 = {grid.x, grid.y, waves per workgroup, column tiles per workgroup,
@@ -465,6 +470,30 @@ int itts_geglu(const void* h, void* y, int M, int Kp, int y_mtp, int dtype, void
 int itts_prefix_rows(const int64_t* text, const float* conds, int conds_rows, const float* text_emb, const float* text_pos, float* emb,
                      int64_t* mask, int32_t* pad, int B, int L, int C, int D, int start_tok, int stop_tok, int n_tok, int n_pos,
                      void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Speaker encoder (ECAPA-TDNN, indextts/BigVGAN/ECAPA_TDNN.py:470-581) over one prompt: its 1 x 1 convolutions are
+ * itts_gemm_skinny calls with the ITTS_EPI_RELU_AFFINE_* epilogues; the rest is below.  Activations are T-typed packed operands
+ * [frames][channels] of `mtp` row tiles; bf16 / f16 only.  The host side is indextts/BigVGAN/speaker_engine.py.
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* y (packed [T][Kp]) column j * F + f = x[reflect(t + (j - (taps-1)/2) * dil)][f] (x fp32 [T][F]), zeros from taps * F on: a k-tap
+ * convolution with reflect "same" padding (nnet/CNN.py:430-488) becomes a plain GEMM over this operand. */
+int itts_im2col_reflect(const float* x, void* y, int T, int F, int taps, int dil, int Kp, int y_mtp, int dtype, void* stream);
+/* One step of a Res2Net block (scale 8, 64-channel chunks): cat[:, 64 c : 64 c + 64] = BN(relu(conv_k3_dil(y1 chunk c [+ cat chunk
+ * c - 1 unless first]) + bias)), reflect padding; first also copies chunk 0 (cat[:, :64] = y1[:, :64]).  wp = itts_pack_weight of the
+ * [3 * 64][64] matrix (row = tap * 64 + input channel); bias / scale / shift fp32 [64]. */
+int itts_res2_step(const void* y1, void* cat, const void* wp, const float* bias, const float* scale, const float* shift, int T, int mtp,
+                   int chunk, int dil, int first, int dtype, void* stream);
+/* gate (fp32 [C]) = sigmoid(w2 relu(w1 mean_t(y) + b1) + b2): the squeeze-and-excitation gate; w1 T [H][C], w2 T [C][H] row-major. */
+int itts_se_gate(const void* y, const void* w1, const float* b1, const void* w2, const float* b2, float* gate, int T, int C, int H,
+                 int mtp, int dtype, void* stream);
+/* out = gate[c] * y + res over packed [T][C] operands of one geometry (out may be a k-step run of a wider operand). */
+int itts_scale_resid(const void* y, const void* res, const float* gate, void* out, int T, int C, int mtp, int dtype, void* stream);
+/* Per-channel statistics over time of packed x [T][C]: weights w_t = softmax_t(logit[t][c]) (logit T row-major [T][C]) or 1 / T
+ * (logit NULL); m = sum w x, s = sqrt(max(sum w (x - m)^2, 1e-12)); out (T [2 C]) = [m | s] * scale + shift (fp32 [2 C], or NULL):
+ * the global-context statistics and the attentive statistics pooling + BatchNorm (ECAPA_TDNN.py:543-581). */
+int itts_col_stats(const void* x, const void* logit, const float* scale, const float* shift, void* out, int T, int C, int mtp, int dtype,
+                   void* stream);
 
 #ifdef __cplusplus
 }

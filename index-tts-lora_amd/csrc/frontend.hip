@@ -482,6 +482,256 @@ __global__ __launch_bounds__(256) void prefix_rows_kernel(const int64_t* __restr
   }
 }
 
+// ===============================================================================================================
+// Speaker encoder (ECAPA-TDNN, indextts/BigVGAN/ECAPA_TDNN.py:470-581): what it needs besides the 1 x 1 convolutions,
+// which run on gemm_skinny with the ReLU + affine epilogues.  Activations are T-typed in the packed operand layout
+// ([frames][channels]; a run of 32-channel k-steps of a packed operand is itself a packed operand, so the three
+// SE-Res2Net outputs are written straight into the [frames][1536] operand of the MFA convolution).
+// ===============================================================================================================
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
+
+// x fp32 [T][F] -> packed T [T][Kp]: column j * F + f = x[reflect(t + (j - (taps-1)/2) * dil)][f], zero past taps * F: the
+// operand of the first TDNN block's k = 5 convolution (reflect "same" padding, nnet/CNN.py:430-488) as a plain GEMM.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_reflect_kernel(const float* __restrict__ x, T* __restrict__ y, int Tn, int F, int taps,
+                                                             int dil, int Kp, int mtp) {
+  const int t = blockIdx.x;
+  for (int k8 = threadIdx.x; k8 < Kp / 8; k8 += 256) {
+    typedef T t8 __attribute__((ext_vector_type(8)));
+    t8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = k8 * 8 + e, j = k / F, f = k - j * F;
+      o[e] = Elem<T>::from_f(j < taps ? x[(int64_t)reflect_idx(t + (j - (taps - 1) / 2) * dil, Tn) * F + f] : 0.f);
+    }
+    *reinterpret_cast<t8*>(y + pa_off<T>(t, k8 * 8, mtp)) = o;
+  }
+}
+
+// One step of a Res2Net block: chunk s of the block's first TDNN output (64 channels), plus the previous step's output,
+// through a k = 3 dilated convolution (reflect padding) -> ReLU -> BatchNorm affine, written as chunk s of the block's
+// concatenated output (ECAPA_TDNN.py Res2NetBlock).  y1 / cat: packed [T][C] operands (C = 64 * scale); grid = row tiles,
+// 4 waves = the four 16-channel output tiles; the weights are the A operand (a lane ends with 4 consecutive output channels).
+struct Res2Params {
+  const void* y1;
+  void* cat;
+  const void* wp;      // packed [3 * 64][64]
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  int T, mtp, s, dil, first;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void res2_step_kernel(Res2Params p) {
+  typedef Elem<T> EL;
+  typedef typename EL::frag frag;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
+  const int t0 = (int)blockIdx.x * 16;
+  const T* Y1 = (const T*)p.y1;
+  T* CAT = (T*)p.cat;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  frag wf[6], xf[6];
+#pragma unroll
+  for (int ks = 0; ks < 6; ++ks) {
+    const int j = ks >> 1, kk = ks & 1;
+    wf[ks] = ld16<frag>((const char*)p.wp + (((int64_t)wave * 6 + ks) * 64 + lane) * 16);
+    const int row = reflect_idx(min(t0 + r, p.T - 1) + (j - 1) * p.dil, p.T);
+    const int c0 = 64 * p.s + 32 * kk + 8 * g;
+    const frag a = ld16<frag>(Y1 + pa_off<T>(row, c0, p.mtp));
+    if (p.first) {
+      xf[ks] = a;
+    } else {
+      const frag b = ld16<frag>(CAT + pa_off<T>(row, c0 - 64, p.mtp));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xf[ks][e] = EL::from_f(EL::to_f(a[e]) + EL::to_f(b[e]));
+    }
+  }
+#pragma unroll
+  for (int ks = 0; ks < 6; ++ks) acc = EL::mma(wf[ks], xf[ks], acc);
+  const int row = t0 + r, col = 16 * wave + 4 * g;
+  if (row < p.T) {
+    const f32x4 bs = ld16<f32x4>(p.bias + col), sc = ld16<f32x4>(p.scale + col), sh = ld16<f32x4>(p.shift + col);
+    typedef T t4 __attribute__((ext_vector_type(4)));
+    t4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = EL::from_f(fmaf(fmaxf(acc[e] + bs[e], 0.f), sc[e], sh[e]));
+    *reinterpret_cast<t4*>(CAT + pa_off<T>(row, 64 * p.s + col, p.mtp)) = o;
+  }
+  if (p.first && tid < 128) {      // chunk 0 passes through unchanged
+    const int rr = tid >> 3, c8 = (tid & 7) * 8;
+    if (t0 + rr < p.T) st16(CAT + pa_off<T>(t0 + rr, c8, p.mtp), ld16<frag>(Y1 + pa_off<T>(t0 + rr, c8, p.mtp)));
+  }
+}
+
+// Squeeze-and-excitation gate of a block: g = sigmoid(W2 relu(W1 mean_t(y) + b1) + b2), y packed [T][C]; W1 T [H][C], W2 T [C][H]
+// row-major.  One workgroup of 1024 threads (300 frames x 512 channels: a few microseconds of one CU, one launch).
+template <typename T>
+__global__ __launch_bounds__(1024) void se_gate_kernel(const T* __restrict__ y, const T* __restrict__ w1, const float* __restrict__ b1,
+                                                       const T* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ gate,
+                                                       int Tn, int C, int H, int mtp) {
+  extern __shared__ __attribute__((aligned(16))) float se_lds[];   // part [16][C] | mean [C] | h [H]
+  float* part = se_lds;
+  float* mean = se_lds + 16 * C;
+  float* hid = mean + C;
+  typedef typename Elem<T>::frag frag;
+  const int tid = threadIdx.x;
+  const int nch = C / 8;                              // 16-byte chunks per row (<= 128 -> at least 8 row slices)
+  const int slices = 1024 / nch > 16 ? 16 : 1024 / nch;
+  {
+    const int ch = tid % nch, sl = tid / nch;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (sl < slices)
+      for (int t = sl; t < Tn; t += slices) {
+        const frag v = ld16<frag>(y + pa_off<T>(t, ch * 8, mtp));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += Elem<T>::to_f(v[e]);
+      }
+    if (sl < slices)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part[sl * C + ch * 8 + e] = a[e];
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 1024) {
+    float sum = 0.f;
+    for (int sl = 0; sl < slices; ++sl) sum += part[sl * C + c];
+    mean[c] = sum / (float)Tn;
+  }
+  __syncthreads();
+  for (int o = tid >> 3; o < H; o += 128) {          // 8 lanes per hidden unit
+    const int part8 = tid & 7;
+    float sum = 0.f;
+    for (int i = part8 * 8; i < C; i += 64) {
+      const frag wv = ld16<frag>(w1 + (int64_t)o * C + i);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum = fmaf(Elem<T>::to_f(wv[e]), mean[i + e], sum);
+    }
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    sum += __shfl_xor(sum, 4, 64);
+    if (part8 == 0) hid[o] = fmaxf(sum + b1[o], 0.f);
+  }
+  __syncthreads();
+  for (int c = tid >> 1; c < C; c += 512) {          // 2 lanes per channel
+    const int half = tid & 1;
+    float sum = 0.f;
+    for (int i = half * 8; i < H; i += 16) {
+      const frag wv = ld16<frag>(w2 + (int64_t)c * H + i);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum = fmaf(Elem<T>::to_f(wv[e]), hid[i + e], sum);
+    }
+    sum += __shfl_xor(sum, 1, 64);
+    if (half == 0) gate[c] = 1.f / (1.f + __expf(-(sum + b2[c])));
+  }
+}
+
+// out = gate[c] * y + res over packed [T][C] operands of identical geometry (the block's output: SE scaling + residual)
+template <typename T>
+__global__ __launch_bounds__(256) void scale_resid_kernel(const T* __restrict__ y, const T* __restrict__ res, const float* __restrict__ gate,
+                                                          T* __restrict__ out, int nchunks, int mtp) {
+  typedef typename Elem<T>::frag frag;
+  const int q = (int)blockIdx.x * 256 + threadIdx.x;
+  if (q >= nchunks) return;
+  const int blk = q >> 6, lane = q & 63;
+  const int ks = blk / mtp, col = ks * 32 + (lane >> 4) * 8;
+  const frag a = ld16<frag>(y + (int64_t)q * 8), b = ld16<frag>(res + (int64_t)q * 8);
+  const f32x4 g0 = ld16<f32x4>(gate + col), g1 = ld16<f32x4>(gate + col + 4);
+  frag o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = Elem<T>::from_f(fmaf(e < 4 ? g0[e & 3] : g1[e & 3], Elem<T>::to_f(a[e]), Elem<T>::to_f(b[e])));
+  st16(out + (int64_t)q * 8, o);
+}
+
+// Statistics over time of packed x [T][C], per channel, optionally weighted by softmax_t(logit[t][c]) (logit T row-major [T][C]):
+//   w_t = softmax over t (or 1 / T);  m = sum_t w_t x_t;  s = sqrt(max(sum_t w_t (x_t - m)^2, 1e-12))
+//   out (T [2 C]) = [m * scale[:C] + shift[:C] | s * scale[C:] + shift[C:]]   (scale / shift NULL = identity)
+// = the global-context statistics and the attentive statistics pooling (+ BatchNorm) of ECAPA_TDNN.py:543-581.
+// grid C / 64 workgroups of 256 threads: 8 column chunks x 32 row slices.
+template <typename T>
+__global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ x, const T* __restrict__ logit, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, T* __restrict__ out, int Tn, int C, int mtp) {
+  __shared__ float red[32][64];
+  __shared__ float tot[64];
+  typedef typename Elem<T>::frag frag;
+  const int tid = threadIdx.x, ch = tid & 7, sl = tid >> 3;
+  const int c0 = (int)blockIdx.x * 64 + ch * 8;
+  auto reduce = [&](const float (&v)[8], bool is_max) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[sl][ch * 8 + e] = v[e];
+    __syncthreads();
+    if (tid < 64) {
+      float a = red[0][tid];
+      for (int i = 1; i < 32; ++i) a = is_max ? fmaxf(a, red[i][tid]) : a + red[i][tid];
+      tot[tid] = a;
+    }
+    __syncthreads();
+  };
+  float mx[8], v[8];
+  const bool wtd = logit != nullptr;
+  if (wtd) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = -INFINITY;
+    for (int t = sl; t < Tn; t += 32) {
+      const frag l = ld16<frag>(logit + (int64_t)t * C + c0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], Elem<T>::to_f(l[e]));
+    }
+    reduce(v, true);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mx[e] = tot[ch * 8 + e];
+  }
+  // normaliser and weighted sum
+  float se[8], sx[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) se[e] = sx[e] = 0.f;
+  for (int t = sl; t < Tn; t += 32) {
+    const frag xv = ld16<frag>(x + pa_off<T>(t, c0, mtp));
+    frag l = xv;
+    if (wtd) l = ld16<frag>(logit + (int64_t)t * C + c0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float w = wtd ? __expf(Elem<T>::to_f(l[e]) - mx[e]) : 1.f;
+      se[e] += w;
+      sx[e] = fmaf(w, Elem<T>::to_f(xv[e]), sx[e]);
+    }
+  }
+  float den[8], mean[8];
+  reduce(se, false);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) den[e] = tot[ch * 8 + e];
+  reduce(sx, false);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) mean[e] = tot[ch * 8 + e] / den[e];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  for (int t = sl; t < Tn; t += 32) {
+    const frag xv = ld16<frag>(x + pa_off<T>(t, c0, mtp));
+    frag l = xv;
+    if (wtd) l = ld16<frag>(logit + (int64_t)t * C + c0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float w = wtd ? __expf(Elem<T>::to_f(l[e]) - mx[e]) : 1.f;
+      const float d = Elem<T>::to_f(xv[e]) - mean[e];
+      v[e] = fmaf(w * d, d, v[e]);
+    }
+  }
+  reduce(v, false);
+  if (sl == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + e;
+      float m = mean[e], sd = sqrtf(fmaxf(tot[ch * 8 + e] / den[e], 1e-12f));
+      if (scale != nullptr) {
+        m = fmaf(m, scale[c], shift[c]);
+        sd = fmaf(sd, scale[C + c], shift[C + c]);
+      }
+      out[c] = Elem<T>::from_f(m);
+      out[C + c] = Elem<T>::from_f(sd);
+    }
+  }
+}
+
 }  // namespace itts
 
 using namespace itts;
@@ -609,4 +859,69 @@ extern "C" int itts_prefix_rows(const int64_t* text, const float* conds, int con
   hipLaunchKernelGGL(prefix_rows_kernel, dim3((P + 7) / 8, B), dim3(256), 0, (hipStream_t)stream, text, conds, conds_rows, text_emb,
                      text_pos, emb, mask, pad, L, C, D, start_tok, stop_tok, n_tok, n_pos);
   return check_launch("itts_prefix_rows");
+}
+
+#define ITTS_FE_DTYPE(who) ITTS_REQUIRE(dtype == ITTS_BF16 || dtype == ITTS_F16, who ": built for bf16 / f16")
+
+extern "C" int itts_im2col_reflect(const float* x, void* y, int T, int F, int taps, int dil, int Kp, int y_mtp, int dtype, void* stream) {
+  ITTS_REQUIRE(x && y && T > 0 && F > 0 && taps > 0 && taps % 2 == 1 && dil > 0, "itts_im2col_reflect: bad arguments");
+  ITTS_FE_DTYPE("itts_im2col_reflect");
+  ITTS_REQUIRE(Kp % 32 == 0 && Kp >= taps * F && y_mtp * 16 >= T, "itts_im2col_reflect: Kp %% 32 == 0, Kp >= taps * F, y_mtp covers T");
+  ITTS_REQUIRE((taps - 1) / 2 * dil < T, "itts_im2col_reflect: the reflect padding needs more than %d frames", (taps - 1) / 2 * dil);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == ITTS_BF16) hipLaunchKernelGGL(im2col_reflect_kernel<bf16_t>, dim3(T), dim3(256), 0, s, x, (bf16_t*)y, T, F, taps, dil, Kp, y_mtp);
+  else hipLaunchKernelGGL(im2col_reflect_kernel<f16_t>, dim3(T), dim3(256), 0, s, x, (f16_t*)y, T, F, taps, dil, Kp, y_mtp);
+  return check_launch("itts_im2col_reflect");
+}
+
+extern "C" int itts_res2_step(const void* y1, void* cat, const void* wp, const float* bias, const float* scale, const float* shift, int T,
+                              int mtp, int chunk, int dil, int first, int dtype, void* stream) {
+  ITTS_REQUIRE(y1 && cat && wp && bias && scale && shift && T > 0 && chunk >= 1 && dil > 0, "itts_res2_step: bad arguments");
+  ITTS_FE_DTYPE("itts_res2_step");
+  ITTS_REQUIRE(mtp * 16 >= T && dil < T, "itts_res2_step: mtp covers T, dilation < T");
+  Res2Params p;
+  p.y1 = y1; p.cat = cat; p.wp = wp; p.bias = bias; p.scale = scale; p.shift = shift;
+  p.T = T; p.mtp = mtp; p.s = chunk; p.dil = dil; p.first = first != 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == ITTS_BF16) hipLaunchKernelGGL(res2_step_kernel<bf16_t>, dim3((T + 15) / 16), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(res2_step_kernel<f16_t>, dim3((T + 15) / 16), dim3(256), 0, s, p);
+  return check_launch("itts_res2_step");
+}
+
+extern "C" int itts_se_gate(const void* y, const void* w1, const float* b1, const void* w2, const float* b2, float* gate, int T, int C,
+                            int H, int mtp, int dtype, void* stream) {
+  ITTS_REQUIRE(y && w1 && b1 && w2 && b2 && gate && T > 0, "itts_se_gate: bad arguments");
+  ITTS_FE_DTYPE("itts_se_gate");
+  ITTS_REQUIRE(C % 64 == 0 && C <= 1024 && H % 16 == 0 && H <= 512 && mtp * 16 >= T, "itts_se_gate: C %% 64, C <= 1024, H %% 16, H <= 512");
+  const size_t lds = (size_t)(17 * C + H) * 4;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == ITTS_BF16)
+    hipLaunchKernelGGL(se_gate_kernel<bf16_t>, dim3(1), dim3(1024), lds, s, (const bf16_t*)y, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, gate, T, C, H, mtp);
+  else
+    hipLaunchKernelGGL(se_gate_kernel<f16_t>, dim3(1), dim3(1024), lds, s, (const f16_t*)y, (const f16_t*)w1, b1, (const f16_t*)w2, b2, gate, T, C, H, mtp);
+  return check_launch("itts_se_gate");
+}
+
+extern "C" int itts_scale_resid(const void* y, const void* res, const float* gate, void* out, int T, int C, int mtp, int dtype, void* stream) {
+  ITTS_REQUIRE(y && res && gate && out && T > 0 && C % 32 == 0 && mtp * 16 >= T, "itts_scale_resid: bad arguments");
+  ITTS_FE_DTYPE("itts_scale_resid");
+  const int nchunks = C / 32 * mtp * 64;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((nchunks + 255) / 256), block(256);
+  if (dtype == ITTS_BF16) hipLaunchKernelGGL(scale_resid_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)y, (const bf16_t*)res, gate, (bf16_t*)out, nchunks, mtp);
+  else hipLaunchKernelGGL(scale_resid_kernel<f16_t>, grid, block, 0, s, (const f16_t*)y, (const f16_t*)res, gate, (f16_t*)out, nchunks, mtp);
+  return check_launch("itts_scale_resid");
+}
+
+extern "C" int itts_col_stats(const void* x, const void* logit, const float* scale, const float* shift, void* out, int T, int C, int mtp,
+                              int dtype, void* stream) {
+  ITTS_REQUIRE(x && out && T > 0 && C % 64 == 0 && mtp * 16 >= T, "itts_col_stats: bad arguments (C %% 64 == 0)");
+  ITTS_REQUIRE((scale == nullptr) == (shift == nullptr), "itts_col_stats: scale and shift come together");
+  ITTS_FE_DTYPE("itts_col_stats");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == ITTS_BF16)
+    hipLaunchKernelGGL(col_stats_kernel<bf16_t>, dim3(C / 64), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)logit, scale, shift, (bf16_t*)out, T, C, mtp);
+  else
+    hipLaunchKernelGGL(col_stats_kernel<f16_t>, dim3(C / 64), dim3(256), 0, s, (const f16_t*)x, (const f16_t*)logit, scale, shift, (f16_t*)out, T, C, mtp);
+  return check_launch("itts_col_stats");
 }

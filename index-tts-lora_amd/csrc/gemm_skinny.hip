@@ -66,6 +66,8 @@ struct SkinnyParams {
   int x_pa, y_pa;          // packed-activation layout for x / y
   int mtp, row0;           // row tiles of the WHOLE operand, first row of this launch (a multiple of 16)
   int y_mtp, y_row0;       // the same for a packed y (the rows may land inside a taller packed operand)
+  const float* post_scale; // RELU_AFFINE epilogues: y = relu(v) * post_scale[n] + post_shift[n]
+  const float* post_shift;
 #if ITTS_STAMPS
   unsigned long long* stamps;
 #endif
@@ -374,6 +376,18 @@ __global__ __launch_bounds__(MAXW * 64) void gemm_skinny_kernel(SkinnyParams p) 
         for (int e = 0; e < 4; ++e) sv[e] = v[e] / (1.f + __expf(-v[e]));
         store4<T>((T*)p.y + (p.y_pa ? pa_off<T>(p.y_row0 + row, col0, p.y_mtp) : (int64_t)row * p.N + col0), sv, nval);
       } break;
+      case ITTS_EPI_RELU_AFFINE_STORE:
+      case ITTS_EPI_RELU_AFFINE_TANH_STORE: {
+        // TDNN block of the speaker encoder: BatchNorm (eval: an affine map per channel) BEHIND the ReLU
+        const f32x4 sc = load4f(p.post_scale + col0, nval), sh = load4f(p.post_shift + col0, nval);
+        f32x4 rv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          rv[e] = fmaf(fmaxf(v[e], 0.f), sc[e], sh[e]);
+          if (p.epi == ITTS_EPI_RELU_AFFINE_TANH_STORE) rv[e] = tanhf(rv[e]);
+        }
+        store4<T>((T*)p.y + (p.y_pa ? pa_off<T>(p.y_row0 + row, col0, p.y_mtp) : (int64_t)row * p.N + col0), rv, nval);
+      } break;
       case ITTS_EPI_RESID_F32: {
         // residual stream update, one owner per element (no split-K): the old values were requested with the bias.  The
         // T-typed copy (p.y, optional) is what the next LayerNorm-folded GEMM multiplies.
@@ -580,8 +594,11 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
   else if (a->epi == ITTS_EPI_RESID_F32 || a->epi == ITTS_EPI_STORE_F32 || a->epi == ITTS_EPI_SLAB_F32)
     ITTS_REQUIRE(a->yf, "itts_gemm_skinny: yf is null");
   else
-    ITTS_REQUIRE((a->epi == ITTS_EPI_STORE || a->epi == ITTS_EPI_GELU_STORE || a->epi == ITTS_EPI_SILU_STORE) && a->y,
+    ITTS_REQUIRE((a->epi == ITTS_EPI_STORE || a->epi == ITTS_EPI_GELU_STORE || a->epi == ITTS_EPI_SILU_STORE ||
+                  a->epi == ITTS_EPI_RELU_AFFINE_STORE || a->epi == ITTS_EPI_RELU_AFFINE_TANH_STORE) && a->y,
                  "itts_gemm_skinny: bad epilogue %d", a->epi);
+  if (a->epi == ITTS_EPI_RELU_AFFINE_STORE || a->epi == ITTS_EPI_RELU_AFFINE_TANH_STORE)
+    ITTS_REQUIRE(a->post_scale && a->post_shift, "itts_gemm_skinny: the ReLU + affine epilogues need post_scale and post_shift");
   if (a->epi == ITTS_EPI_RESID_F32)
     ITTS_REQUIRE(a->N % 4 == 0 && (int64_t)a->M * a->N < (1ll << 29), "itts_gemm_skinny: the residual epilogue needs N %% 4 == 0");
   if (a->ln_c != nullptr)
@@ -591,6 +608,7 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
   ITTS_REQUIRE(a->rows_per_wg == 0 || a->rows_per_wg == 16 || a->rows_per_wg == 32, "itts_gemm_skinny: rows_per_wg must be 0, 16 or 32");
   if (a->y_packed)
     ITTS_REQUIRE((a->epi == ITTS_EPI_STORE || a->epi == ITTS_EPI_GELU_STORE || a->epi == ITTS_EPI_SILU_STORE ||
+                  a->epi == ITTS_EPI_RELU_AFFINE_STORE || a->epi == ITTS_EPI_RELU_AFFINE_TANH_STORE ||
                   a->epi == ITTS_EPI_RESID_F32) && a->N % ks == 0 && a->y,
                  "itts_gemm_skinny: a packed y needs the STORE / GELU_STORE / SILU_STORE / RESID_F32 epilogue and N %% %d == 0", ks);
   const int y_mtp = a->y_mtp > 0 ? a->y_mtp : (a->M + 15) / 16;
@@ -616,6 +634,8 @@ extern "C" int itts_gemm_skinny(const itts_skinny_args* a, void* stream) {
     p.mtp = a->x_mtp > 0 ? a->x_mtp : (a->M + 15) / 16;
     p.row0 = r0;
     p.y_mtp = y_mtp;
+    p.post_scale = a->post_scale;
+    p.post_shift = a->post_shift;
     p.y_row0 = r0 + a->y_row0;
     p.epi = a->epi;
     const size_t ycols = a->epi == ITTS_EPI_QKV_CACHE ? (size_t)a->N / 3 : (size_t)a->N;

@@ -13,6 +13,7 @@ speaker encoder and the 1x1 conditioning projections (a few MFLOP, once per call
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -20,6 +21,7 @@ import torch.nn.functional as F
 
 from .. import _native as nat
 from .ECAPA_TDNN import ecapa_embed
+from .speaker_engine import SpeakerEngine
 
 
 def kaiser_sinc_filter(cutoff=0.25, half_width=0.3, kernel_size=12) -> np.ndarray:
@@ -174,9 +176,24 @@ class BigVGAN:
         self._built = P
 
     # ---- forward ----------------------------------------------------------------------------------------------
-    def speaker_embedding(self, mel_ref: torch.Tensor) -> torch.Tensor:
+    def speaker_engine(self):
+        """The ECAPA-TDNN speaker encoder on the HIP kernels (speaker_engine.py), or None for an fp32 vocoder: a 16-bit vocoder (the
+        benched precision) runs it in fp16; fp32 keeps the functional PyTorch form, the parity mode."""
         self._build()
-        return ecapa_embed(self._built["spk"], mel_ref.to(self.device, torch.float32))
+        if self.dtype == torch.float32 or os.environ.get("ITTS_NATIVE_SPEAKER", "1") == "0":
+            return None
+        if self._built.get("spk_engine") is None:
+            self._built["spk_engine"] = SpeakerEngine(self._built["spk"], dtype=torch.float16, device=self.device)
+        return self._built["spk_engine"]
+
+    def speaker_embedding(self, mel_ref: torch.Tensor) -> torch.Tensor:
+        """mel_ref [B, Tref, 100] -> [B, 1, 512] fp32."""
+        self._build()
+        mel = mel_ref.to(self.device, torch.float32)
+        eng = self.speaker_engine()
+        if eng is not None and mel.shape[1] > 8:          # (the reflect padding of the dilated convolutions needs a few frames)
+            return torch.stack([eng(mel[i].contiguous()).clone() for i in range(mel.shape[0])], 0)[:, None, :]
+        return ecapa_embed(self._built["spk"], mel)
 
     def _act(self, x, ab, out=None, valid=None):
         P = self._built

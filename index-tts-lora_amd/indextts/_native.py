@@ -13,6 +13,7 @@ import torch
 
 F32, BF16, F16 = 0, 1, 2
 EPI_STORE, EPI_GELU_STORE, EPI_RESID_F32, EPI_QKV_CACHE, EPI_STORE_F32, EPI_SLAB_F32, EPI_SILU_STORE = 0, 1, 2, 3, 4, 5, 6
+EPI_RELU_AFFINE_STORE, EPI_RELU_AFFINE_TANH_STORE = 7, 8
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libindextts_hip.so")
@@ -30,7 +31,8 @@ class SkinnyArgs(C.Structure):
                 ("kcache", C.c_void_p), ("vcache", C.c_void_p), ("pos", C.c_void_p), ("heads", C.c_int),
                 ("smax", C.c_int), ("ksplit", C.c_int), ("ln_c", C.c_void_p), ("ln_eps", C.c_float), ("bump", C.c_void_p),
                 ("rows_per_wg", C.c_int), ("wide_wg", C.c_int), ("kv_tab", C.c_void_p), ("kv_bs", C.c_int),
-                ("x_packed", C.c_int), ("y_packed", C.c_int), ("y_row0", C.c_int), ("y_mtp", C.c_int), ("x_mtp", C.c_int)]
+                ("x_packed", C.c_int), ("y_packed", C.c_int), ("y_row0", C.c_int), ("y_mtp", C.c_int), ("x_mtp", C.c_int),
+                ("post_scale", C.c_void_p), ("post_shift", C.c_void_p)]
 
 
 class MhaArgs(C.Structure):
@@ -123,6 +125,14 @@ _SIGNATURES = {
                                           C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "itts_rows": (C.c_int, [C.POINTER(RowsArgs), C.c_void_p]),
     "itts_geglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "itts_im2col_reflect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "itts_res2_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "itts_se_gate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                               C.c_int, C.c_int, C.c_void_p]),
+    "itts_scale_resid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "itts_col_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_void_p]),
     "itts_prefix_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
@@ -227,12 +237,12 @@ def aa_snake(x, alpha_log, beta_log, up_f, down_f, layout=0, out=None, valid_row
 
 def gemm_skinny(dtype, M, N, K, wp, bias=None, x=None, epi=EPI_STORE, y=None, yf=None, kcache=None, vcache=None, pos=None,
                 heads=0, smax=0, ksplit=1, x_packed=False, y_packed=False, ln_c=None, ln_eps=1e-5, bump=None, rows_per_wg=0,
-                wide_wg=False, kv_tab=None, kv_bs=0, y_row0=0, y_mtp=0, x_mtp=0):
+                wide_wg=False, kv_tab=None, kv_bs=0, y_row0=0, y_mtp=0, x_mtp=0, post=None):
     """ln_c fp32 [N]: LayerNorm folded into the GEMM -- x holds the RAW rows, wp = pack(gamma . W), bias = beta W + b
     (see itts_skinny_args).  EPI_RESID_F32: yf += x W + bias, and y (optional, T) receives a copy of the new rows.
     bump: int32 device word the launch increments.  rows_per_wg / wide_wg: launch-geometry hints.
     y_row0 / y_mtp: a packed y's rows land at [y_row0, y_row0 + M) of an operand of y_mtp row tiles; x_mtp: a packed x is the
-    first M rows of an operand of x_mtp row tiles."""
+    first M rows of an operand of x_mtp row tiles.  post = (scale, shift) fp32 [N]: the EPI_RELU_AFFINE_* epilogues."""
     a = SkinnyArgs()
     a.dtype, a.M, a.N, a.K = dt(dtype), M, N, K
     a.wp, a.bias, a.x = _p(wp), _p(bias), _p(x)
@@ -243,6 +253,8 @@ def gemm_skinny(dtype, M, N, K, wp, bias=None, x=None, epi=EPI_STORE, y=None, yf
     a.rows_per_wg, a.wide_wg = int(rows_per_wg), int(bool(wide_wg))
     a.kv_tab, a.kv_bs = _p(kv_tab), int(kv_bs)
     a.y_row0, a.y_mtp, a.x_mtp = int(y_row0), int(y_mtp), int(x_mtp)
+    if post is not None:
+        a.post_scale, a.post_shift = _p(post[0]), _p(post[1])
     _check(lib().itts_gemm_skinny(C.byref(a), _stream()), "itts_gemm_skinny")
 
 
@@ -307,6 +319,32 @@ def prefix_rows(text, conds, text_emb, text_pos, start_tok, stop_tok):
     _check(lib().itts_prefix_rows(_p(text), _p(conds), Bc, _p(text_emb), _p(text_pos), _p(emb), _p(mask), _p(pad), B, L, Cn, D,
                                   int(start_tok), int(stop_tok), text_emb.shape[0], text_pos.shape[0], _stream()), "itts_prefix_rows")
     return emb, mask, pad
+
+
+def im2col_reflect(x, y, taps, dil, Kp, y_mtp):
+    """x fp32 [T, F] -> y T packed [T, Kp]: the k-tap reflect-padded convolution's operand (itts_im2col_reflect)."""
+    _dev(x, y)
+    _check(lib().itts_im2col_reflect(_p(x), _p(y), x.shape[0], x.shape[1], taps, dil, Kp, y_mtp, dt(y.dtype), _stream()), "itts_im2col_reflect")
+
+
+def res2_step(y1, cat, wp, bias, scale, shift, T, mtp, chunk, dil, first):
+    _check(lib().itts_res2_step(_p(y1), _p(cat), _p(wp), _p(bias), _p(scale), _p(shift), T, mtp, chunk, dil, int(bool(first)),
+                                dt(cat.dtype), _stream()), "itts_res2_step")
+
+
+def se_gate(y, w1, b1, w2, b2, gate, T, Cn, H, mtp):
+    _dev(y, w1, b1, w2, b2, gate)
+    _check(lib().itts_se_gate(_p(y), _p(w1), _p(b1), _p(w2), _p(b2), _p(gate), T, Cn, H, mtp, dt(y.dtype), _stream()), "itts_se_gate")
+
+
+def scale_resid(y, res, gate, out, T, Cn, mtp):
+    """out = gate * y + res over packed [T, Cn] operands (res / out may be k-step runs of a wider packed operand: views)."""
+    _check(lib().itts_scale_resid(_p(y), _p(res), _p(gate), _p(out), T, Cn, mtp, dt(y.dtype), _stream()), "itts_scale_resid")
+
+
+def col_stats(x, out, T, Cn, mtp, logit=None, scale=None, shift=None):
+    """out T [2 Cn] = [mean | std] over time of packed x [T, Cn], optionally softmax(logit)-weighted and affine-mapped."""
+    _check(lib().itts_col_stats(_p(x), _p(logit), _p(scale), _p(shift), _p(out), T, Cn, mtp, dt(out.dtype), _stream()), "itts_col_stats")
 
 
 def packed_rows(M: int) -> int:

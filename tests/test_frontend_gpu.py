@@ -266,3 +266,116 @@ def test_prefix_rows_matches_torch(B, L, C, D, shared):
     remb, rmask, rpad = _prefix_ref(t, conds, te, tp, start, stop)
     assert torch.equal(mask, rmask) and torch.equal(pad, rpad)
     assert torch.equal(emb, remb)
+
+
+# ---------------------------------------------------------------------------------------------------- speaker encoder
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_im2col_reflect_and_res2_step(dtype):
+    """The two convolution forms of the speaker encoder against F.conv1d over a reflect-padded signal."""
+    from indextts import _native as nat
+    T, Fq, C = 45, 100, 512
+    mtp = (T + 15) // 16
+    x = rnd(T, Fq, seed=40)
+    Kp = 512
+    col = torch.zeros(mtp * 16 * Kp, dtype=dtype, device=DEV)
+    nat.im2col_reflect(x, col, 5, 1, Kp, mtp)
+    got = nat.unpack_activation(col, T, Kp).float()
+    xp = F.pad(x.t()[None], (2, 2), mode="reflect")[0].t()                    # [T + 4, F]
+    ref = torch.cat([xp[j:j + T] for j in range(5)], dim=1)                    # [T, 500]
+    assert torch.equal(got[:, :500], ref.to(dtype).float()) and (got[:, 500:] == 0).all()
+    # one Res2Net step: chunk 3 of y1 plus chunk 2 of cat, dilation 3
+    y1 = rnd(T, C, seed=41).to(dtype)
+    cat = rnd(T, C, seed=42).to(dtype)
+    w, b = rnd(64, 64, 3, seed=43, scale=0.08), rnd(64, seed=44, scale=0.1)
+    sc, sh = 1.0 + rnd(64, seed=45, scale=0.1), rnd(64, seed=46, scale=0.1)
+    wp = nat.pack_weight(w.permute(2, 1, 0).reshape(192, 64).to(dtype).contiguous())
+    for first in (False, True):
+        y1p, catp = nat.pack_activation(y1), nat.pack_activation(cat)
+        nat.res2_step(y1p, catp, wp, b, sc, sh, T, mtp, 3, 3, first)
+        out = nat.unpack_activation(catp, T, C)
+        inp = y1[:, 192:256].float() if first else (y1[:, 192:256].float() + cat[:, 128:192].float()).to(dtype).float()
+        z = F.conv1d(F.pad(inp.t()[None], (3, 3), mode="reflect"), w.to(dtype).float(), b, dilation=3)[0].t()
+        ref = F.relu(z) * sc + sh
+        assert (out[:, 192:256].float() - ref).abs().max().item() <= 6 * RES[dtype] * max(1.0, ref.abs().max().item())
+        keep = torch.ones(C, dtype=torch.bool)
+        keep[192:256] = False
+        if first:
+            keep[:64] = False
+            assert torch.equal(out[:, :64], y1[:, :64])
+        assert torch.equal(out[:, keep.to(DEV)], cat[:, keep.to(DEV)])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_se_gate_scale_resid_col_stats(dtype):
+    from indextts import _native as nat
+    T, C, H = 77, 512, 128
+    mtp = (T + 15) // 16
+    y, res = rnd(T, C, seed=50).to(dtype), rnd(T, C, seed=51).to(dtype)
+    w1, b1 = rnd(H, C, seed=52, scale=C ** -0.5).to(dtype), rnd(H, seed=53, scale=0.1)
+    w2, b2 = rnd(C, H, seed=54, scale=H ** -0.5).to(dtype), rnd(C, seed=55, scale=0.1)
+    gate = torch.empty(C, device=DEV)
+    yp = nat.pack_activation(y)
+    nat.se_gate(yp, w1, b1, w2, b2, gate, T, C, H, mtp)
+    ref_g = torch.sigmoid(F.relu(y.float().mean(0) @ w1.float().t() + b1) @ w2.float().t() + b2)
+    assert (gate - ref_g).abs().max().item() < 1e-4
+    wide = torch.zeros(mtp * 16 * 3 * C, dtype=dtype, device=DEV)             # a [T][3 C] operand; write its middle third
+    off = (C // 32) * mtp * 512
+    nat.scale_resid(yp, nat.pack_activation(res), gate, wide[off:], T, C, mtp)
+    got = nat.unpack_activation(wide, T, 3 * C)
+    ref = gate * y.float() + res.float()
+    assert (got[:, C:2 * C].float() - ref).abs().max().item() <= 2 * RES[dtype] * max(1.0, ref.abs().max().item())
+    assert (got[:, :C] == 0).all() and (got[:, 2 * C:] == 0).all()
+    # statistics: plain and softmax-weighted + affine
+    x = (rnd(T, C, seed=56) * 1.5 + 0.7).to(dtype)
+    xp = nat.pack_activation(x)
+    out = torch.empty(2 * C, dtype=dtype, device=DEV)
+    nat.col_stats(xp, out, T, C, mtp)
+    xf = x.float()
+    m = xf.mean(0)
+    sd = torch.sqrt(((xf - m) ** 2).mean(0).clamp(1e-12))
+    assert (out.float() - torch.cat([m, sd])).abs().max().item() <= 2 * RES[dtype] * 4
+    logit = rnd(T, C, seed=57, scale=2.0).to(dtype)
+    sc, sh = 1.0 + rnd(2 * C, seed=58, scale=0.1), rnd(2 * C, seed=59, scale=0.1)
+    nat.col_stats(xp, out, T, C, mtp, logit=logit, scale=sc, shift=sh)
+    a = torch.softmax(logit.float(), dim=0)
+    m = (a * xf).sum(0)
+    sd = torch.sqrt((a * (xf - m) ** 2).sum(0).clamp(1e-12))
+    ref = torch.cat([m, sd]) * sc + sh
+    assert (out.float() - ref).abs().max().item() <= 2 * RES[dtype] * 4
+
+
+def _vocoder(dtype):
+    from indextts.BigVGAN.models import BigVGAN
+    from indextts.utils.config import Config
+    v = BigVGAN(Config(weights.reference_config()["bigvgan"]))
+    v.load_state_dict(weights.bigvgan_state_dict())
+    v.to(DEV).to(dtype).remove_weight_norm()
+    return v
+
+
+@pytest.mark.parametrize("frames", [300, 57, 1000])
+def test_speaker_engine_matches_functional_fp32(frames):
+    v = _vocoder(torch.float16)
+    mel = torch.from_numpy(synth.uniform("in.ref_mel", (2, frames, 100), -6.0, 2.0)).to(DEV)
+    mel[1] *= 0.5
+    got = v.speaker_embedding(mel)
+    assert v.speaker_engine() is not None and v.speaker_engine().launches == 2 + 3 * 11 + 7
+    os.environ["ITTS_NATIVE_SPEAKER"] = "0"
+    try:
+        ref = v.speaker_embedding(mel)
+    finally:
+        del os.environ["ITTS_NATIVE_SPEAKER"]
+    assert got.shape == ref.shape == (2, 1, 512) and torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    assert err < 2e-2 * max(1.0, ref.abs().max().item()), (err, ref.abs().max().item())
+    assert not torch.equal(got[0], got[1])
+
+
+def test_speaker_engine_against_reference_fixture():
+    """spk4 of the reference run (tests/golden/bigvgan.npz)."""
+    g = np.load(os.path.join(G, "bigvgan.npz"))
+    v = _vocoder(torch.float16)
+    got = v.speaker_embedding(torch.from_numpy(g["melref"]).to(DEV))
+    ref = torch.from_numpy(g["spk4"]).to(DEV)
+    assert (got - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item())
+    assert _vocoder(torch.float32).speaker_engine() is None

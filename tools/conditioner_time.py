@@ -44,11 +44,30 @@ def graphed(fn):
     return g, out
 
 
-print(f"frames {frames}: HIP engine, {eng.launches} launches")
-print(f"  eager        {bench(lambda: eng(row), reps):8.3f} ms")
+print(f"conditioner, frames {frames}: HIP engine")
+print(f"  eager        {bench(lambda: eng(row), reps):8.3f} ms  ({eng.launches} launches)")
 g, out = graphed(lambda: eng(row))
 print(f"  graph replay {bench(g.replay, reps):8.3f} ms")
 os.environ["ITTS_NATIVE_CONDITIONER"] = "0"
 g2, out2 = graphed(lambda: m.get_conditioning(mel, None))
 print(f"functional PyTorch form (fp32), graph replay {bench(g2.replay, reps):8.3f} ms")
 print(f"max |HIP - functional| = {(out - out2[0]).abs().max().item():.2e}")
+
+# ---- the speaker encoder (ECAPA-TDNN), same prompt
+from indextts.BigVGAN.models import BigVGAN  # noqa: E402
+from indextts.utils.config import Config  # noqa: E402
+
+del os.environ["ITTS_NATIVE_CONDITIONER"]
+v = BigVGAN(Config(weights.reference_config()["bigvgan"]))
+v.load_state_dict(weights.bigvgan_state_dict())
+v.to("cuda").to(torch.float16).remove_weight_norm()
+mel_btf = mel.transpose(1, 2).contiguous()
+se = v.speaker_engine()
+print(f"speaker encoder, frames {frames}: HIP engine")
+print(f"  eager        {bench(lambda: se(row), reps):8.3f} ms  ({se.launches} launches)")
+g3, out3 = graphed(lambda: se(row))
+print(f"  graph replay {bench(g3.replay, reps):8.3f} ms")
+os.environ["ITTS_NATIVE_SPEAKER"] = "0"
+g4, out4 = graphed(lambda: v.speaker_embedding(mel_btf))
+print(f"functional PyTorch form (fp32), graph replay {bench(g4.replay, reps):8.3f} ms")
+print(f"max |HIP - functional| = {(out3 - out4[0, 0]).abs().max().item():.2e} (embedding max {out4.abs().max().item():.2f})")
