@@ -570,41 +570,48 @@ template <typename T>
 __global__ __launch_bounds__(1024) void se_gate_kernel(const T* __restrict__ y, const T* __restrict__ w1, const float* __restrict__ b1,
                                                        const T* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ gate,
                                                        int Tn, int C, int H, int mtp) {
-  extern __shared__ __attribute__((aligned(16))) float se_lds[];   // part [16][C] | mean [C] | h [H]
-  float* part = se_lds;
-  float* mean = se_lds + 16 * C;
+  extern __shared__ __attribute__((aligned(16))) float se_lds[];   // mean [C] | h [H]
+  float* mean = se_lds;
   float* hid = mean + C;
   typedef typename Elem<T>::frag frag;
   const int tid = threadIdx.x;
-  const int nch = C / 8;                              // 16-byte chunks per row (<= 128 -> at least 8 row slices)
-  const int slices = 1024 / nch > 16 ? 16 : 1024 / nch;
   {
-    const int ch = tid % nch, sl = tid / nch;
-    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (sl < slices)
-      for (int t = sl; t < Tn; t += slices) {
-        const frag v = ld16<frag>(y + pa_off<T>(t, ch * 8, mtp));
+    // column sums: a wave walks the 1-KiB blocks of one 32-channel k-step (lane (g, r) = row r, channels 8 g .. 8 g + 7 of the
+    // block: one contiguous wave-load per block), four blocks in flight, then folds the 16 rows of the lanes together
+    const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
+    for (int ks = wave; ks < C / 32; ks += 16) {
+      float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int mt = 0; mt < mtp; mt += 4) {
+        frag v[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] += Elem<T>::to_f(v[e]);
+        for (int j = 0; j < 4; ++j)
+          v[j] = (mt + j < mtp && (mt + j) * 16 + r < Tn) ? ld16<frag>(y + (((int64_t)ks * mtp + mt + j) * 64 + lane) * 8) : zero_frag<frag>();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] += Elem<T>::to_f(v[j][e]);
       }
-    if (sl < slices)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) part[sl * C + ch * 8 + e] = a[e];
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) a[e] += __shfl_xor(a[e], o, 64);
+        if (r == 0) mean[ks * 32 + g * 8 + e] = a[e] / (float)Tn;
+      }
+    }
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 1024) {
-    float sum = 0.f;
-    for (int sl = 0; sl < slices; ++sl) sum += part[sl * C + c];
-    mean[c] = sum / (float)Tn;
-  }
-  __syncthreads();
-  for (int o = tid >> 3; o < H; o += 128) {          // 8 lanes per hidden unit
+  for (int o = tid >> 3; o < H; o += 128) {          // 8 lanes per hidden unit; 8 weight requests in flight per lane
     const int part8 = tid & 7;
     float sum = 0.f;
-    for (int i = part8 * 8; i < C; i += 64) {
-      const frag wv = ld16<frag>(w1 + (int64_t)o * C + i);
+    for (int i0 = part8 * 8; i0 < C; i0 += 512) {
+      frag wv[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) sum = fmaf(Elem<T>::to_f(wv[e]), mean[i + e], sum);
+      for (int j = 0; j < 8; ++j) wv[j] = i0 + 64 * j < C ? ld16<frag>(w1 + (int64_t)o * C + i0 + 64 * j) : zero_frag<frag>();
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (i0 + 64 * j < C)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sum = fmaf(Elem<T>::to_f(wv[j][e]), mean[i0 + 64 * j + e], sum);
     }
     sum += __shfl_xor(sum, 1, 64);
     sum += __shfl_xor(sum, 2, 64);
@@ -615,10 +622,15 @@ __global__ __launch_bounds__(1024) void se_gate_kernel(const T* __restrict__ y, 
   for (int c = tid >> 1; c < C; c += 512) {          // 2 lanes per channel
     const int half = tid & 1;
     float sum = 0.f;
-    for (int i = half * 8; i < H; i += 16) {
-      const frag wv = ld16<frag>(w2 + (int64_t)c * H + i);
+    for (int i0 = half * 8; i0 < H; i0 += 128) {
+      frag wv[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) sum = fmaf(Elem<T>::to_f(wv[e]), hid[i + e], sum);
+      for (int j = 0; j < 8; ++j) wv[j] = i0 + 16 * j < H ? ld16<frag>(w2 + (int64_t)c * H + i0 + 16 * j) : zero_frag<frag>();
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (i0 + 16 * j < H)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sum = fmaf(Elem<T>::to_f(wv[j][e]), hid[i0 + 16 * j + e], sum);
     }
     sum += __shfl_xor(sum, 1, 64);
     if (half == 0) gate[c] = 1.f / (1.f + __expf(-(sum + b2[c])));
@@ -646,82 +658,118 @@ __global__ __launch_bounds__(256) void scale_resid_kernel(const T* __restrict__ 
 //   w_t = softmax over t (or 1 / T);  m = sum_t w_t x_t;  s = sqrt(max(sum_t w_t (x_t - m)^2, 1e-12))
 //   out (T [2 C]) = [m * scale[:C] + shift[:C] | s * scale[C:] + shift[C:]]   (scale / shift NULL = identity)
 // = the global-context statistics and the attentive statistics pooling (+ BatchNorm) of ECAPA_TDNN.py:543-581.
-// grid C / 64 workgroups of 256 threads: 8 column chunks x 32 row slices.
+// grid C / 64 workgroups of 1024 threads; up to 512 frames stay in registers over the passes.
 template <typename T>
-__global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ x, const T* __restrict__ logit, const float* __restrict__ scale,
-                                                        const float* __restrict__ shift, T* __restrict__ out, int Tn, int C, int mtp) {
-  __shared__ float red[32][64];
+__global__ __launch_bounds__(1024) void col_stats_kernel(const T* __restrict__ x, const T* __restrict__ logit, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, T* __restrict__ out, int Tn, int C, int mtp) {
+  // 64 channels = two 32-channel k-steps of the packed operand; wave w walks the 1-KiB blocks (k-step w & 1, row tiles w >> 1,
+  // + 8, ...): lane (g, r) = row r, channels 8 g .. 8 g + 7 of a block, one contiguous wave-load per block
+  __shared__ float red[8][64];
   __shared__ float tot[64];
   typedef typename Elem<T>::frag frag;
-  const int tid = threadIdx.x, ch = tid & 7, sl = tid >> 3;
-  const int c0 = (int)blockIdx.x * 64 + ch * 8;
-  auto reduce = [&](const float (&v)[8], bool is_max) {
-    __syncthreads();
+  constexpr int NR = 4;                               // blocks a lane keeps in registers (T <= 8 * 16 * NR = 512: one pass over memory)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
+  const int ks2 = wave & 1, grp = wave >> 1;
+  const int ks = (int)blockIdx.x * 2 + ks2;
+  const int c0 = ks * 32 + 8 * g;                     // this lane's 8 channels
+  const int cl = ks2 * 32 + 8 * g;                    // ... within the workgroup's 64
+  auto reduce = [&](const float (&vin)[8], bool is_max) {   // over rows: the 16 r-lanes (shuffles), then the 8 waves of a k-step (LDS)
+    float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[sl][ch * 8 + e] = v[e];
+    for (int e = 0; e < 8; ++e) {
+      v[e] = vin[e];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const float u = __shfl_xor(v[e], o, 64);
+        v[e] = is_max ? fmaxf(v[e], u) : v[e] + u;
+      }
+    }
+    __syncthreads();
+    if (r == 0)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[grp][cl + e] = v[e];
     __syncthreads();
     if (tid < 64) {
       float a = red[0][tid];
-      for (int i = 1; i < 32; ++i) a = is_max ? fmaxf(a, red[i][tid]) : a + red[i][tid];
+#pragma unroll
+      for (int i = 1; i < 8; ++i) a = is_max ? fmaxf(a, red[i][tid]) : a + red[i][tid];
       tot[tid] = a;
     }
     __syncthreads();
   };
-  float mx[8], v[8];
   const bool wtd = logit != nullptr;
+  const bool one_pass = mtp <= 8 * NR;
+  frag xr[NR], lr[NR];
+  auto row_of = [&](int mb, int j) { return (mb + grp + 8 * j) * 16 + r; };
+  auto fetch = [&](int mb) {
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int mt = mb + grp + 8 * j, t = mt * 16 + r;
+      xr[j] = t < Tn ? ld16<frag>(x + (((int64_t)ks * mtp + mt) * 64 + lane) * 8) : zero_frag<frag>();
+      if (wtd) lr[j] = t < Tn ? ld16<frag>(logit + (int64_t)t * C + c0) : zero_frag<frag>();
+    }
+  };
+  float mx[8], v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) mx[e] = 0.f;
+  fetch(0);
   if (wtd) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = -INFINITY;
-    for (int t = sl; t < Tn; t += 32) {
-      const frag l = ld16<frag>(logit + (int64_t)t * C + c0);
+    for (int mb = 0; mb < mtp; mb += 8 * NR) {
+      if (!one_pass) fetch(mb);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], Elem<T>::to_f(l[e]));
+      for (int j = 0; j < NR; ++j)
+        if (row_of(mb, j) < Tn)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], Elem<T>::to_f(lr[j][e]));
     }
     reduce(v, true);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) mx[e] = tot[ch * 8 + e];
+    for (int e = 0; e < 8; ++e) mx[e] = tot[cl + e];
   }
-  // normaliser and weighted sum
   float se[8], sx[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) se[e] = sx[e] = 0.f;
-  for (int t = sl; t < Tn; t += 32) {
-    const frag xv = ld16<frag>(x + pa_off<T>(t, c0, mtp));
-    frag l = xv;
-    if (wtd) l = ld16<frag>(logit + (int64_t)t * C + c0);
+  for (int mb = 0; mb < mtp; mb += 8 * NR) {
+    if (!one_pass) fetch(mb);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float w = wtd ? __expf(Elem<T>::to_f(l[e]) - mx[e]) : 1.f;
-      se[e] += w;
-      sx[e] = fmaf(w, Elem<T>::to_f(xv[e]), sx[e]);
-    }
+    for (int j = 0; j < NR; ++j)
+      if (row_of(mb, j) < Tn)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float w = wtd ? __expf(Elem<T>::to_f(lr[j][e]) - mx[e]) : 1.f;
+          se[e] += w;
+          sx[e] = fmaf(w, Elem<T>::to_f(xr[j][e]), sx[e]);
+        }
   }
   float den[8], mean[8];
   reduce(se, false);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) den[e] = tot[ch * 8 + e];
+  for (int e = 0; e < 8; ++e) den[e] = tot[cl + e];
   reduce(sx, false);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) mean[e] = tot[ch * 8 + e] / den[e];
+  for (int e = 0; e < 8; ++e) mean[e] = tot[cl + e] / den[e];
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = 0.f;
-  for (int t = sl; t < Tn; t += 32) {
-    const frag xv = ld16<frag>(x + pa_off<T>(t, c0, mtp));
-    frag l = xv;
-    if (wtd) l = ld16<frag>(logit + (int64_t)t * C + c0);
+  for (int mb = 0; mb < mtp; mb += 8 * NR) {
+    if (!one_pass) fetch(mb);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float w = wtd ? __expf(Elem<T>::to_f(l[e]) - mx[e]) : 1.f;
-      const float d = Elem<T>::to_f(xv[e]) - mean[e];
-      v[e] = fmaf(w * d, d, v[e]);
-    }
+    for (int j = 0; j < NR; ++j)
+      if (row_of(mb, j) < Tn)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float w = wtd ? __expf(Elem<T>::to_f(lr[j][e]) - mx[e]) : 1.f;
+          const float d = Elem<T>::to_f(xr[j][e]) - mean[e];
+          v[e] = fmaf(w * d, d, v[e]);
+        }
   }
   reduce(v, false);
-  if (sl == 0) {
+  if (grp == 0 && r == 0) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = c0 + e;
-      float m = mean[e], sd = sqrtf(fmaxf(tot[ch * 8 + e] / den[e], 1e-12f));
+      float m = mean[e], sd = sqrtf(fmaxf(tot[cl + e] / den[e], 1e-12f));
       if (scale != nullptr) {
         m = fmaf(m, scale[c], shift[c]);
         sd = fmaf(sd, scale[C + c], shift[C + c]);
@@ -893,7 +941,7 @@ extern "C" int itts_se_gate(const void* y, const void* w1, const float* b1, cons
   ITTS_REQUIRE(y && w1 && b1 && w2 && b2 && gate && T > 0, "itts_se_gate: bad arguments");
   ITTS_FE_DTYPE("itts_se_gate");
   ITTS_REQUIRE(C % 64 == 0 && C <= 1024 && H % 16 == 0 && H <= 512 && mtp * 16 >= T, "itts_se_gate: C %% 64, C <= 1024, H %% 16, H <= 512");
-  const size_t lds = (size_t)(17 * C + H) * 4;
+  const size_t lds = (size_t)(C + H) * 4;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == ITTS_BF16)
     hipLaunchKernelGGL(se_gate_kernel<bf16_t>, dim3(1), dim3(1024), lds, s, (const bf16_t*)y, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, gate, T, C, H, mtp);
@@ -920,8 +968,8 @@ extern "C" int itts_col_stats(const void* x, const void* logit, const float* sca
   ITTS_FE_DTYPE("itts_col_stats");
   hipStream_t s = (hipStream_t)stream;
   if (dtype == ITTS_BF16)
-    hipLaunchKernelGGL(col_stats_kernel<bf16_t>, dim3(C / 64), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)logit, scale, shift, (bf16_t*)out, T, C, mtp);
+    hipLaunchKernelGGL(col_stats_kernel<bf16_t>, dim3(C / 64), dim3(1024), 0, s, (const bf16_t*)x, (const bf16_t*)logit, scale, shift, (bf16_t*)out, T, C, mtp);
   else
-    hipLaunchKernelGGL(col_stats_kernel<f16_t>, dim3(C / 64), dim3(256), 0, s, (const f16_t*)x, (const f16_t*)logit, scale, shift, (f16_t*)out, T, C, mtp);
+    hipLaunchKernelGGL(col_stats_kernel<f16_t>, dim3(C / 64), dim3(1024), 0, s, (const f16_t*)x, (const f16_t*)logit, scale, shift, (f16_t*)out, T, C, mtp);
   return check_launch("itts_col_stats");
 }
