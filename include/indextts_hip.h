@@ -48,7 +48,7 @@ extern "C" {
 #define ITTS_BF16 1
 #define ITTS_F16 2
 
-#define ITTS_ABI_VERSION 8 /* 8: prompt front-end (itts_subsample_conv, itts_mha_small, itts_glu_dwconv_ln_silu, itts_rows, itts_geglu, itts_prefix_rows) and speaker encoder (itts_im2col_reflect, itts_res2_step, itts_se_gate, itts_scale_resid, itts_col_stats, ITTS_EPI_RELU_AFFINE_*), ITTS_EPI_SILU_STORE, y_row0 / y_mtp and any M with rows_per_wg in itts_gemm_skinny, itts_gemm_conv ksplit <= 64; 7: LayerNorm folded into the consuming skinny GEMM (ln_c), residual epilogue with a packed T copy, rows_per_wg / wide_wg, bump words in itts_gemm_skinny / itts_embed_step (+ clamp, packed copy); the reducer tail is gone; paged KV cache (kv_tab / kv_bs); 6: per-row clocks (row_step0) in itts_embed_step / itts_sample_args (slot refill), itts_attn_prefill_prefix / _shared, kv_share in itts_attn_decode; 5: itts_ln_reduce takes up to 6 slabs */
+#define ITTS_ABI_VERSION 8 /* 8: prompt front-end (itts_subsample_conv, itts_mha_small, itts_glu_dwconv_ln_silu, itts_rows, itts_geglu, itts_prefix_rows) and speaker encoder (itts_im2col_reflect, itts_res2_step, itts_se_gate, itts_scale_resid, itts_col_stats, ITTS_EPI_RELU_AFFINE_*), itts_kv_share_rows, ITTS_EPI_SILU_STORE, y_row0 / y_mtp and any M with rows_per_wg in itts_gemm_skinny, itts_gemm_conv ksplit <= 64; 7: LayerNorm folded into the consuming skinny GEMM (ln_c), residual epilogue with a packed T copy, rows_per_wg / wide_wg, bump words in itts_gemm_skinny / itts_embed_step (+ clamp, packed copy); the reducer tail is gone; paged KV cache (kv_tab / kv_bs); 6: per-row clocks (row_step0) in itts_embed_step / itts_sample_args (slot refill), itts_attn_prefill_prefix / _shared, kv_share in itts_attn_decode; 5: itts_ln_reduce takes up to 6 slabs */
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -395,6 +395,12 @@ int itts_beam_kv_rows(int32_t* kv_rows, const int32_t* src, const int32_t* state
  * Cache layout [layers][rows][heads][smax][64]; layer_stride in elements. */
 int itts_beam_reorder_kv(void* kcache, void* vcache, const int32_t* src, const int32_t* state, int layers, int B, int num_beams,
                          int heads, int smax, int64_t layer_stride, int dtype, void* stream);
+
+/* Keys / values of cache positions [p0, p0 + C) of row 0 -> positions [pad[b], pad[b] + C) of rows 1 .. B-1, all `layers` layers in
+ * one launch (layer l of a cache at + l * layer_stride elements): a one-prompt batch's conditioning rows, computed once by the
+ * shared-prefix prefill (itts_attn_prefill_shared), reach every row's cache.  Both cache forms (kv_tab NULL = contiguous). */
+int itts_kv_share_rows(void* kcache, void* vcache, int layers, int64_t layer_stride, int B, int H, int C, int p0, const int32_t* pad,
+                       int smax, const int32_t* kv_tab, int kv_bs, int dtype, void* stream);
 
 /* pcm[b][i] = trunc( clamp(32767 * tanh(x[b][i]), -32767, 32767) ) as int16; also writes fp32 wav if wav != NULL.
  * apply_tanh = 0 skips the tanh (input already in (-1,1)). */

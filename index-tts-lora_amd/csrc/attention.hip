@@ -536,3 +536,40 @@ extern "C" int itts_attn_prefill_packed(const void* qkv, void* out, void* kcache
   return attn_prefill_impl(qkv, out, kcache, vcache, nullptr, B, Smax, H, smax, dtype, row_off, cache_shift, stream, nullptr, nullptr,
                            nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, kv_tab, kv_bs);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// A one-prompt batch's shared rows (the conditioning latents) are computed once by the packed prefill and land in cache row 0;
+// this copies their keys / values, all layers in one launch, to the same sequence positions of every other row:
+//   row b, positions [pad[b], pad[b] + C)  <-  row 0, positions [p0, p0 + C)          (b = 1 .. B-1; 16 bytes per thread)
+// Both cache forms (kv_tab NULL: contiguous rows).  Replaces two advanced-indexing gathers and two scatters of the torch form.
+// ---------------------------------------------------------------------------------------------------------------
+namespace itts {
+__global__ __launch_bounds__(256) void kv_share_rows_kernel(char* __restrict__ kc, char* __restrict__ vc, int64_t layer_bytes, int H, int C,
+                                                            int p0, const int32_t* __restrict__ pad, int smax,
+                                                            const int32_t* __restrict__ kv_tab, int bs_log2, int es, int total) {
+  const int idx = (int)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int cpr = 64 * es / 16;                        // 16-byte chunks of a 64-element row: 8 (16-bit) / 16 (fp32)
+  const int seg = idx % cpr, kv = (idx / cpr) & 1, rest = idx / (2 * cpr);
+  const int c = rest % C, h = rest / C;
+  const int b = (int)blockIdx.y + 1;
+  char* base = (kv ? vc : kc) + (int64_t)blockIdx.z * layer_bytes;
+  const int64_t so = kv_elem_off(kv_tab, bs_log2, 0, p0 + c, H, h, smax) * es + seg * 16;
+  const int64_t d_o = kv_elem_off(kv_tab, bs_log2, b, pad[b] + c, H, h, smax) * es + seg * 16;
+  st16(base + d_o, ld16<B16>(base + so));
+}
+}  // namespace itts
+
+extern "C" int itts_kv_share_rows(void* kcache, void* vcache, int layers, int64_t layer_stride, int B, int H, int C, int p0,
+                                  const int32_t* pad, int smax, const int32_t* kv_tab, int kv_bs, int dtype, void* stream) {
+  ITTS_REQUIRE(kcache && vcache && pad && layers > 0 && B >= 1 && H > 0 && C > 0 && p0 >= 0, "itts_kv_share_rows: bad arguments");
+  ITTS_REQUIRE(kv_tab != nullptr ? (kv_bs == 16 || kv_bs == 32 || kv_bs == 64) : smax >= p0 + C,
+               "itts_kv_share_rows: paged cache: kv_bs must be 16, 32 or 64; contiguous cache: smax covers the block");
+  ITTS_REQUIRE(layers <= 65535 && B <= 65536, "itts_kv_share_rows: too many layers / rows");
+  if (B == 1) return ITTS_OK;
+  const int es = dtype == ITTS_F32 ? 4 : 2;
+  const int total = H * C * 2 * (64 * es / 16);
+  hipLaunchKernelGGL(itts::kv_share_rows_kernel, dim3((total + 255) / 256, B - 1, layers), dim3(256), 0, (hipStream_t)stream, (char*)kcache,
+                     (char*)vcache, layer_stride * es, H, C, p0, pad, smax, kv_tab, kv_bs == 64 ? 6 : kv_bs == 32 ? 5 : 4, es, total);
+  return itts::check_launch("itts_kv_share_rows");
+}

@@ -133,6 +133,8 @@ _SIGNATURES = {
     "itts_scale_resid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_col_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p]),
+    "itts_kv_share_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                     C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "itts_prefix_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
@@ -481,6 +483,14 @@ def attn_prefill_shared(qkv, out, kcache, vcache, row_off, pre_len, pre_row0, w_
     _check(lib().itts_attn_prefill_shared(_p(qkv), _p(out), _p(kcache), _p(vcache), _p(row_off), _p(pre_len), _p(pre_row0),
                                           _p(w_row), _p(w_pos0), E, Smax, H, smax, dt(qkv.dtype), _p(kv_tab), int(kv_bs), _stream()),
            "itts_attn_prefill_shared")
+
+
+def kv_share_rows(kc, vc, B, H, Cn, p0, pad, smax, kv_tab=None, kv_bs=0):
+    """kc / vc: the whole caches [L, ...] (all layers in one launch): row 0's positions [p0, p0 + Cn) -> [pad[b], pad[b] + Cn) of
+    rows 1 .. B-1 (itts_kv_share_rows)."""
+    _dev(kc, vc, pad)
+    _check(lib().itts_kv_share_rows(_p(kc), _p(vc), kc.shape[0], kc.stride(0), B, H, Cn, p0, _p(pad), smax, _p(kv_tab), int(kv_bs),
+                                    dt(kc.dtype), _stream()), "itts_kv_share_rows")
 
 
 def sample(logits, tokens, history, finished, state, extra_ids, force_stop, rep_penalty, temperature, top_k, top_p,

@@ -426,7 +426,7 @@ class GPTEngine:
         (text + start token), whose attention reads the shared block's keys / values out of the same qkv buffer
         (itts_attn_prefill_shared: key tiles cut from sequence position 0 as in the un-shared pass, same bits per row).  The
         kernel appends every element's own rows to its cache row; the shared block's cache rows are copied to the other
-        elements afterwards (one gather / scatter over all layers).  Returns the hidden states of the elements' last rows."""
+        elements afterwards (itts_kv_share_rows: all layers in one launch).  Returns the hidden states of the elements' last rows."""
         import numpy as np
         T, D, H, dev = self.dtype, self.D, self.H, self.device
         B = emb.shape[0]
@@ -436,11 +436,9 @@ class GPTEngine:
         off = np.concatenate([[0, C], C + np.cumsum(own)]).astype(np.int64)
         M = int(off[-1])
         idx = np.concatenate([pad_h[0] + np.arange(C)] + [b * S + pad_h[b] + C + np.arange(own[b]) for b in range(B)])
-        dst_b = np.repeat(np.arange(1, B), C)
-        dst_p = np.concatenate([pad_h[b] + np.arange(C) for b in range(1, B)]) if B > 1 else np.zeros(0, np.int64)
         meta = torch.from_numpy(np.concatenate([
             idx, off, [0] + [C] * B, np.zeros(B + 1, np.int64), [0] + list(range(B)), [pad_h[0]] + [p + C for p in pad_h],
-            off[2:] - 1, dst_b, dst_p]).astype(np.int64)).to(dev)                                           # one upload
+            off[2:] - 1]).astype(np.int64)).to(dev)                                                         # one upload
         E = B + 1
         o = 0
 
@@ -451,23 +449,14 @@ class GPTEngine:
             return t.to(torch.int32) if as32 else t
         i_rows, row_off = take(M, False), take(E + 1)
         pre_len, pre_row0, w_row, w_pos0 = take(E), take(E), take(E), take(E)
-        last_rows, i_db, i_dp = take(B, False), take((B - 1) * C, False), take((B - 1) * C, False)
+        last_rows = take(B, False)
         h = emb.view(B * S, D)[i_rows]
         Smax = max(C, max(own))
         kva = self._kvargs()
         h = self._big_m_layers(h, lambda i, qkv, att: nat.attn_prefill_shared(
             qkv, att, self.kc[i], self.vc[i], row_off, pre_len, pre_row0, w_row, w_pos0, E, Smax, H, self._cap_s, **kva))
         if B > 1:   # the shared block's keys / values: cache row 0 -> the same sequence positions of every other cache row
-            p0 = pad_h[0]
-            if self.kv is None:
-                self.kc[:, i_db, :, i_dp] = self.kc[:, 0, :, p0:p0 + C].permute(2, 0, 1, 3).repeat(B - 1, 1, 1, 1)
-                self.vc[:, i_db, :, i_dp] = self.vc[:, 0, :, p0:p0 + C].permute(2, 0, 1, 3).repeat(B - 1, 1, 1, 1)
-            else:   # the same copy through the block table: (block, offset) of every source / destination position
-                sb, so = self.kv.phys(np.zeros((B - 1) * C, np.int64), np.tile(p0 + np.arange(C), B - 1))
-                db, do = self.kv.phys(dst_b, dst_p)
-                ix = torch.from_numpy(np.stack([sb, so, db, do])).to(dev)
-                self.kc[:, ix[2], :, ix[3]] = self.kc[:, ix[0], :, ix[1]]
-                self.vc[:, ix[2], :, ix[3]] = self.vc[:, ix[0], :, ix[1]]
+            nat.kv_share_rows(self.kc, self.vc, B, H, C, pad_h[0], self.pad, self._cap_s, **self._kvargs())
         return h[last_rows].contiguous()
 
     def prefill(self, prefix_emb: torch.Tensor, pad: torch.Tensor, max_new: int, beams: int = 1, shared_rows: int = 0, paged=None,
