@@ -16,6 +16,8 @@ nnet/CNN.py:430-488 (reflect "same" padding), nnet/normalization.py:13-108; the 
 """
 from __future__ import annotations
 
+import threading
+
 import torch
 
 from .. import _native as nat
@@ -81,8 +83,17 @@ class SpeakerEngine:
         self._bufs = {}
         self.launches = 0
 
+    def forget(self):
+        """Drop the calling thread's per-length buffers (the caller holds no captured graph over them any more)."""
+        me = threading.get_ident()
+        for k in [k for k in self._bufs if k[1] == me]:
+            del self._bufs[k]
+
     def _buffers(self, T):
-        b = self._bufs.get(T)
+        # per prompt length AND per host thread: the vocoder object (and with it this engine) is shared by the replicas of
+        # infer.RequestPool, one thread + stream each -- shared packed weights, private activations
+        key = (T, threading.get_ident())
+        b = self._bufs.get(key)
         if b is None:
             dev, dt, C = self.device, self.dtype, self.C
             mtp = (T + 15) // 16
@@ -91,7 +102,7 @@ class SpeakerEngine:
                      y2=z(mtp * 16 * C), gate=z(C, dtype=torch.float32), feats=z(mtp * 16 * self.CM), xm=z(mtp * 16 * self.CM),
                      ctx=z(2 * self.CM), asp_bias=z(self.A, dtype=torch.float32), att=z(mtp * 16 * self.A), logit=z(T, self.CM),
                      pooled=z(2 * self.CM), out=z(self.E, dtype=torch.float32))
-            self._bufs[T] = b
+            self._bufs[key] = b
         return b
 
     def __call__(self, mel_tf: torch.Tensor) -> torch.Tensor:

@@ -19,6 +19,7 @@ perceiver.py:181-312 of the reference; the weight keys are the reference checkpo
 from __future__ import annotations
 
 import math
+import threading
 
 import torch
 
@@ -129,8 +130,16 @@ class ConditionerEngine:
         self.launches = 0
 
     # ------------------------------------------------------------------------------------------------------------------
+    def forget(self):
+        """Drop the calling thread's per-length buffers (the caller holds no captured graph over them any more)."""
+        me = threading.get_ident()
+        for k in [k for k in self._bufs if k[2] == me]:
+            del self._bufs[k]
+
     def _buffers(self, T, Fq):
-        key = (T, Fq)
+        # per prompt length AND per host thread: replicas of one model (infer.RequestPool: one thread + stream each) share this
+        # engine's packed weights but must not share activations
+        key = (T, Fq, threading.get_ident())
         b = self._bufs.get(key)
         if b is not None:
             return b

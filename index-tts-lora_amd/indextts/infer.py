@@ -308,6 +308,8 @@ class IndexTTS:
             self._cache_conds = self._cache_spk = None
         return self.cache_cond_mel
 
+    MAX_FEATURE_GRAPHS = 64     # (network, prompt shape) pairs kept captured: ~30 MB of activations + a graph each
+
     def _graphed(self, name, fn, cond_mel):
         """fn(prompt mel) through a CUDA graph per (network, prompt shape): the host-side PyTorch networks are a few hundred
         small launches each; the first call runs eagerly as warm-up, the second captures, later ones replay (any capture
@@ -315,6 +317,13 @@ class IndexTTS:
         key = (name,) + tuple(cond_mel.shape)
         ent = self._feat_graphs.get(key)
         if ent is None:
+            if len(self._feat_graphs) >= self.MAX_FEATURE_GRAPHS:
+                # a server that has seen this many prompt shapes starts over: the graphs go, and with them the per-length
+                # activation buffers of the two front-end engines they replay into (this thread's)
+                self._feat_graphs.clear()
+                for eng in (self.gpt.conditioner(), self.bigvgan.speaker_engine()):
+                    if eng is not None:
+                        eng.forget()
             self._feat_graphs[key] = "warm"
             return fn(cond_mel)
         if ent == "warm":

@@ -175,10 +175,10 @@ def _cond_model(dtype):
     return m.to(DEV).to(dtype)
 
 
-@pytest.mark.parametrize("frames", [120, 300, 437])
+@pytest.mark.parametrize("frames", [120, 300, 437, 1400])
 def test_conditioner_engine_matches_functional_fp32(frames):
     """The whole Conformer + Perceiver conditioner (fp16 kernels) against the functional fp32 form over the same weights;
-    437 frames = 218 context rows: more than one 192-key chunk in the Perceiver's attention."""
+    437 / 1400 frames: 218 / 699 context rows, many 32-key steps per wave in both attentions, 44 row groups in the GEMMs."""
     m = _cond_model(torch.bfloat16)
     mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, frames), -6.0, 2.0)).to(DEV)
     got = m.get_conditioning(mel, None)
@@ -379,3 +379,29 @@ def test_speaker_engine_against_reference_fixture():
     ref = torch.from_numpy(g["spk4"]).to(DEV)
     assert (got - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item())
     assert _vocoder(torch.float32).speaker_engine() is None
+
+
+def test_front_end_buffers_are_per_thread_and_forgettable():
+    """Replicas of one model (RequestPool: a thread + stream each) share the engines' packed weights, never their activations."""
+    import threading
+    m = _cond_model(torch.bfloat16)
+    mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 120), -6.0, 2.0)).to(DEV)
+    a = m.get_conditioning(mel, None)
+    eng = m.conditioner()
+    assert len(eng._bufs) == 1
+    out = {}
+
+    def other():
+        with torch.cuda.stream(torch.cuda.Stream()):
+            out["b"] = m.get_conditioning(mel, None)
+            torch.cuda.current_stream().synchronize()
+            out["n"] = len(eng._bufs)
+            eng.forget()
+            out["after"] = len(eng._bufs)
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert out["n"] == 2 and out["after"] == 1 and torch.equal(out["b"], a)
+    eng.forget()
+    assert len(eng._bufs) == 0
+    assert torch.equal(m.get_conditioning(mel, None), a)
