@@ -48,7 +48,7 @@ extern "C" {
 #define ITTS_BF16 1
 #define ITTS_F16 2
 
-#define ITTS_ABI_VERSION 8 /* 8: prompt front-end (itts_subsample_conv, itts_mha_small, itts_glu_dwconv_ln_silu, itts_rows, itts_geglu, itts_prefix_rows) and speaker encoder (itts_im2col_reflect, itts_res2_step, itts_se_gate, itts_scale_resid, itts_col_stats, ITTS_EPI_RELU_AFFINE_*), itts_kv_share_rows, itts_act_conv, ITTS_EPI_SILU_STORE, y_row0 / y_mtp and any M with rows_per_wg in itts_gemm_skinny, itts_gemm_conv ksplit <= 64; 7: LayerNorm folded into the consuming skinny GEMM (ln_c), residual epilogue with a packed T copy, rows_per_wg / wide_wg, bump words in itts_gemm_skinny / itts_embed_step (+ clamp, packed copy); the reducer tail is gone; paged KV cache (kv_tab / kv_bs); 6: per-row clocks (row_step0) in itts_embed_step / itts_sample_args (slot refill), itts_attn_prefill_prefix / _shared, kv_share in itts_attn_decode; 5: itts_ln_reduce takes up to 6 slabs */
+#define ITTS_ABI_VERSION 8 /* 8: prompt front-end (itts_subsample_conv, itts_mha_small, itts_glu_dwconv_ln_silu, itts_rows, itts_geglu, itts_prefix_rows) and speaker encoder (itts_im2col_reflect, itts_res2_step, itts_se_gate, itts_scale_resid, itts_col_stats, ITTS_EPI_RELU_AFFINE_*), itts_kv_share_rows, ITTS_EPI_SILU_STORE, y_row0 / y_mtp and any M with rows_per_wg in itts_gemm_skinny, itts_gemm_conv ksplit <= 64; 7: LayerNorm folded into the consuming skinny GEMM (ln_c), residual epilogue with a packed T copy, rows_per_wg / wide_wg, bump words in itts_gemm_skinny / itts_embed_step (+ clamp, packed copy); the reducer tail is gone; paged KV cache (kv_tab / kv_bs); 6: per-row clocks (row_step0) in itts_embed_step / itts_sample_args (slot refill), itts_attn_prefill_prefix / _shared, kv_share in itts_attn_decode; 5: itts_ln_reduce takes up to 6 slabs */
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -207,18 +207,6 @@ typedef struct itts_conv_args {
   int ksplit;
 } itts_conv_args;
 int itts_gemm_conv(const itts_conv_args* a, void* stream);
-
-
-/* The anti-aliased SnakeBeta activation FUSED into the narrow convolution that consumes it (fp16, Cin = N = 24 / 48, 3 / 7 / 11 taps:
- * the AMP blocks of BigVGAN's last two stages, indextts/BigVGAN/models.py:65-74):
- *     y = conv(a)  with  a = itts_aa_snake_fwd(x; alpha_log, beta_log, filters)   -- bit for bit what the two launches give,
- * but `a` never exists in HBM (the activated rows of a tile, halo included, go straight into the convolution's LDS row tile).
- * `a` describes the CONVOLUTION as for itts_gemm_conv with a->x = the ACTIVATION's input; restrictions: Tin == Tout, dense batches
- * (x_bstride = Tin * Cin, y_bstride = y_limit = Tout * N, y_shift 0), T-typed y, no bias2 / act / ksplit; resid, accumulate, scale
- * and valid_rows as in itts_gemm_conv.  itts_act_conv_supported tells whether a shape is built (otherwise: the two launches). */
-int itts_act_conv_supported(int dtype, int C, int taps, int dil);
-int itts_act_conv(const itts_conv_args* a, const float* alpha_log, const float* beta_log, const float* up_filter12,
-                  const float* down_filter12, void* stream);
 
 
 /* LayerNorm over the last dim of fp32 rows; y is T (y_f32 = 0) or fp32 (y_f32 = 1).  If w2 != NULL a second LayerNorm

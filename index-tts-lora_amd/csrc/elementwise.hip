@@ -81,6 +81,33 @@ __global__ __launch_bounds__(256) void aa_snake_btc_kernel(const T* __restrict__
 // snake output goes back to LDS, and the result to the channels-last tensor, as 8-byte vectors.
 // Follows alias_free_torch/act.py:10-28 like aa_tile.h; replaces anti_alias_activation_cuda.cu:44-181 for 16-bit tensors.
 // -------------------------------------------------------------------------------------------------------------------
+template <int NCB>   // 16-channel blocks per workgroup (CS = 16 * NCB channels)
+struct AaMfma {
+  static constexpr int TT = 128;                 // output rows per tile
+  static constexpr int CS = 16 * NCB;
+  static constexpr int XR = TT + 32;             // X image rows: x rows t0-12 .. t0+TT+19 (8-aligned 32-row windows of the u blocks)
+  static constexpr int NUB = (2 * TT + 16) / 16; // u row blocks: u rows 2*t0-8 .. 2*t0+2*TT+7
+  static constexpr int SR = 2 * TT + 16 + 16;    // S image rows (+16: the last y block's 64-row window runs past the u rows; zero taps there)
+  static constexpr int RS = CS + 8;              // row stride of both images (elements)
+  static constexpr int NYB = TT / 16;            // y row blocks
+  static constexpr size_t LDS = (size_t)(XR + SR) * RS * 2;
+};
+
+typedef short aa_v4s __attribute__((__vector_size__(4 * sizeof(short))));
+// fragment of a [rows][RS] fp16 image for the MFMA A operand "16 channels x 32 rows": lane (g, r) gets rows row0 + 8g .. +7 of
+// channel col0 + r.  Two transposed reads; lane 4q+p of a 16-lane group addresses row q, columns 4p .. 4p+3 of the block.
+template <int RS>
+__device__ __forceinline__ f16x8 aa_tr_frag(const f16_t* img, int row0, int col0, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+  const f16_t* a = img + (row0 + 8 * g + q) * RS + col0 + 4 * pq;
+  typedef __attribute__((address_space(3))) aa_v4s* lptr;
+  const aa_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a));
+  const aa_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a + 4 * RS));
+  typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
+  const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(f16x8, both);
+}
+
 template <int NCB>
 __global__ __launch_bounds__(256) void aa_snake_mfma_kernel(const f16_t* __restrict__ x, f16_t* __restrict__ y,
                                                              const float* __restrict__ alpha_log,

@@ -63,8 +63,6 @@ class BigVGAN:
     def __init__(self, h, use_cuda_kernel=False):
         self.h = h
         self.use_cuda_kernel = use_cuda_kernel  # accepted for API compatibility; the HIP kernels are always used
-        # fp16, C = 24 / 48: every activation of an AMP block runs inside the convolution that consumes it (itts_act_conv; same bits)
-        self.fuse_act_conv = os.environ.get("ITTS_FUSE_ACT_CONV", "1") != "0"
         if str(h.get("resblock", "1")) != "1":
             raise NotImplementedError("only resblock '1' (AMPBlock1) is on the IndexTTS inference path")
         if h.get("activation", "snakebeta") != "snakebeta" or not h.get("snake_logscale", True):
@@ -278,27 +276,17 @@ class BigVGAN:
                     work[1] += 4 * B * Tu * c * es          # two activations: read + write each
                     conv_work(Tu, c, c, k)
                     conv_work(Tu, c, c, k, extra_ops=1 if (n + 1 < nd or j == 0) else 2)   # + residual (+ accumulate)
-                    a1, a2 = blk["act"][2 * n], blk["act"][2 * n + 1]
-                    last = n + 1 >= nd    # last conv of the block: + residual, then the 1/3 mean over the three AMP blocks
-                    out2 = xs if last else pp[n % 2]
-                    kw2 = dict(bias=blk["c2"][n][1], resid=xc, valid_rows=vr)
-                    if last:
-                        kw2.update(accumulate=(j > 0), scale=1.0 / nk)
-                    if self.fuse_act_conv and nat.act_conv_supported(T, c, k, d):
-                        # C = 24 / 48 in fp16: each activation runs inside the convolution that consumes it (itts_act_conv): the
-                        # activated tensor never goes to HBM, same bits as the two launches
-                        nat.act_conv(xc, a1[0], a1[1], P["up_f"], P["down_f"], B, Tu, c, blk["c1"][n][0], bb, k, -((k * d - d) // 2), d,
-                                     bias=blk["c1"][n][1], valid_rows=vr)
-                        nat.act_conv(bb, a2[0], a2[1], P["up_f"], P["down_f"], B, Tu, c, blk["c2"][n][0], out2, k, -((k - 1) // 2), 1,
-                                     **kw2)
-                    else:
-                        self._act(xc, a1, out=ba, valid=vr)
-                        nat.gemm_conv(T, B, Tu, Tu, c, c, blk["c1"][n][0], ba, bb, taps=k, off0=-((k * d - d) // 2), dil=d,
-                                      bias=blk["c1"][n][1], valid_rows=vr)
-                        self._act(bb, a2, out=ba, valid=vr)
-                        nat.gemm_conv(T, B, Tu, Tu, c, c, blk["c2"][n][0], ba, out2, taps=k, off0=-((k - 1) // 2), dil=1, **kw2)
-                    if not last:
-                        xc = out2
+                    self._act(xc, blk["act"][2 * n], out=ba, valid=vr)
+                    nat.gemm_conv(T, B, Tu, Tu, c, c, blk["c1"][n][0], ba, bb, taps=k, off0=-((k * d - d) // 2), dil=d,
+                                  bias=blk["c1"][n][1], valid_rows=vr)
+                    self._act(bb, blk["act"][2 * n + 1], out=ba, valid=vr)
+                    if n + 1 < nd:
+                        nat.gemm_conv(T, B, Tu, Tu, c, c, blk["c2"][n][0], ba, pp[n % 2], taps=k, off0=-((k - 1) // 2), dil=1,
+                                      bias=blk["c2"][n][1], resid=xc, valid_rows=vr)
+                        xc = pp[n % 2]
+                    else:  # last conv of the block: + residual, then the 1/3 mean over the three AMP blocks
+                        nat.gemm_conv(T, B, Tu, Tu, c, c, blk["c2"][n][0], ba, xs, taps=k, off0=-((k - 1) // 2), dil=1,
+                                      bias=blk["c2"][n][1], resid=xc, accumulate=(j > 0), scale=1.0 / nk, valid_rows=vr)
             cur, Tn = xs, Tu
             mark(f"stage {i}: x{u} upsampler + {nk} AMP blocks at C = {c}, T = {Tu}")
             if taps is not None:

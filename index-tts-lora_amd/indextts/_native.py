@@ -133,8 +133,6 @@ _SIGNATURES = {
     "itts_scale_resid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "itts_col_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p]),
-    "itts_act_conv_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
-    "itts_act_conv": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "itts_kv_share_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                      C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "itts_prefix_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -403,31 +401,6 @@ def gemm_conv(dtype, B, Tin, Tout, Cin, N, wp, x, y, taps=1, off0=0, dil=1, x_bs
     a.valid_rows = _p(valid_rows)
     a.ksplit = int(ksplit)
     _check(lib().itts_gemm_conv(C.byref(a), _stream()), "itts_gemm_conv")
-
-
-def act_conv_supported(dtype, Cn, taps, dil) -> bool:
-    """Is the fused activation + narrow convolution built for this shape (itts_act_conv_supported)?"""
-    return bool(lib().itts_act_conv_supported(dt(dtype), int(Cn), int(taps), int(dil)))
-
-
-def act_conv(x, alpha_log, beta_log, up_f, down_f, B, T, Cn, wp, y, taps, off0, dil, bias=None, resid=None, accumulate=False,
-             scale=1.0, valid_rows=None):
-    """y = conv(aa_snake(x)) in one launch (fp16, Cn = 24 / 48): x, y, resid T [B, T, Cn]; filters are host arrays of 12 taps."""
-    _dev(x, alpha_log, beta_log, y)
-    a = ConvArgs()
-    a.dtype, a.B, a.Tin, a.Tout, a.Cin, a.N = dt(x.dtype), B, T, T, Cn, Cn
-    a.taps, a.off0, a.dil = taps, off0, dil
-    a.x, a.x_bstride = _p(x), T * Cn
-    a.wp, a.bias, a.bias2, a.act = _p(wp), _p(bias), None, 0
-    a.y, a.y_f32 = _p(y), 0
-    a.y_bstride, a.y_shift, a.y_limit = T * Cn, 0, T * Cn
-    a.resid, a.accumulate, a.scale = _p(resid), int(accumulate), float(scale)
-    a.valid_rows, a.ksplit = _p(valid_rows), 0
-    uf = (C.c_float * 12)(*[float(v) for v in up_f])
-    df = (C.c_float * 12)(*[float(v) for v in down_f])
-    _check(lib().itts_act_conv(C.byref(a), _p(alpha_log), _p(beta_log), C.cast(uf, C.c_void_p), C.cast(df, C.c_void_p), _stream()),
-           "itts_act_conv")
-    return y
 
 
 def layernorm(h, w, b, out, w2=None, b2=None):

@@ -1101,39 +1101,3 @@ def test_attn_prefill_packed_equals_left_padded(nat, dtype):
     for b in range(B):
         assert torch.equal(kc[b, :, pads[b]:S], kc_ref[b, :, pads[b]:S]) and torch.equal(vc[b, :, pads[b]:S], vc_ref[b, :, pads[b]:S])
         assert kc[b, :, :pads[b]].abs().max().item() == 0 if pads[b] else True
-
-
-@pytest.mark.parametrize("C,k,d", [(24, 3, 1), (24, 7, 3), (24, 11, 5), (48, 3, 5), (48, 7, 1), (48, 11, 5), (48, 11, 3)])
-def test_act_conv_fused_equals_the_two_launches(C, k, d):
-    """itts_act_conv = itts_aa_snake_fwd + itts_gemm_conv, bit for bit: residual / accumulate / scale epilogue, a ragged batch
-    (one element shorter than a tile, one ending inside a tile, one empty), a length that is no multiple of the tile."""
-    from indextts import _native as nat
-    from indextts.BigVGAN.models import kaiser_sinc_filter
-    dt = torch.float16
-    B, T = 5, 7000                    # B * T >= 32 768: the stand-alone activation takes its MFMA form too (same roundings)
-    assert nat.act_conv_supported(dt, C, k, d) and not nat.act_conv_supported(torch.bfloat16, C, k, d) and not nat.act_conv_supported(dt, 96, k, d)
-    g = torch.Generator().manual_seed(C * 100 + k * 10 + d)
-    x = (torch.randn(B, T, C, generator=g) * 0.8).to(DEV).to(dt)
-    res = (torch.randn(B, T, C, generator=g) * 0.5).to(DEV).to(dt)
-    w = (torch.randn(k, C, C, generator=g) * (C * k) ** -0.5).to(DEV).to(dt)
-    wp = nat.pack_weight(w)
-    bias = (torch.randn(C, generator=g) * 0.1).to(DEV)
-    al, be = (torch.randn(C, generator=g) * 0.3).to(DEV), (torch.randn(C, generator=g) * 0.3).to(DEV)
-    f = kaiser_sinc_filter()
-    off0 = -((k * d - d) // 2)
-    for vr in (None, torch.tensor([7000, 37, 4000, 0, 6999], dtype=torch.int32, device=DEV)):
-        for resid, acc, scale in ((None, False, 1.0), (res, True, 1.0 / 3)):
-            y0 = (torch.randn(B, T, C, generator=g) * 0.2).to(DEV).to(dt)
-            a = torch.zeros_like(x)
-            nat.aa_snake(x, al, be, f, f, layout=0, out=a, valid_rows=vr)
-            ref = y0.clone()
-            nat.gemm_conv(dt, B, T, T, C, C, wp, a, ref, taps=k, off0=off0, dil=d, bias=bias, resid=resid, accumulate=acc, scale=scale,
-                          valid_rows=vr)
-            got = y0.clone()
-            nat.act_conv(x, al, be, f, f, B, T, C, wp, got, k, off0, d, bias=bias, resid=resid, accumulate=acc, scale=scale,
-                         valid_rows=vr)
-            lens = [T] * B if vr is None else vr.tolist()
-            for b in range(B):
-                assert torch.equal(got[b, :lens[b]], ref[b, :lens[b]]), (b, vr is None, acc, (got[b, :lens[b]].float() - ref[b, :lens[b]].float()).abs().max().item())
-    with pytest.raises(nat.NativeError):
-        nat.act_conv(x.to(torch.bfloat16), al, be, f, f, B, T, C, wp, got, k, off0, d)
