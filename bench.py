@@ -523,9 +523,9 @@ def main():
 
     # p50 first-token latency: cached prompt mel -> conditioner + prefix + prefill + first sample  (30 samples)
     lat_ms = []
-    batch_tokens = torch.full((BATCH, max(int(t.numel()) for t in texts)), 1, dtype=torch.int32, device=device)
+    batch_tokens = torch.full((BATCH, max(int(t.numel()) for t in texts)), 1, dtype=torch.int32)   # host ids, as infer_batch has them
     for i, t in enumerate(texts):
-        batch_tokens[i, : t.numel()] = t.to(device)
+        batch_tokens[i, : t.numel()] = t.cpu()
     sp = dict(do_sample=True, top_p=0.8, top_k=30, temperature=1.0, repetition_penalty=10.0, seed=1)
     for _ in range(32):
         torch.cuda.synchronize()

@@ -161,11 +161,19 @@ class UnifiedVoice:
 
     def prefix_rows(self, conditional_latents, text_inputs):
         """What the engine needs of prepare_gpt_inputs: (prefix_emb [B,P,D] fp32, left padding per row int32 [B]) -- the same
-        launch, without the fake ids and without re-deriving the padding from the mask."""
+        launch, without the fake ids and without re-deriving the padding from the mask.  The padding comes back as a HOST tensor
+        when the ids were given on the host (no device round trip in front of the prefill), else as the kernel's device tensor."""
+        pad_host = None
+        if not text_inputs.is_cuda:
+            # ids still on the host: the padding (L - ids kept) is known here, and GPTEngine.prefill() -- which sizes its launches
+            # from it -- need not wait for the device to hand it back
+            th = text_inputs.long()
+            keep = (th != self.stop_text_token) & (th != self.start_text_token)
+            pad_host = (th.shape[1] - keep.sum(dim=1)).to(torch.int32)
         t = text_inputs.to(self.device).long().contiguous()
         c = conditional_latents.to(self.device, torch.float32).contiguous()
         emb, _, pad = nat.prefix_rows(t, c, self.engine.text_emb, self.engine.text_pos, self.start_text_token, self.stop_text_token)
-        return emb, pad
+        return emb, (pad if pad_host is None else pad_host)
 
     # ---- generation -------------------------------------------------------------------------------------------
     def inference_speech(self, speech_conditioning_mel, text_inputs, cond_mel_lengths=None, input_tokens=None,

@@ -205,6 +205,12 @@ class IndexTTS:
     def remove_long_silence(self, codes: torch.Tensor, silent_token=52, max_consecutive=30):
         """infer.py:446-497: cut at the first stop token; when a row holds more than `max_consecutive` silent tokens,
         keep at most 10 per run."""
+        c, lens = IndexTTS._squeeze_silence_host(self, codes, silent_token, max_consecutive)   # (self: anything with stop_mel_token)
+        return torch.from_numpy(c).to(codes.device), torch.tensor(lens, dtype=torch.long, device=codes.device)
+
+    def _squeeze_silence_host(self, codes: torch.Tensor, silent_token=52, max_consecutive=30):
+        """remove_long_silence on the host: (codes as a contiguous numpy array, lengths as a list) -- ONE device-to-host copy; the
+        batch path keeps working from these host copies instead of uploading them and reading them back."""
         c = codes.detach().cpu().numpy()
         rows, lens, fixed = [], [], False
         for code in c:
@@ -237,7 +243,7 @@ class IndexTTS:
         mx = max(lens)
         if mx < c.shape[1]:
             c = c[:, :mx]
-        return torch.from_numpy(np.ascontiguousarray(c)).to(codes.device), torch.tensor(lens, dtype=torch.long, device=codes.device)
+        return np.ascontiguousarray(c), lens
 
     def bucket_sentences(self, sentences, bucket_max_size=4) -> List[List[Dict]]:
         """infer.py:499-550: sort by length, open a new bucket when a sentence is >= 1.5x the bucket median or the
@@ -666,7 +672,7 @@ class IndexTTS:
             bh = torch.full((len(ids), L), stop_text, dtype=torch.int32)
             for j, i in enumerate(ids):
                 bh[j, : texts[i].numel()] = texts[i]
-            return g.prefix_rows(conds, bh.to(self.device))
+            return g.prefix_rows(conds, bh)
 
         queue = sorted(range(N), key=lambda i: -int(texts[i].numel()))     # longest first: every later prompt fits
         rows: List[torch.Tensor | None] = [None] * N
@@ -753,9 +759,8 @@ class IndexTTS:
             text_token_rows = [t.cpu() for t in text_token_rows]
         for i, t in enumerate(text_token_rows):
             batch_h[i, : t.numel()] = t.reshape(-1).to(torch.int32)
-        batch = batch_h.to(self.device)   # one upload for the whole batch
         g = self.gpt
-        emb, pad = g.prefix_rows(conds, batch)
+        emb, pad = g.prefix_rows(conds, batch_h)   # one upload for the whole batch; the padding stays a host tensor
         sp = dict(do_sample=bool(gen["do_sample"]), top_p=float(gen["top_p"]), top_k=int(gen["top_k"]),
                   temperature=float(gen["temperature"]), repetition_penalty=float(gen["repetition_penalty"]), seed=int(seed))
         if not sp["do_sample"]:
@@ -778,8 +783,8 @@ class IndexTTS:
             self._mark(phase_events, "prefilled")
             codes = g.engine.decode(max_mel_tokens, sp, force_stop=force_stop)
         self._mark(phase_events, "decoded")
-        codes_c, lens = self.remove_long_silence(codes)
-        codes_h, lens_h = codes_c.cpu(), lens.tolist()   # host copies: one transfer each instead of a sync per row
+        codes_np, lens_h = self._squeeze_silence_host(codes)   # infer.py:848-861 on the host copy: one device-to-host transfer in all
+        codes_h = torch.from_numpy(codes_np)
         rows = [codes_h[i, : lens_h[i]] for i in range(codes_h.shape[0])]
         # where the latent pass finds each element's prompt in the KV cache: row b, or row b * num_beams when the beam prefill
         # expanded the rows (beam_kv = "copy")

@@ -25,7 +25,7 @@ lens = torch.randint(20, 61, (32,), generator=g)
 tok = torch.full((32, int(lens.max())), 1, dtype=torch.int32)
 for i, n in enumerate(lens):
     tok[i, : int(n)] = torch.randint(2, 12000, (int(n),), generator=g).to(torch.int32)
-tok = tok.to("cuda:0")
+# (host ids, as IndexTTS.infer_batch has them: the padding is then known without a device round trip)
 sp = dict(do_sample=True, top_p=0.8, top_k=30, temperature=1.0, repetition_penalty=10.0, seed=1)
 parts = {"conditioner": [], "prefix": [], "prefill": [], "sample": [], "speaker embedding (not on the first token's path)": []}
 
