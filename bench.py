@@ -701,6 +701,14 @@ def main():
                                "frac_mfma": round(fl / ms_ / 1e9 / PEAK_MFMA_TFLOPS, 4),
                                "frac_hbm": round(by / ms_ / 1e6 / PEAK_HBM_GBS, 4)})
             roof["vocoder"]["stages"] = stages
+            op_gb = sum(st["MB"] for st in stages) / 1e3
+            alg_gb = frames * 9.7e6 / 1e9
+            roof["vocoder"]["operand_traffic"] = {
+                "launch_operands_GB": round(op_gb, 1), "algorithmic_GB": round(alg_gb, 1), "ratio": round(op_gb / alg_gb, 2),
+                "note": "sum over the launches of one forward of their operand bytes (inputs + outputs + residual / accumulate operands) "
+                        "against SURVEY 8(d)'s 9.7 MB per frame: the un-fused [activation, conv, activation, conv + residual] groups move "
+                        "9 tensor passes where 5 would do; the fusion that removes them was built and measured slower "
+                        "(profiles/r04_act_conv_fusion.txt)"}
             roof["vocoder"]["stages_note"] = (f"one extra pass over [{BATCH}, {int(force[0])}, 1280] random latents; FLOP = the "
                                               "convolutions' 2*rows*Cout*Cin*taps, bytes = every launch's operands in fp16")
         except Exception as e:   # a measurement aid must not take the line down
