@@ -405,3 +405,29 @@ def test_front_end_buffers_are_per_thread_and_forgettable():
     eng.forget()
     assert len(eng._bufs) == 0
     assert torch.equal(m.get_conditioning(mel, None), a)
+
+
+def test_indextts_prompt_features_run_on_the_hip_engines():
+    """The product path of a 16-bit IndexTTS: _prompt_conds / _prompt_spk (first call eager, second captured, third replayed) go
+    through ConditionerEngine / SpeakerEngine -- no silent fall-back to the functional PyTorch forms -- and replay to the bits of
+    the eager call; the prompt rows come from itts_prefix_rows with the padding as a host tensor for host-resident ids."""
+    from indextts.infer import IndexTTS
+    import copy
+    cfg = copy.deepcopy(weights.reference_config())
+    cfg["gpt"]["layers"] = 2
+    tts = IndexTTS.from_weights(cfg, weights.gpt_state_dict(2), weights.bigvgan_state_dict(), device=DEV,
+                                precision_config={"gpt": "bf16", "vocoder": "fp16"})
+    mel = torch.from_numpy(synth.uniform("in.cond_mel", (1, 100, 150), -6.0, 2.0)).to(DEV)
+    ce, se = tts.gpt.conditioner(), tts.bigvgan.speaker_engine()
+    assert ce is not None and se is not None and ce.launches == 0 and se.launches == 0
+    c = [tts._prompt_conds(mel).clone() for _ in range(3)]
+    s = [tts._prompt_spk(mel).clone() for _ in range(3)]
+    assert ce.launches == 72 and se.launches == 42
+    assert torch.equal(c[0], c[1]) and torch.equal(c[1], c[2]) and c[0].shape == (1, 32, 1280)
+    assert torch.equal(s[0], s[1]) and torch.equal(s[1], s[2]) and s[0].shape == (1, 1, 512)
+    assert all(isinstance(v, tuple) for v in tts._feat_graphs.values())          # both networks captured, none fell back to eager
+    ids = torch.tensor([[5, 6, 7, 1, 1], [9, 8, 7, 6, 5]], dtype=torch.int32)
+    emb, pad = tts.gpt.prefix_rows(c[0], ids)
+    assert not pad.is_cuda and pad.tolist() == [2, 0] and emb.shape == (2, 32 + 5 + 2, 1280)
+    emb_d, pad_d = tts.gpt.prefix_rows(c[0], ids.to(DEV))
+    assert pad_d.is_cuda and pad_d.tolist() == [2, 0] and torch.equal(emb_d, emb)
