@@ -212,6 +212,11 @@ class IndexTTS:
         """remove_long_silence on the host: (codes as a contiguous numpy array, lengths as a list) -- ONE device-to-host copy; the
         batch path keeps working from these host copies instead of uploading them and reading them back."""
         c = codes.detach().cpu().numpy()
+        if c.shape[0] and not ((c == silent_token).sum(axis=1) > max_consecutive).any():
+            # no row has a long silence (the usual case): only the cut at the first stop token, all rows at once
+            is_stop = c == self.stop_mel_token
+            lens = np.where(is_stop.any(axis=1), is_stop.argmax(axis=1), c.shape[1]).tolist()
+            return np.ascontiguousarray(c[:, : max(lens)]), lens
         rows, lens, fixed = [], [], False
         for code in c:
             stops = np.nonzero(code == self.stop_mel_token)[0]
@@ -415,14 +420,16 @@ class IndexTTS:
         if reuse_prefix and self.reuse_prompt_kv:
             cl = [int(c.numel()) for c in code_rows]
             flat = torch.cat([c.reshape(-1).long() for c in code_rows]).cpu().numpy() if code_rows else np.zeros(0, np.int64)
-            ids, pos, o = [], [], 0
-            for c in cl:
-                ids.append(np.concatenate([[g.start_mel_token], flat[o: o + c], [g.stop_mel_token]]))
-                pos.append(np.arange(c + 2))
-                o += c
-            idx = torch.from_numpy(np.stack([np.concatenate(ids), np.concatenate(pos)]).astype(np.int64)).to(dev)
+            # start | codes | stop of every row and the position of each token in its row, for all rows at once
+            cln = np.asarray(cl, dtype=np.int64)
+            m = cln + 2
+            offs = np.concatenate([[0], np.cumsum(m)])
+            pos = np.arange(int(offs[-1])) - np.repeat(offs[:-1], m)
+            ids = np.full(int(offs[-1]), g.stop_mel_token, dtype=np.int64)
+            ids[pos == 0] = g.start_mel_token
+            ids[(pos > 0) & (pos <= np.repeat(cln, m))] = flat
+            idx = torch.from_numpy(np.stack([ids, pos])).to(dev)
             enc = eng.latent_mel_rows(eng.mel_emb[idx[0]] + eng.mel_pos[idx[1]], [c + 2 for c in cl], cache_rows)
-            offs = np.concatenate([[0], np.cumsum([c + 2 for c in cl])])
             return [enc[int(offs[i]): int(offs[i]) + cl[i]] for i in range(len(cl))]
 
         def flat_host(rows):
