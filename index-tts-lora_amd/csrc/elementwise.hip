@@ -664,8 +664,14 @@ using namespace itts;
 
 // consecutive tiles one workgroup of the MFMA activation walks: enough workgroups to fill the chip several times over (768
 // resident at 3 per CU), as few fragment set-ups as that allows
-static int aa_tiles_per_wg(int64_t tiles) {
-  int64_t t = tiles / 3072;
+#ifndef ITTS_AA_MFMA_MAXC
+#define ITTS_AA_MFMA_MAXC 192    // build-time A/B: widest tensor the MFMA form of the activation takes
+#endif
+// Workgroups the MFMA form aims for: 3072 (four rounds of the 768 resident ones) at C <= 96; at C = 192 a batch element has only
+// 70 tiles per 48-channel slice, and twice the tiles per workgroup (1536 workgroups) amortise the tap-fragment set-up better:
+// 85 us against 94 for either form with 3072 (profiles/r04_act_variants.txt; C = 96: 150 / 163 / 179 us for 3072 / 1536 / 6144).
+static int aa_tiles_per_wg(int64_t tiles, int C) {
+  int64_t t = tiles / (C > 96 ? 1536 : 3072);
   return (int)(t < 1 ? 1 : t > 8 ? 8 : t);
 }
 
@@ -706,18 +712,18 @@ extern "C" int itts_aa_snake_fwd(const void* x, void* y, const float* alpha_log,
         ITTS_AA_BY_CS(bf16_t);
         break;
       case ITTS_F16:
-        if (ITTS_AA_F16_MFMA && C <= 96 && (int64_t)B * T >= 32768) {
+        if (ITTS_AA_F16_MFMA && C <= ITTS_AA_MFMA_MAXC && (int64_t)B * T >= 32768) {
           // Both FIRs on the matrix cores: 48-channel slices where the channel count allows, one 32-channel slice for C = 24.
           // Measured (batch 32, MI355X, us per launch, MFMA form | VALU form): C = 96: 163 | 207, C = 48: 151 | 193, C = 24: 166 |
-          // 191; C = 192: 97 | 96, C = 384: 56 | 46, C = 768: 37 | 27 (few rows per batch element: the per-workgroup set-up of
-          // the tap fragments is not amortised) -- hence the last three stages only.
+          // 191; C = 192: 97 | 96 (85 with twice the tiles per workgroup: round 4), C = 384: 56 | 46, C = 768: 37 | 27 (few rows per batch
+          // element: the per-workgroup set-up of the tap fragments is not amortised) -- hence the last four stages only.
           if (C % 48 == 0) {
             static std::once_flag once3;
             std::call_once(once3, [] {
               (void)hipFuncSetAttribute((const void*)aa_snake_mfma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AaMfma<3>::LDS);
             });
             const int nt = (T + AaMfma<3>::TT - 1) / AaMfma<3>::TT;
-            const int tpw = aa_tiles_per_wg((int64_t)nt * (C / 48) * B);
+            const int tpw = aa_tiles_per_wg((int64_t)nt * (C / 48) * B, C);
             dim3 g3((nt + tpw - 1) / tpw, C / 48, B);
             hipLaunchKernelGGL(aa_snake_mfma_kernel<3>, g3, block, AaMfma<3>::LDS, s, (const f16_t*)x, (f16_t*)y, alpha_log, beta_log, f, T, C, valid_rows, tpw);
           } else {
@@ -726,7 +732,7 @@ extern "C" int itts_aa_snake_fwd(const void* x, void* y, const float* alpha_log,
               (void)hipFuncSetAttribute((const void*)aa_snake_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AaMfma<2>::LDS);
             });
             const int nt = (T + AaMfma<2>::TT - 1) / AaMfma<2>::TT;
-            const int tpw = aa_tiles_per_wg((int64_t)nt * ((C + 31) / 32) * B);
+            const int tpw = aa_tiles_per_wg((int64_t)nt * ((C + 31) / 32) * B, C);
             dim3 g2((nt + tpw - 1) / tpw, (C + 31) / 32, B);
             hipLaunchKernelGGL(aa_snake_mfma_kernel<2>, g2, block, AaMfma<2>::LDS, s, (const f16_t*)x, (f16_t*)y, alpha_log, beta_log, f, T, C, valid_rows, tpw);
           }
