@@ -60,11 +60,15 @@ class PagedKV:
             sp = self.span[row] = [b0, b0]
         if b1 - sp[0] > KV_TAB - 1:
             raise ValueError(f"paged KV: row {row} would keep {(b1 - sp[0]) * self.bs} positions live (limit {self.window})")
-        while sp[1] < b1:
-            if not self.free:
+        need = b1 - sp[1]
+        if need > 0:
+            if need > len(self.free):
                 raise RuntimeError("paged KV: the block pool is exhausted")
-            self.tab_h[row, sp[1] & (KV_TAB - 1)] = self.free.pop()
-            sp[1] += 1
+            import numpy as np
+            ids = self.free[-need:][::-1]                   # the blocks pop() would hand out, in that order
+            del self.free[-need:]
+            self.tab_h[row, (np.arange(sp[1], b1) & (KV_TAB - 1))] = ids
+            sp[1] = b1
             self.dirty = True
 
     def release(self, row):
