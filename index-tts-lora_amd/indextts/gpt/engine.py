@@ -357,13 +357,25 @@ class GPTEngine:
     # ------------------------------------------------------------------------------------------------ big-M passes
     def _proj_ksplit(self, M):
         """Split-K factor for the two N = D projections of a big-M pass: their 128 x 128 output tiles number M/128 x 10 -- 160 at the
-        prefill's ~2 000 rows for 512 workgroup slots.  3 slices fill the chip; the slabs are summed by the LayerNorm launch that
+        prefill's ~2 000 rows.  2-4 slices fill the chip (the factor is chosen below); the slabs are summed by the LayerNorm launch that
         follows (itts_ln_reduce: residual + bias + slabs, then LN), which replaces the GEMM's residual epilogue AND the LayerNorm
         launch.  1 where the tiles alone already fill the slots (the latent pass)."""
         if self.dtype == torch.float32 or self.D % 256 or os.environ.get("ITTS_PREFILL_KSPLIT", "1") == "0":
             return 1
         tiles = ((M + 127) // 128) * (self.D // 128)
-        return 3 if tiles * 3 <= 540 else 2 if tiles * 2 <= 540 else 1
+        force = os.environ.get("ITTS_PREFILL_KS")          # measurement aid (tools/): a fixed factor
+        if force:
+            return max(1, int(force))
+        if tiles > 270:
+            return 1
+        # a CU's share of the work, in whole-K tile units: ceil(tiles x ks / 256 CUs) slices of 1 / ks each (the kernel is priced by the
+        # CU's load path, so two co-resident slices take twice one slice).  Config 3's prefill (M ~ 1 400: 110 tiles): ks = 2 -> 0.5
+        # against 0.67 for ks = 3 (74 CUs would hold two slices) and 1.0 unsplit: 4.2 -> 3.8 ms; M ~ 2 000 (160 tiles): ks = 3 -> 0.67
+        cus = 256
+        cost = lambda ks: -(-tiles * ks // cus) / ks                                  # noqa: E731
+        rule = 3 if tiles * 3 <= 540 else 2 if tiles * 2 <= 540 else 1               # round 3's choice (512 workgroup slots)
+        best = min((1, 2, 3), key=lambda ks: (cost(ks), ks))
+        return best if cost(best) < 0.9 * cost(rule) else rule
 
     def _big_m_layers(self, h, attn):
         """The 24 blocks over packed rows h fp32 [M, D] (in place): LayerNorm -> QKV -> attn(i, qkv, att) -> out-projection ->
