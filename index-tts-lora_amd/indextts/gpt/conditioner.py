@@ -1,6 +1,6 @@
 """Conformer + Perceiver conditioner on the HIP kernels: the prompt front-end of UnifiedVoice.get_conditioning.
 
-One prompt (mel [T, 100], no padding) -> conditioning latents [32, 1280], as ~75 launches of libindextts_hip.so instead of the
+One prompt (mel [T, 100], no padding) -> conditioning latents [32, 1280], as 72 launches of libindextts_hip.so instead of the
 ~250 library launches of the functional PyTorch form (conformer_encoder.py / perceiver.py in this package, which stay as the fp32
 parity mode and as the checker of this path).  Structure, all 16-bit storage (fp16 by default) with an fp32 residual stream:
 
