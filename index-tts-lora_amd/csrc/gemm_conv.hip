@@ -16,6 +16,9 @@
 
 namespace itts {
 
+#ifndef ITTS_NARROW_C96
+#define ITTS_NARROW_C96 1   // build-time A/B: the LDS-staged narrow kernel for C = 96, 3 taps (265 -> 236 us per layer, batch 32 x 35 840 rows)
+#endif
 constexpr int CV_MAX_HALO = 64;                 // (taps-1)*dil must not exceed this
 
 struct ConvParams {
@@ -1192,6 +1195,12 @@ static int dispatch_narrow(const ConvParams& p, hipStream_t s, bool& handled) {
     ITTS_NL_CASE(48, 4, 4, 8)       // C = 48: the same; 11 taps: 66 KB of weights -> one 8-wave workgroup per CU (2 row tiles per wave)
 #undef ITTS_NL_CASE
   }
+#if ITTS_NARROW_C96
+  // C = 96, 3 taps only (54 KB of weights; 7 taps would be 126 KB): bandwidth-shaped like the C = 48 layers
+  if constexpr (sizeof(T) == 2) if (g_conv_cfg != 30 && g_conv_cfg != 31 && p.Cin == 96 && p.N == 96 && p.taps == 3 && !p.y_f32 && p.bias2 == nullptr &&
+                                    p.act == 0 && ((p.N | p.y_shift | p.y_limit) & 3) == 0)
+    return launch_narrow_lds<T, 96, 3, 2, 8>(p, s);
+#endif
   if (g_conv_cfg != 30) {   // (diagnostic build: cfg 30 = the first form everywhere, for A/B runs)
 #define ITTS_NT_CASE(KT_, NT_, TM_, NW_)                                                               \
     if (kt == KT_ && nt == NT_ && p.taps == 3) return launch_narrow_taps<T, KT_, NT_, 3, TM_, NW_>(p, s);   \
@@ -1216,7 +1225,8 @@ static int dispatch_narrow(const ConvParams& p, hipStream_t s, bool& handled) {
 template <typename T>
 static int dispatch_conv(const ConvParams& p, hipStream_t s) {
   const bool plain = (p.taps == 1);  // GEMM: no halo, 4 k-steps per chunk
-  if (p.Cin <= 64 && p.N <= 64 && g_conv_cfg != 2 && (size_t)p.taps * p.NT * p.KT * 1024 <= 150 * 1024) {
+  if (((p.Cin <= 64 && p.N <= 64) || (ITTS_NARROW_C96 && p.Cin == 96 && p.N == 96 && p.taps == 3)) && g_conv_cfg != 2 &&
+      (size_t)p.taps * p.NT * p.KT * 1024 <= 150 * 1024) {
     bool handled;
     int rc = dispatch_narrow<T>(p, s, handled);
     if (handled) return rc;

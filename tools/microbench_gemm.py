@@ -64,6 +64,8 @@ bench("voc C192 k7 d1 T8960 B32", fh, 32, 8960, 192, 192, 7, 1)
 bench("voc C96 k7 d1 T35840 B32", fh, 32, 35840, 96, 96, 7, 1)
 bench("voc C48 k7 d1 T71680 B32", fh, 32, 71680, 48, 48, 7, 1)
 bench("voc C24 k7 d1 T143360 B32", fh, 32, 143360, 24, 24, 7, 1)
+for d in (1, 3, 5):                           # stage 3's k = 3 layers (candidates for the LDS-staged narrow kernel, ITTS_NARROW_C96)
+    bench(f"voc C96 k3 d{d} T35840 B32 +res", fh, 32, 35840, 96, 96, 3, d, resid=True)
 for C, T in ((48, 71680), (24, 143360)):     # the narrow layers of the last two stages, every (taps, dilation) class, with the residual epilogue
     for k, d in ((3, 1), (3, 5), (7, 1), (7, 5), (11, 1), (11, 5)):
         bench(f"narrow C{C} k{k} d{d} +res", fh, 32, T, C, C, k, d, resid=True)
