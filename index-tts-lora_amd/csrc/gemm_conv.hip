@@ -17,7 +17,7 @@
 namespace itts {
 
 #ifndef ITTS_NARROW_C96
-#define ITTS_NARROW_C96 1   // build-time A/B: the LDS-staged narrow kernel for C = 96, 3 taps (265 -> 236 us per layer, batch 32 x 35 840 rows)
+#define ITTS_NARROW_C96 1   // build-time A/B: the LDS-staged narrow kernel for C = 96, 3 taps (246-266 -> 198-219 us per layer at batch 32 x 35 840 rows; one row tile per wave, 8 waves: 2 or 4 row tiles per wave spill)
 #endif
 constexpr int CV_MAX_HALO = 64;                 // (taps-1)*dil must not exceed this
 
@@ -1199,7 +1199,7 @@ static int dispatch_narrow(const ConvParams& p, hipStream_t s, bool& handled) {
   // C = 96, 3 taps only (54 KB of weights; 7 taps would be 126 KB): bandwidth-shaped like the C = 48 layers
   if constexpr (sizeof(T) == 2) if (g_conv_cfg != 30 && g_conv_cfg != 31 && p.Cin == 96 && p.N == 96 && p.taps == 3 && !p.y_f32 && p.bias2 == nullptr &&
                                     p.act == 0 && ((p.N | p.y_shift | p.y_limit) & 3) == 0)
-    return launch_narrow_lds<T, 96, 3, 2, 8>(p, s);
+    return launch_narrow_lds<T, 96, 3, 1, 8>(p, s);
 #endif
   if (g_conv_cfg != 30) {   // (diagnostic build: cfg 30 = the first form everywhere, for A/B runs)
 #define ITTS_NT_CASE(KT_, NT_, TM_, NW_)                                                               \
