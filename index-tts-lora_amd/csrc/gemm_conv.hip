@@ -1001,7 +1001,7 @@ struct NarrowLds {
   static constexpr int CPR = DB / 16;                                      // 16-byte chunks per row
 };
 
-template <typename T, int CIN, int TAPS, int TM, int NW>
+template <typename T, int CIN, int TAPS, int TM, int NW, int MAXH = CV_MAX_HALO>   // MAXH: largest (taps - 1) * dil the row tile is sized for
 __global__ __launch_bounds__(NW * 64, 2)
 void conv_narrow_lds_kernel(ConvParams p) {
   typedef Elem<T> EL;
@@ -1009,7 +1009,7 @@ void conv_narrow_lds_kernel(ConvParams p) {
   constexpr int KS = EL::KS, ES = (int)sizeof(T), BM = NW * TM * 16, NTH = NW * 64;
   constexpr int KT = (CIN + KS - 1) / KS, NT = (CIN + 15) / 16;
   constexpr int WB = TAPS * NT * KT * 1024;
-  constexpr int MAXROWS = BM + CV_MAX_HALO + 1;
+  constexpr int MAXROWS = BM + MAXH + 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1140,7 +1140,7 @@ void conv_narrow_lds_kernel(ConvParams p) {
   }
 }
 
-template <typename T, int CIN, int TAPS, int TM, int NW>
+template <typename T, int CIN, int TAPS, int TM, int NW, int MAXH = CV_MAX_HALO>
 static int launch_narrow_lds(const ConvParams& p, hipStream_t s) {
   constexpr int BM = NW * TM * 16, ES = (int)sizeof(T), KS = Elem<T>::KS;
   constexpr int KT = (CIN + KS - 1) / KS, NT = (CIN + 15) / 16;
@@ -1149,10 +1149,11 @@ static int launch_narrow_lds(const ConvParams& p, hipStream_t s) {
   q.NB = 1;
   q.GM = 1;
   const int64_t tiles = (int64_t)q.MB * p.B;
-  constexpr size_t ldsb = (size_t)TAPS * NT * KT * 1024 + (size_t)(BM + CV_MAX_HALO + 1) * NarrowLds<CIN, ES>::RSB;
+  constexpr size_t ldsb = (size_t)TAPS * NT * KT * 1024 + (size_t)(BM + MAXH + 1) * NarrowLds<CIN, ES>::RSB;
+  static_assert(ldsb <= 160 * 1024 - 256, "conv_narrow_lds: weights + row tile exceed the LDS");
   static std::once_flag attr;
   std::call_once(attr, [] {
-    (void)hipFuncSetAttribute((const void*)conv_narrow_lds_kernel<T, CIN, TAPS, TM, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)conv_narrow_lds_kernel<T, CIN, TAPS, TM, NW, MAXH>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024 - 256);
     (void)hipGetLastError();
   });
@@ -1160,7 +1161,7 @@ static int launch_narrow_lds(const ConvParams& p, hipStream_t s) {
   static thread_local int occ_wgs = 1;
   if (occ_lds != ldsb) {
     int q_wgs = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q_wgs, (const void*)conv_narrow_lds_kernel<T, CIN, TAPS, TM, NW>, NW * 64, ldsb) !=
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q_wgs, (const void*)conv_narrow_lds_kernel<T, CIN, TAPS, TM, NW, MAXH>, NW * 64, ldsb) !=
             hipSuccess || q_wgs < 1)
       q_wgs = 1;
     (void)hipGetLastError();
@@ -1169,7 +1170,7 @@ static int launch_narrow_lds(const ConvParams& p, hipStream_t s) {
   }
   int64_t grid = (int64_t)conv_num_cus() * occ_wgs;
   if (grid > tiles) grid = tiles;
-  hipLaunchKernelGGL((conv_narrow_lds_kernel<T, CIN, TAPS, TM, NW>), dim3((unsigned)grid), dim3(NW * 64), ldsb, s, q);
+  hipLaunchKernelGGL((conv_narrow_lds_kernel<T, CIN, TAPS, TM, NW, MAXH>), dim3((unsigned)grid), dim3(NW * 64), ldsb, s, q);
   return check_launch("itts_gemm_conv");
 }
 
@@ -1200,6 +1201,10 @@ static int dispatch_narrow(const ConvParams& p, hipStream_t s, bool& handled) {
   if constexpr (sizeof(T) == 2) if (g_conv_cfg != 30 && g_conv_cfg != 31 && p.Cin == 96 && p.N == 96 && p.taps == 3 && !p.y_f32 && p.bias2 == nullptr &&
                                     p.act == 0 && ((p.N | p.y_shift | p.y_limit) & 3) == 0)
     return launch_narrow_lds<T, 96, 3, 1, 8>(p, s);
+  // ... and 7 taps with the row tile sized for the vocoder's dilations (halo <= 30 rows): 126 KB of weights + 159 rows = 158 KB
+  if constexpr (sizeof(T) == 2) if (g_conv_cfg != 30 && g_conv_cfg != 31 && p.Cin == 96 && p.N == 96 && p.taps == 7 && 6 * p.dil <= 30 && !p.y_f32 &&
+                                    p.bias2 == nullptr && p.act == 0 && ((p.N | p.y_shift | p.y_limit) & 3) == 0)
+    return launch_narrow_lds<T, 96, 7, 1, 8, 30>(p, s);
 #endif
   if (g_conv_cfg != 30) {   // (diagnostic build: cfg 30 = the first form everywhere, for A/B runs)
 #define ITTS_NT_CASE(KT_, NT_, TM_, NW_)                                                               \
@@ -1225,8 +1230,8 @@ static int dispatch_narrow(const ConvParams& p, hipStream_t s, bool& handled) {
 template <typename T>
 static int dispatch_conv(const ConvParams& p, hipStream_t s) {
   const bool plain = (p.taps == 1);  // GEMM: no halo, 4 k-steps per chunk
-  if (((p.Cin <= 64 && p.N <= 64) || (ITTS_NARROW_C96 && p.Cin == 96 && p.N == 96 && p.taps == 3)) && g_conv_cfg != 2 &&
-      (size_t)p.taps * p.NT * p.KT * 1024 <= 150 * 1024) {
+  if (((p.Cin <= 64 && p.N <= 64) || (ITTS_NARROW_C96 && p.Cin == 96 && p.N == 96 && (p.taps == 3 || p.taps == 7))) && g_conv_cfg != 2 &&
+      (size_t)p.taps * p.NT * p.KT * 1024 <= 150 * 1024) {   // (C = 96, 7 taps: 126 KB)
     bool handled;
     int rc = dispatch_narrow<T>(p, s, handled);
     if (handled) return rc;

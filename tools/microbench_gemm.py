@@ -69,3 +69,7 @@ for d in (1, 3, 5):                           # stage 3's k = 3 layers (candidat
 for C, T in ((48, 71680), (24, 143360)):     # the narrow layers of the last two stages, every (taps, dilation) class, with the residual epilogue
     for k, d in ((3, 1), (3, 5), (7, 1), (7, 5), (11, 1), (11, 5)):
         bench(f"narrow C{C} k{k} d{d} +res", fh, 32, T, C, C, k, d, resid=True)
+if os.environ.get("MB_VOC_ALL"):              # every (taps, dilation) class of the four wide stages, with the residual epilogue
+    for C, T in ((96, 35840), (192, 8960), (384, 2240), (768, 560)):
+        for k, d in ((3, 1), (3, 5), (7, 1), (7, 5), (11, 1), (11, 5)):
+            bench(f"stage C{C} k{k} d{d} +res", fh, 32, T, C, C, k, d, resid=True)
