@@ -108,7 +108,9 @@ __device__ __forceinline__ f16x8 aa_tr_frag(const f16_t* img, int row0, int col0
   return __builtin_bit_cast(f16x8, both);
 }
 
-template <int NCB>
+// PAIR (C = 24 only, dense batches): the 48-channel slice holds the 24 channels of TWO batch elements side by side (b = 2 z, 2 z + 1:
+// same rows, same filters) -- three full 16-channel MFMA blocks instead of 2 x (one full + one half-empty) blocks.
+template <int NCB, bool PAIR = false>
 __global__ __launch_bounds__(256) void aa_snake_mfma_kernel(const f16_t* __restrict__ x, f16_t* __restrict__ y,
                                                              const float* __restrict__ alpha_log,
                                                              const float* __restrict__ beta_log, Fir24 f, int T_full, int C,
@@ -120,11 +122,11 @@ __global__ __launch_bounds__(256) void aa_snake_mfma_kernel(const f16_t* __restr
   f16_t* Xi = reinterpret_cast<f16_t*>(aa_lds);          // [XR][RS]
   f16_t* Si = Xi + XR * RS;                              // [SR][RS]
   __shared__ float taps[24];
-  const int c0 = blockIdx.y * CS;
-  const int b = blockIdx.z;
+  const int c0 = PAIR ? 0 : blockIdx.y * CS;
+  const int b = PAIR ? 2 * (int)blockIdx.z : (int)blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, r = lane & 15;
-  const int T_len = valid_rows != nullptr ? min(max(valid_rows[b], 0), T_full) : T_full;
+  const int T_len = (!PAIR && valid_rows != nullptr) ? min(max(valid_rows[b], 0), T_full) : T_full;
   if ((int)blockIdx.x * tiles_per_wg * TT >= T_len) return;
   const f16_t* xb = x + (int64_t)b * T_full * C;
   f16_t* yb = y + (int64_t)b * T_full * C;
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void aa_snake_mfma_kernel(const f16_t* __restr
   for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int ch = min(c0 + 16 * cb + 4 * g + e, C - 1);
+      const int ch = PAIR ? (16 * cb + 4 * g + e) % 24 : min(c0 + 16 * cb + 4 * g + e, C - 1);
       ca[cb][e] = __expf(alpha_log[ch]) * 0.15915494309189535f;    // e^alpha / (2 pi): v_sin_f32 takes revolutions
       cbv[cb][e] = __frcp_rn(__expf(beta_log[ch]) + 1e-9f);
     }
@@ -177,8 +179,9 @@ __global__ __launch_bounds__(256) void aa_snake_mfma_kernel(const f16_t* __restr
   constexpr int RPP = 256 / C4;                 // rows per pass of the workgroup (RPP * C4 threads take part)
   constexpr int NP = (XR + RPP - 1) / RPP;
   const int pr = tid / C4, pc4 = tid - pr * C4;
-  const bool pact = pr < RPP && c0 + pc4 * 4 < C;
-  const f16_t* xc = xb + c0 + pc4 * 4;
+  const bool pact = pr < RPP && (PAIR || c0 + pc4 * 4 < C);
+  // PAIR: channel quads 0..5 are element b's, 6..11 element b + 1's
+  const f16_t* xc = PAIR ? xb + (int64_t)(pc4 >= 6) * T_full * C + (pc4 % 6) * 4 : xb + c0 + pc4 * 4;
   h4 xv[NP];
   auto request = [&](const int t0r) {
 #pragma unroll
@@ -266,9 +269,10 @@ __global__ __launch_bounds__(256) void aa_snake_mfma_kernel(const f16_t* __restr
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(s1[cb], wd_lo[1], acc, 0, 0, 0);
       // lane (g, r): channels 16 cb + 4g .. +3 of output row t0 + 16 yb + r
       const int ch = c0 + 16 * cb + 4 * g;
-      if (t < T_len && ch < C) {
+      if (PAIR ? t < T_len : (t < T_len && ch < C)) {
         h4 o = {(f16_t)acc[0], (f16_t)acc[1], (f16_t)acc[2], (f16_t)acc[3]};
-        *reinterpret_cast<h4*>(yb + (int64_t)t * C + ch) = o;
+        if constexpr (PAIR) *reinterpret_cast<h4*>(yb + (int64_t)(ch >= 24) * T_full * C + (int64_t)t * C + ch % 24) = o;
+        else *reinterpret_cast<h4*>(yb + (int64_t)t * C + ch) = o;
       }
     }
   }
@@ -664,6 +668,9 @@ using namespace itts;
 
 // consecutive tiles one workgroup of the MFMA activation walks: enough workgroups to fill the chip several times over (768
 // resident at 3 per CU), as few fragment set-ups as that allows
+#ifndef ITTS_AA_PAIR24
+#define ITTS_AA_PAIR24 1         // build-time A/B: C = 24 with two batch elements per 48-channel slice
+#endif
 #ifndef ITTS_AA_MFMA_MAXC
 #define ITTS_AA_MFMA_MAXC 192    // build-time A/B: widest tensor the MFMA form of the activation takes
 #endif
@@ -726,6 +733,16 @@ extern "C" int itts_aa_snake_fwd(const void* x, void* y, const float* alpha_log,
             const int tpw = aa_tiles_per_wg((int64_t)nt * (C / 48) * B, C);
             dim3 g3((nt + tpw - 1) / tpw, C / 48, B);
             hipLaunchKernelGGL(aa_snake_mfma_kernel<3>, g3, block, AaMfma<3>::LDS, s, (const f16_t*)x, (f16_t*)y, alpha_log, beta_log, f, T, C, valid_rows, tpw);
+          } else if (C == 24 && valid_rows == nullptr && B % 2 == 0 && ITTS_AA_PAIR24) {
+            // C = 24, dense batch: two batch elements share a 48-channel slice (3 full MFMA blocks instead of 2 x 1.5)
+            static std::once_flag once3p;
+            std::call_once(once3p, [] {
+              (void)hipFuncSetAttribute((const void*)aa_snake_mfma_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AaMfma<3>::LDS);
+            });
+            const int nt = (T + AaMfma<3>::TT - 1) / AaMfma<3>::TT;
+            const int tpw = aa_tiles_per_wg((int64_t)nt * (B / 2), C);
+            dim3 g3((nt + tpw - 1) / tpw, 1, B / 2);
+            hipLaunchKernelGGL((aa_snake_mfma_kernel<3, true>), g3, block, AaMfma<3>::LDS, s, (const f16_t*)x, (f16_t*)y, alpha_log, beta_log, f, T, C, valid_rows, tpw);
           } else {
             static std::once_flag once2;
             std::call_once(once2, [] {

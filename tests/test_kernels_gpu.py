@@ -1101,3 +1101,24 @@ def test_attn_prefill_packed_equals_left_padded(nat, dtype):
     for b in range(B):
         assert torch.equal(kc[b, :, pads[b]:S], kc_ref[b, :, pads[b]:S]) and torch.equal(vc[b, :, pads[b]:S], vc_ref[b, :, pads[b]:S])
         assert kc[b, :, :pads[b]].abs().max().item() == 0 if pads[b] else True
+
+
+def test_aa_snake_c24_pairs_batch_elements_same_bits():
+    """fp16, C = 24, dense even batch: two batch elements share one 48-channel slice of the MFMA activation; every channel's FIR
+    sums are its own, so the result equals, bit for bit, the single-element form (odd batch: one 32-channel slice per element)."""
+    from indextts import _native as nat
+    from indextts.BigVGAN.models import kaiser_sinc_filter
+    T, C = 36000, 24
+    g = torch.Generator().manual_seed(24)
+    x = (torch.randn(4, T, C, generator=g) * 0.9).to(DEV).half()
+    al, be = (torch.randn(C, generator=g) * 0.3).to(DEV), (torch.randn(C, generator=g) * 0.3).to(DEV)
+    f = kaiser_sinc_filter()
+    paired = torch.empty_like(x)
+    nat.aa_snake(x, al, be, f, f, layout=0, out=paired)                      # B = 4: pairs (0, 1), (2, 3)
+    for b in range(4):
+        one = torch.empty(1, T, C, dtype=torch.float16, device=DEV)
+        nat.aa_snake(x[b:b + 1].contiguous(), al, be, f, f, layout=0, out=one)   # B = 1: the unpaired form
+        assert torch.equal(one[0], paired[b]), b
+    ragged = torch.zeros_like(x)
+    nat.aa_snake(x, al, be, f, f, layout=0, out=ragged, valid_rows=torch.tensor([T, 100, T, 20000], dtype=torch.int32, device=DEV))
+    assert torch.equal(ragged[0], paired[0]) and torch.equal(ragged[2], paired[2])   # (a ragged batch takes the unpaired form)
